@@ -1,0 +1,143 @@
+/*
+ * l4p_hip.h — C ABI of libl4p_hip.so: the MI355X (gfx950) engine behind the L4P inference hot path.
+ *
+ * This is the drop-in boundary.  The reference (NVlabs/L4P) is pure Python/PyTorch with no native
+ * layer, so there is no FFI to mirror one-to-one: each entry point below replaces the ATen/cuDNN
+ * work done by a specific reference function (cited per entry as file:line relative to the
+ * reference tree).  The Python host (package l4p_amd, same class / argument names as the
+ * reference's l4p.l4p.L4PLitModule, l4p.models.*) binds these symbols with ctypes; INTEGRATION.md
+ * shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer named *dev* / every tensor argument is a DEVICE
+ *    pointer owned by the caller (the Python host allocates with torch and passes data_ptr()).
+ *  - every function returns 0 on success, a negative L4P_E_* code otherwise; the message is
+ *    available through l4p_last_error() (thread-local).  No C++ exception crosses this boundary.
+ *  - all work is enqueued asynchronously on the caller-supplied HIP stream (l4p_stream ==
+ *    hipStream_t, NULL = default stream).  No hidden synchronisation, no allocation.
+ *  - dtype selects the arithmetic/storage type T of activations and weights: L4P_BF16 (bf16 storage,
+ *    bf16 MFMA, f32 accumulate; residual stream, LayerNorm and softmax statistics always f32) or
+ *    L4P_F32 (f32 storage, exact-f32 MFMA) — the parity mode.
+ */
+#ifndef L4P_HIP_H
+#define L4P_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L4P_BF16 0
+#define L4P_F32 1
+
+#define L4P_OK 0
+#define L4P_E_INVALID (-1) /* bad argument / unsupported shape */
+#define L4P_E_HIP (-2)     /* a HIP runtime call failed */
+#define L4P_E_MISSING (-3) /* a required weight was never bound */
+
+typedef void* l4p_stream; /* hipStream_t */
+typedef struct l4p_engine l4p_engine;
+
+const char* l4p_last_error(void);
+int l4p_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel-level entry points (also the unit-parity surface of tests/).
+ * ---------------------------------------------------------------------------------------------- */
+
+#define L4P_EPI_DENSE 0
+#define L4P_EPI_QKV 1
+#define L4P_EPI_CONVT 2
+#define L4P_ACT_NONE 0
+#define L4P_ACT_GELU 1
+#define L4P_ACT_RELU 2
+
+/* out[m][n] = epilogue( sum_k A[m][k] * W[n][k] ), both operands k-contiguous.
+ * Replaces F.linear / nn.Linear (modeling_finetune.py:57-68,176,188; sam/transformer.py:215-218,
+ * 225-228; mask_decoder.py:160-180), nn.Conv3d 1x1x1 (dpt_block.py:447-507,218-227),
+ * nn.ConvTranspose3d with kernel == stride (dpt_block.py:255-265; mask_decoder.py:58-66) and,
+ * through l4p_conv3d_k3, nn.Conv3d 3x3x3 (dpt_block.py:44-79,110-129,266-276,406-414). */
+typedef struct l4p_gemm_desc {
+    const void* A; /* [M][lda] T (dense) or channels-last conv input [B][Ti][Hi][Wi][Cin] T */
+    long long lda;
+    const void* W; /* [ceil(N/128)*128][ldw] T, rows >= N are zero */
+    long long ldw;
+    int M, N, K;
+    /* conv3d k=3 pad=1 (l4p_conv3d_k3 only): M = B*To*Ho*Wo, K = 27*Cin, k = tap*Cin + c */
+    int Ti, Hi, Wi, Cin, To, Ho, Wo, st, sh, sw, relu_in;
+    /* epilogue: v = acc + bias[n]; v = act(v); v += res1[m][n] (+ res2[m][n]); store */
+    const float* bias;
+    int act;
+    const void* res1;
+    const void* res2;
+    int res_f32;   /* residual element type: 1 float, 0 T */
+    long long ldr; /* residual row stride (elements) */
+    int res_mod;   /* > 0: residual row is m % res_mod (broadcast table, e.g. the pos-embed) */
+    float* out_f32; /* optional float output  [M][ldc] */
+    void* out_T;    /* optional T output      [M][ldc] */
+    long long ldc;
+    int epi;
+    /* L4P_EPI_QKV: n < 2*H*Dp -> out_T[m][n] (q|k, ldc = 2*H*Dp); n >= 2*H*Dp -> vt[b][h][d][s] */
+    void* vt;
+    int S, H, Dp;
+    /* L4P_EPI_CONVT: n = tap*Cout + co, tap = (dt*kh + dh)*kw + dw; A rows are the (Ti,Hi,Wi) grid;
+     * output is channels-last [B][Ti*kt][Hi*kh][Wi*kw][Cout] */
+    int kt, kh, kw, Cout;
+} l4p_gemm_desc;
+
+int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
+int l4p_conv3d_k3(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
+
+/* Row LayerNorm of a float [M][C] stream -> T and/or float.  Replaces nn.LayerNorm
+ * (modeling_finetune.py:212,235; l4p_videomae.py:115,177; sam/transformer.py:143-153) and
+ * LayerNorm3d over channels-last data (mask_decoder.py:145-157). */
+int l4p_layernorm(l4p_stream stream, int dtype, const float* x, const float* gamma, const float* beta, float eps,
+                  void* out_T, float* out_f32, int M, int C);
+
+/* Fused softmax(q k^T * scale) v for the encoder (modeling_finetune.py:180-186).
+ * qk: [B][S][2][H][96] T, vt: [B][H][96][S] T (both written by L4P_EPI_QKV), out: [B*S][H*Dh] T. */
+int l4p_attention(l4p_stream stream, int dtype, const void* qk, const void* vt, void* out, int B, int S, int H, int Dh,
+                  float scale);
+
+/* Tubelet gather of PatchEmbed's Conv3d(kernel=stride) (modeling_finetune.py:269-283):
+ * rgb [B][Cin][T][H][W] float -> out [B*nT*nH*nW][Kp] T, zero-padded columns >= Cin*pt*ph*pw. */
+int l4p_patch_gather(l4p_stream stream, int dtype, const float* rgb, void* out, int B, int Cin, int T, int H, int W,
+                     int pt, int ph, int pw, int Kp);
+
+int l4p_cast(l4p_stream stream, int dtype, const float* x, void* y, long long n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Engine: holds the table of packed device weights and runs whole sub-networks with one call.
+ * ---------------------------------------------------------------------------------------------- */
+
+int l4p_create(int device, int dtype, l4p_engine** out);
+int l4p_destroy(l4p_engine* e);
+
+/* Register a packed weight that lives in caller-owned device memory (the Python host packs the
+ * reference state_dict — models/utils.py:52-53 — into kernel layouts and keeps the arena alive). */
+int l4p_bind_weight(l4p_engine* e, const char* name, const void* dev_ptr, long long numel);
+
+typedef struct l4p_encoder_cfg {
+    int dim, depth, heads, head_dim, mlp_hidden;
+    int in_chans, frames, img_h, img_w, pt, ph, pw; /* tubelet */
+    int patch_kp;                                    /* padded gather width (multiple of 64) */
+    float ln_eps;
+} l4p_encoder_cfg;
+
+int l4p_encoder_configure(l4p_engine* e, const l4p_encoder_cfg* cfg);
+size_t l4p_encoder_workspace_bytes(const l4p_engine* e, int B);
+
+/* VideoMAEEncoder.forward (l4p_videomae.py:80-122): patch embed + sinusoid pos + `depth` pre-LN
+ * blocks + final norm.  The reference returns all depth+1 features; here the caller names the taps
+ * it wants: tap_layer[i] in [0, depth] (0 = embeddings, k = after k blocks, depth = norm(x_depth)),
+ * written as float to tap_f32[i] and/or as T to tap_T[i] (either may be NULL), each [B*tokens][dim].
+ * Blocks after the highest requested tap are not executed. */
+int l4p_encoder_forward(l4p_engine* e, l4p_stream stream, const float* rgb, int B, void* workspace, size_t ws_bytes,
+                        int n_taps, const int* tap_layer, float* const* tap_f32, void* const* tap_T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L4P_HIP_H */

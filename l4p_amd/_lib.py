@@ -1,0 +1,102 @@
+"""ctypes binding of libl4p_hip.so (C ABI declared in include/l4p_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C l4p_amd/csrc`` into
+``l4p_amd/lib/``.  There is no fallback: if the shared object is missing or a symbol cannot be
+resolved, importing the engine raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+L4P_BF16 = 0
+L4P_F32 = 1
+
+EPI_DENSE, EPI_QKV, EPI_CONVT = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libl4p_hip.so")
+
+
+class GemmDesc(C.Structure):
+    """Mirror of ``l4p_gemm_desc`` (include/l4p_hip.h) — field order and types must match."""
+
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_longlong),
+        ("W", C.c_void_p), ("ldw", C.c_longlong),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("Ti", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int), ("Cin", C.c_int),
+        ("To", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+        ("st", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("relu_in", C.c_int),
+        ("bias", C.c_void_p), ("act", C.c_int),
+        ("res1", C.c_void_p), ("res2", C.c_void_p), ("res_f32", C.c_int),
+        ("ldr", C.c_longlong), ("res_mod", C.c_int),
+        ("out_f32", C.c_void_p), ("out_T", C.c_void_p), ("ldc", C.c_longlong),
+        ("epi", C.c_int),
+        ("vt", C.c_void_p), ("S", C.c_int), ("H", C.c_int), ("Dp", C.c_int),
+        ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("Cout", C.c_int),
+    ]
+
+
+class EncoderCfg(C.Structure):
+    """Mirror of ``l4p_encoder_cfg``."""
+
+    _fields_ = [
+        ("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("mlp_hidden", C.c_int),
+        ("in_chans", C.c_int), ("frames", C.c_int), ("img_h", C.c_int), ("img_w", C.c_int),
+        ("pt", C.c_int), ("ph", C.c_int), ("pw", C.c_int),
+        ("patch_kp", C.c_int), ("ln_eps", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/l4p_hip.h declares must appear here
+_VP, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+SIGNATURES = {
+    "l4p_last_error": (C.c_char_p, []),
+    "l4p_abi_version": (_I, []),
+    "l4p_gemm": (_I, [_VP, _I, C.POINTER(GemmDesc)]),
+    "l4p_conv3d_k3": (_I, [_VP, _I, C.POINTER(GemmDesc)]),
+    "l4p_layernorm": (_I, [_VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I]),
+    "l4p_attention": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _F]),
+    "l4p_patch_gather": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "l4p_cast": (_I, [_VP, _I, _VP, _VP, _LL]),
+    "l4p_create": (_I, [_I, _I, C.POINTER(_VP)]),
+    "l4p_destroy": (_I, [_VP]),
+    "l4p_bind_weight": (_I, [_VP, C.c_char_p, _VP, _LL]),
+    "l4p_encoder_configure": (_I, [_VP, C.POINTER(EncoderCfg)]),
+    "l4p_encoder_workspace_bytes": (_SZ, [_VP, _I]),
+    "l4p_encoder_forward": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _I, C.POINTER(_I), C.POINTER(_VP), C.POINTER(_VP)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class L4PHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libl4p_hip.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise L4PHipError(
+            f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C l4p_amd/csrc`. There is no CPU/eager fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().l4p_last_error().decode("utf-8", "replace")
+        raise L4PHipError(f"{what or 'l4p_hip call'} failed (rc={rc}): {msg}")

@@ -1,0 +1,337 @@
+// C ABI of libl4p_hip.so (see include/l4p_hip.h): error plumbing, kernel-level entry points and the
+// engine that runs the encoder with a single call.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "engine.hpp"
+
+static thread_local char g_err[512] = "";
+
+void l4p_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* l4p_last_error(void) { return g_err; }
+int l4p_abi_version(void) { return 1; }
+
+int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d) {
+    if (!d) {
+        l4p_set_error("l4p_gemm: null descriptor");
+        return L4P_E_INVALID;
+    }
+    return launch_gemm(dtype, 0, *d, (hipStream_t)stream);
+}
+int l4p_conv3d_k3(l4p_stream stream, int dtype, const l4p_gemm_desc* d) {
+    if (!d) {
+        l4p_set_error("l4p_conv3d_k3: null descriptor");
+        return L4P_E_INVALID;
+    }
+    return launch_gemm(dtype, 1, *d, (hipStream_t)stream);
+}
+int l4p_layernorm(l4p_stream stream, int dtype, const float* x, const float* gamma, const float* beta, float eps,
+                  void* out_T, float* out_f32, int M, int C) {
+    return launch_layernorm(dtype, x, gamma, beta, eps, out_T, out_f32, M, C, (hipStream_t)stream);
+}
+int l4p_attention(l4p_stream stream, int dtype, const void* qk, const void* vt, void* out, int B, int S, int H, int Dh,
+                  float scale) {
+    return launch_attention(dtype, qk, vt, out, B, S, H, Dh, scale, (hipStream_t)stream);
+}
+int l4p_patch_gather(l4p_stream stream, int dtype, const float* rgb, void* out, int B, int Cin, int T, int H, int W,
+                     int pt, int ph, int pw, int Kp) {
+    return launch_patch_gather(dtype, rgb, out, B, Cin, T, H, W, pt, ph, pw, Kp, (hipStream_t)stream);
+}
+int l4p_cast(l4p_stream stream, int dtype, const float* x, void* y, long long n) {
+    return launch_cast(dtype, x, y, n, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------------
+int l4p_create(int device, int dtype, l4p_engine** out) {
+    if (!out || (dtype != L4P_BF16 && dtype != L4P_F32)) {
+        l4p_set_error("l4p_create: bad arguments");
+        return L4P_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    l4p_engine* e = new l4p_engine();
+    e->device = device;
+    e->dtype = dtype;
+    *out = e;
+    return 0;
+}
+int l4p_destroy(l4p_engine* e) {
+    delete e;
+    return 0;
+}
+int l4p_bind_weight(l4p_engine* e, const char* name, const void* dev_ptr, long long numel) {
+    if (!e || !name || !dev_ptr) {
+        l4p_set_error("l4p_bind_weight: null argument");
+        return L4P_E_INVALID;
+    }
+    e->w[name] = Weight{dev_ptr, numel};
+    return 0;
+}
+
+int l4p_encoder_configure(l4p_engine* e, const l4p_encoder_cfg* c) {
+    if (!e || !c) {
+        l4p_set_error("l4p_encoder_configure: null argument");
+        return L4P_E_INVALID;
+    }
+    const int tokens = (c->frames / c->pt) * (c->img_h / c->ph) * (c->img_w / c->pw);
+    if (c->heads * c->head_dim != c->dim || c->head_dim > 96 || c->head_dim % 4 || tokens % 128 || c->dim % 8 ||
+        c->mlp_hidden % 8 || c->patch_kp % 8 || c->patch_kp < c->in_chans * c->pt * c->ph * c->pw) {
+        l4p_set_error("l4p_encoder_configure: unsupported geometry (dim=%d heads=%d head_dim=%d tokens=%d)", c->dim,
+                      c->heads, c->head_dim, tokens);
+        return L4P_E_INVALID;
+    }
+    e->enc = *c;
+    e->enc_tokens = tokens;
+    e->enc_set = true;
+    return 0;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct EncWs {
+    float* x;
+    char *xn, *qk, *vt, *ao, *hb;
+    size_t total;
+};
+static EncWs enc_layout(const l4p_engine* e, int B, char* base) {
+    const l4p_encoder_cfg& c = e->enc;
+    const size_t es = e->dtype == L4P_BF16 ? 2 : 4;
+    const size_t M = (size_t)B * e->enc_tokens;
+    const size_t wide = (size_t)(c.dim > c.patch_kp ? c.dim : c.patch_kp);
+    EncWs w;
+    size_t off = 0;
+    w.x = (float*)(base + off);
+    off += align256(M * c.dim * 4);
+    w.xn = base + off;
+    off += align256(M * wide * es);
+    w.qk = base + off;
+    off += align256(M * 2 * c.heads * 96 * es);
+    w.vt = base + off;
+    off += align256(M * c.heads * 96 * es);
+    w.ao = base + off;
+    off += align256(M * c.dim * es);
+    w.hb = base + off;
+    off += align256(M * c.mlp_hidden * es);
+    w.total = off;
+    return w;
+}
+
+size_t l4p_encoder_workspace_bytes(const l4p_engine* e, int B) {
+    if (!e || !e->enc_set || B <= 0) return 0;
+    return enc_layout(e, B, nullptr).total;
+}
+
+#define GETW(var, key)                                                  \
+    const void* var = e->find(key);                                     \
+    if (!var) {                                                         \
+        l4p_set_error("weight '%s' was never bound", std::string(key).c_str()); \
+        return L4P_E_MISSING;                                           \
+    }
+
+int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int B, void* workspace, size_t ws_bytes,
+                        int n_taps, const int* tap_layer, float* const* tap_f32, void* const* tap_T) {
+    if (!e || !e->enc_set || !rgb || !workspace || B <= 0 || n_taps <= 0) {
+        l4p_set_error("l4p_encoder_forward: bad arguments");
+        return L4P_E_INVALID;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const l4p_encoder_cfg& c = e->enc;
+    const int dt = e->dtype;
+    const size_t es = dt == L4P_BF16 ? 2 : 4;
+    const int S = e->enc_tokens, M = B * S, C = c.dim, H = c.heads, Dh = c.head_dim, Dp = 96;
+    EncWs w = enc_layout(e, B, (char*)workspace);
+    if (ws_bytes < w.total) {
+        l4p_set_error("l4p_encoder_forward: workspace too small (%zu < %zu)", ws_bytes, w.total);
+        return L4P_E_INVALID;
+    }
+    int last = 0;
+    for (int i = 0; i < n_taps; ++i) {
+        if (tap_layer[i] < 0 || tap_layer[i] > c.depth) {
+            l4p_set_error("l4p_encoder_forward: tap layer %d out of range", tap_layer[i]);
+            return L4P_E_INVALID;
+        }
+        if (tap_layer[i] > last) last = tap_layer[i];
+    }
+    int rc;
+    auto emit_taps = [&](int layer) -> int {
+        for (int i = 0; i < n_taps; ++i) {
+            if (tap_layer[i] != layer) continue;
+            if (layer == c.depth) {
+                // features_list[-1] = norm(x)  (l4p_videomae.py:115)
+                const void* g = e->find("enc.norm.g");
+                const void* b = e->find("enc.norm.b");
+                if (!g || !b) {
+                    l4p_set_error("weight 'enc.norm.*' was never bound");
+                    return L4P_E_MISSING;
+                }
+                int r = launch_layernorm(dt, w.x, (const float*)g, (const float*)b, c.ln_eps, tap_T ? tap_T[i] : nullptr,
+                                         tap_f32 ? tap_f32[i] : nullptr, M, C, stream);
+                if (r) return r;
+            } else {
+                if (tap_f32 && tap_f32[i]) {
+                    hipError_t he = hipMemcpyAsync(tap_f32[i], w.x, (size_t)M * C * 4, hipMemcpyDeviceToDevice, stream);
+                    if (he != hipSuccess) {
+                        l4p_set_error("tap copy failed: %s", hipGetErrorString(he));
+                        return L4P_E_HIP;
+                    }
+                }
+                if (tap_T && tap_T[i]) {
+                    int r = launch_cast(dt, w.x, tap_T[i], (long long)M * C, stream);
+                    if (r) return r;
+                }
+            }
+        }
+        return 0;
+    };
+
+    // ---- patch embed: gather -> GEMM (+bias, + fixed sinusoid table)   modeling_finetune.py:276-283,
+    //      l4p_videomae.py:99-101
+    {
+        GETW(pw_, "enc.patch.w");
+        GETW(pb_, "enc.patch.b");
+        GETW(pos_, "enc.pos");
+        rc = launch_patch_gather(dt, rgb, w.xn, B, c.in_chans, c.frames, c.img_h, c.img_w, c.pt, c.ph, c.pw, c.patch_kp,
+                                 stream);
+        if (rc) return rc;
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.A = w.xn;
+        p.lda = c.patch_kp;
+        p.W = pw_;
+        p.ldw = c.patch_kp;
+        p.M = M;
+        p.N = C;
+        p.K = c.patch_kp;
+        p.bias = (const float*)pb_;
+        p.res1 = pos_;
+        p.res_f32 = 1;
+        p.ldr = C;
+        p.res_mod = S;
+        p.out_f32 = w.x;
+        p.ldc = C;
+        rc = launch_gemm(dt, 0, p, stream);
+        if (rc) return rc;
+    }
+    rc = emit_taps(0);
+    if (rc) return rc;
+
+    const float scale = 1.0f / sqrtf((float)Dh);
+    char key[96];
+    for (int l = 0; l < last && l < c.depth; ++l) {
+#define BW(var, suffix)                                  \
+    snprintf(key, sizeof(key), "enc.blk%d." suffix, l);  \
+    GETW(var, key)
+        BW(ln1g, "ln1.g");
+        BW(ln1b, "ln1.b");
+        BW(qkvw, "qkv.w");
+        BW(qkvb, "qkv.b");
+        BW(projw, "proj.w");
+        BW(projb, "proj.b");
+        BW(ln2g, "ln2.g");
+        BW(ln2b, "ln2.b");
+        BW(fc1w, "fc1.w");
+        BW(fc1b, "fc1.b");
+        BW(fc2w, "fc2.w");
+        BW(fc2b, "fc2.b");
+#undef BW
+        // x = x + proj(attn(norm1(x)))            modeling_finetune.py:247, :169-190
+        rc = launch_layernorm(dt, w.x, (const float*)ln1g, (const float*)ln1b, c.ln_eps, w.xn, nullptr, M, C, stream);
+        if (rc) return rc;
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.A = w.xn;
+        p.lda = C;
+        p.W = qkvw;
+        p.ldw = C;
+        p.M = M;
+        p.N = 3 * H * Dp;
+        p.K = C;
+        p.bias = (const float*)qkvb;
+        p.out_T = w.qk;
+        p.ldc = 2 * H * Dp;
+        p.epi = EPI_QKV;
+        p.vt = w.vt;
+        p.S = S;
+        p.H = H;
+        p.Dp = Dp;
+        rc = launch_gemm(dt, 0, p, stream);
+        if (rc) return rc;
+        rc = launch_attention(dt, w.qk, w.vt, w.ao, B, S, H, Dh, scale, stream);
+        if (rc) return rc;
+        memset(&p, 0, sizeof(p));
+        p.A = w.ao;
+        p.lda = C;
+        p.W = projw;
+        p.ldw = C;
+        p.M = M;
+        p.N = C;
+        p.K = C;
+        p.bias = (const float*)projb;
+        p.res1 = w.x;
+        p.res_f32 = 1;
+        p.ldr = C;
+        p.out_f32 = w.x;
+        p.ldc = C;
+        rc = launch_gemm(dt, 0, p, stream);
+        if (rc) return rc;
+        // x = x + fc2(gelu(fc1(norm2(x))))         modeling_finetune.py:248, :62-69
+        rc = launch_layernorm(dt, w.x, (const float*)ln2g, (const float*)ln2b, c.ln_eps, w.xn, nullptr, M, C, stream);
+        if (rc) return rc;
+        memset(&p, 0, sizeof(p));
+        p.A = w.xn;
+        p.lda = C;
+        p.W = fc1w;
+        p.ldw = C;
+        p.M = M;
+        p.N = c.mlp_hidden;
+        p.K = C;
+        p.bias = (const float*)fc1b;
+        p.act = ACT_GELU;
+        p.out_T = w.hb;
+        p.ldc = c.mlp_hidden;
+        rc = launch_gemm(dt, 0, p, stream);
+        if (rc) return rc;
+        memset(&p, 0, sizeof(p));
+        p.A = w.hb;
+        p.lda = c.mlp_hidden;
+        p.W = fc2w;
+        p.ldw = c.mlp_hidden;
+        p.M = M;
+        p.N = C;
+        p.K = c.mlp_hidden;
+        p.bias = (const float*)fc2b;
+        p.res1 = w.x;
+        p.res_f32 = 1;
+        p.ldr = C;
+        p.out_f32 = w.x;
+        p.ldc = C;
+        rc = launch_gemm(dt, 0, p, stream);
+        if (rc) return rc;
+        if (l + 1 < c.depth) {
+            rc = emit_taps(l + 1);
+            if (rc) return rc;
+        }
+    }
+    if (last == c.depth) {
+        rc = emit_taps(c.depth);
+        if (rc) return rc;
+    }
+    (void)es;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+// HBM-bound kernels of the encoder path: LayerNorm, tubelet im2col (patch embed gather), casts.
+// All are one-pass, 16-byte vectorised, one wave per row where a row reduction is needed.
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim of a float [M][C] residual stream (reference: nn.LayerNorm eps=1e-6
+// in the encoder, l4p_videomae.py:177; eps=1e-5 in the SAM two-way transformer, transformer.py:145-153;
+// LayerNorm3d over channels, mask_decoder.py:145-157 == the same row LN in channels-last layout).
+// Two-pass in registers (mean, then centred variance) like ATen.  out_T and/or out_f32 may be given.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        T* __restrict__ out_T, float* __restrict__ out_f32, int M, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = C >> 2;
+    const f32x4* xr = (const f32x4*)(x + (long long)row * C);
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nv) {
+            v[i] = xr[idx];
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else {
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = v[i][k] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nv) {
+            const f32x4 g = ((const f32x4*)gamma)[idx], bb = ((const f32x4*)beta)[idx];
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd * g[k] + bb[k];
+            if (out_f32) ((f32x4*)(out_f32 + (long long)row * C))[idx] = y;
+            if (out_T) {
+                if (sizeof(T) == 2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (bf16_t)y[k];
+                    ((bf16x4*)((bf16_t*)out_T + (long long)row * C))[idx] = o;
+                } else {
+                    ((f32x4*)((float*)out_T + (long long)row * C))[idx] = y;
+                }
+            }
+        }
+    }
+}
+
+int launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, float eps, void* out_T,
+                     float* out_f32, int M, int C, hipStream_t stream) {
+    if (C % 4 || C > 2048) {
+        l4p_set_error("layernorm: C=%d must be a multiple of 4 and <= 2048", C);
+        return L4P_E_INVALID;
+    }
+    const dim3 grid((M + 3) / 4), block(256);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
+                           out_f32, M, C);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, block, 0, stream, x, gamma, beta, eps, (float*)out_T,
+                           out_f32, M, C);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// float -> T cast (hook features handed to the DPT decoders), 16 bytes in per lane.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ x, T* __restrict__ y, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = ((const f32x4*)x)[i];
+        if (sizeof(T) == 2) {
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (bf16_t)v[k];
+            ((bf16x4*)y)[i] = o;
+        } else {
+            ((f32x4*)y)[i] = v;
+        }
+    }
+}
+
+int launch_cast(int dtype, const float* x, void* y, long long n, hipStream_t stream) {
+    if (n % 4) {
+        l4p_set_error("cast: n must be a multiple of 4");
+        return L4P_E_INVALID;
+    }
+    const long long n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, x, (bf16_t*)y, n4);
+    else
+        hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, stream, x, (float*)y, n4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tubelet gather for the patch-embed conv (reference PatchEmbed, modeling_finetune.py:269-283):
+// Conv3d(3 -> C, kernel = stride = (pt, ph, pw)) == gather + GEMM.  Row = token (t', h', w')
+// row-major, column k = ((c*pt + dt)*ph + dh)*pw + dw, zero-padded to Kp columns.
+// rgb: [B][3][T][H][W] float.  One thread per output element; writes are fully coalesced, reads
+// are pw-float runs that stay inside L2 (the whole clip is 9.6 MB).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void patch_gather_kernel(const float* __restrict__ rgb, T* __restrict__ out, int B, int Cin, int Tt, int Hh,
+                                    int Ww, int pt, int ph, int pw, int Kp) {
+    const int nT = Tt / pt, nH = Hh / ph, nW = Ww / pw;
+    const int K = Cin * pt * ph * pw;
+    const long long total = (long long)B * nT * nH * nW * Kp;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        long long tok = i / Kp;
+        float v = 0.f;
+        if (k < K) {
+            const int dw = k % pw;
+            int r = k / pw;
+            const int dh = r % ph;
+            r /= ph;
+            const int dt = r % pt;
+            const int c = r / pt;
+            const int w = (int)(tok % nW);
+            long long r2 = tok / nW;
+            const int hh = (int)(r2 % nH);
+            r2 /= nH;
+            const int t = (int)(r2 % nT);
+            const int b = (int)(r2 / nT);
+            v = rgb[((((long long)b * Cin + c) * Tt + (t * pt + dt)) * Hh + (hh * ph + dh)) * Ww + (w * pw + dw)];
+        }
+        out[i] = from_f32<T>(v);
+    }
+}
+
+int launch_patch_gather(int dtype, const float* rgb, void* out, int B, int Cin, int T, int H, int W, int pt, int ph,
+                        int pw, int Kp, hipStream_t stream) {
+    if (T % pt || H % ph || W % pw || Kp < Cin * pt * ph * pw) {
+        l4p_set_error("patch_gather: bad geometry");
+        return L4P_E_INVALID;
+    }
+    const long long total = (long long)B * (T / pt) * (H / ph) * (W / pw) * Kp;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, rgb, (bf16_t*)out, B, Cin, T,
+                           H, W, pt, ph, pw, Kp);
+    else
+        hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(grid), dim3(256), 0, stream, rgb, (float*)out, B, Cin, T, H,
+                           W, pt, ph, pw, Kp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,13 @@
+#include "gemm.hpp"
+int launch_gemm_bf16(int mode, const GemmParams& p, hipStream_t stream);
+int launch_gemm_f32(int mode, const GemmParams& p, hipStream_t stream);
+
+int launch_gemm(int dtype, int mode, const GemmParams& p, hipStream_t stream) {
+    const int es = dtype == L4P_BF16 ? 2 : 4;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) { l4p_set_error("gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K); return L4P_E_INVALID; }
+    if (p.N % 8) { l4p_set_error("gemm: N=%d must be a multiple of 8", p.N); return L4P_E_INVALID; }
+    if ((p.K * es) % 16 || (p.ldw * es) % 16) { l4p_set_error("gemm: K/ldw not 16-byte aligned"); return L4P_E_INVALID; }
+    if (mode == 0 && (p.lda * es) % 16) { l4p_set_error("gemm: lda not 16-byte aligned"); return L4P_E_INVALID; }
+    if (mode == 1 && (p.Cin % (128 / es) || p.K != 27 * p.Cin)) { l4p_set_error("conv3d: Cin=%d must be a multiple of %d and K=27*Cin", p.Cin, 128 / es); return L4P_E_INVALID; }
+    return dtype == L4P_BF16 ? launch_gemm_bf16(mode, p, stream) : launch_gemm_f32(mode, p, stream);
+}

@@ -1,0 +1,317 @@
+// MFMA GEMM / implicit-GEMM conv3d for gfx950.
+//
+//   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] )        (both operands k-contiguous)
+//
+// One kernel template serves: the encoder linears (reference modeling_finetune.py:169-190, :62-69),
+// the patch-embed GEMM (:276-283), every Conv3d 1x1x1 / 3x3x3 and ConvTranspose3d k==stride of the
+// DPT decoders (dpt_block.py:29-90,93-157,255-278,406-414) and the SAM-style tracker's projections
+// (sam/transformer.py:223-245, mask_decoder.py:58-66).
+//
+// CDNA4 mapping:
+//  * operands are swapped into the MFMA (weights = A operand, activations = B operand) so that a lane
+//    ends up with 4*TN *consecutive output columns of one row*: bias / residual / store are 16-byte
+//    vector accesses and every output row is written in 64..256-byte runs.
+//  * LDS tiles have 128-byte rows, XOR-swizzled at 16-byte granularity (chunk ^= (row>>1)&7) so the
+//    non-contiguous 16-lane groups of ds_read_b128 hit 16 distinct slots.
+//  * global->register->LDS staging, next tile's loads issued before the current tile's MFMAs
+//    (register prefetch, double-buffered LDS, one barrier per k-tile).
+//  * T = bf16 uses v_mfma_f32_16x16x32_bf16, T = float uses 8x v_mfma_f32_16x16x4_f32 on the same
+//    fragment registers (exact-f32 parity mode).
+#pragma once
+#include "common.hpp"
+
+enum { EPI_DENSE = L4P_EPI_DENSE, EPI_QKV = L4P_EPI_QKV, EPI_CONVT = L4P_EPI_CONVT };
+enum { ACT_NONE = L4P_ACT_NONE, ACT_GELU = L4P_ACT_GELU, ACT_RELU = L4P_ACT_RELU };
+
+// The kernel parameter block IS the public descriptor (include/l4p_hip.h): plain pointers and ints.
+typedef l4p_gemm_desc GemmParams;
+
+template <typename T, int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int ES = sizeof(T);
+    constexpr int BK = 128 / ES;   // 64 bf16 / 32 f32 per LDS row
+    constexpr int EPC = 16 / ES;   // elements per 16-byte chunk
+    constexpr int CPF = 8 * ES / 16;  // chunks per fragment (1 bf16, 2 f32)
+    constexpr int KK = BK / 32;
+    constexpr int A_IT = BM * 8 / NT, W_IT = BN * 8 / NT;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    typedef typename Frag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                  // [2][BM*128]
+    char* Ws = smem + 2 * BM * 128;   // [2][BN*128]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int crow = tid >> 3, cc = tid & 7;  // this thread's (row, chunk) inside a staging pass
+
+    // ---- per-thread source addressing -------------------------------------------------------
+    const T* a_base[A_IT];
+    unsigned a_mask[A_IT];
+    const T* w_base[W_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        int m = m0 + crow + i * (NT / 8);
+        if (m >= p.M) m = p.M - 1;
+        if (MODE == 0) {
+            a_base[i] = (const T*)p.A + (long long)m * p.lda + cc * EPC;
+            a_mask[i] = 0;
+        } else {
+            int wo = m % p.Wo;
+            int r = m / p.Wo;
+            int ho = r % p.Ho;
+            r /= p.Ho;
+            int to = r % p.To;
+            int b = r / p.To;
+            int ti = to * p.st, hi = ho * p.sh, wi = wo * p.sw;
+            unsigned mask = 0;
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) {
+                int dt = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+                bool ok = (unsigned)(ti + dt) < (unsigned)p.Ti && (unsigned)(hi + dh) < (unsigned)p.Hi &&
+                          (unsigned)(wi + dw) < (unsigned)p.Wi;
+                mask |= (ok ? 1u : 0u) << tap;
+            }
+            a_mask[i] = mask;
+            long long vox = (((long long)b * p.Ti + ti) * p.Hi + hi) * p.Wi + wi;
+            a_base[i] = (const T*)p.A + vox * p.Cin + cc * EPC;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        int n = n0 + crow + i * (NT / 8);
+        w_base[i] = (const T*)p.W + (long long)n * p.ldw + cc * EPC;
+    }
+
+    const int nk = (p.K + BK - 1) / BK;
+    const int kpc = (MODE == 1) ? (p.Cin / BK) : 1;  // k-tiles per conv tap
+
+    u32x4 ra[A_IT], rw[W_IT];
+
+    auto load_tile = [&](int kt) {
+        if (MODE == 0) {
+            const int k = kt * BK + cc * EPC;
+            const bool kin = k < p.K;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                u32x4 z = {0, 0, 0, 0};
+                ra[i] = kin ? *(const u32x4*)(a_base[i] + kt * BK) : z;
+            }
+#pragma unroll
+            for (int i = 0; i < W_IT; ++i) {
+                u32x4 z = {0, 0, 0, 0};
+                rw[i] = kin ? *(const u32x4*)(w_base[i] + kt * BK) : z;
+            }
+        } else {
+            const int tap = kt / kpc;
+            const int ci0 = (kt - tap * kpc) * BK;
+            const int dt = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+            const long long toff = (((long long)dt * p.Hi + dh) * p.Wi + dw) * p.Cin + ci0;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                u32x4 z = {0, 0, 0, 0};
+                const bool ok = (a_mask[i] >> tap) & 1u;
+                u32x4 v = ok ? *(const u32x4*)(a_base[i] + toff) : z;
+                if (p.relu_in) {
+                    if (ES == 2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            unsigned x = v[q];
+                            unsigned neg = ((x >> 15) & 0x00010001u) * 0xFFFFu;
+                            v[q] = x & ~neg;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = __float_as_uint(fmaxf(__uint_as_float(v[q]), 0.0f));
+                    }
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < W_IT; ++i) rw[i] = *(const u32x4*)(w_base[i] + kt * BK);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int row = crow + i * (NT / 8);
+            *(u32x4*)(As + buf * BM * 128 + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            const int row = crow + i * (NT / 8);
+            *(u32x4*)(Ws + buf * BN * 128 + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4)) = rw[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int li = lane & 15, kg = lane >> 4;
+    // fragment rows inside the block tile
+    int xrow[TM], wrow[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xrow[i] = wm * (TM * 16) + i * 16 + li;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wrow[j] = wn * (TN * 16) + 4 * TN * (li >> 2) + 4 * j + (li & 3);
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* Ab = As + cur * BM * 128;
+        const char* Wb = Ws + cur * BN * 128;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            frag_t xf[TM], wf[TN];
+            const int c0 = kk * 2 * ES + kg * CPF;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = xrow[i];
+                const int sw = (row >> 1) & 7;
+                u32x4* d = (u32x4*)&xf[i];
+#pragma unroll
+                for (int q = 0; q < CPF; ++q) d[q] = *(const u32x4*)(Ab + row * 128 + (((c0 + q) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wrow[j];
+                const int sw = (row >> 1) & 7;
+                u32x4* d = (u32x4*)&wf[j];
+#pragma unroll
+                for (int q = 0; q < CPF; ++q) d[q] = *(const u32x4*)(Wb + row * 128 + (((c0 + q) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mma16(wf[j], xf[i], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns row m, columns [nb, nb + 4*TN) -------------------------------------
+    constexpr int NV = 4 * TN;
+    const int nb = n0 + wn * (TN * 16) + NV * kg;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (TM * 16) + i * 16 + li;
+        if (m >= p.M) continue;
+        float v[NV];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
+#pragma unroll
+        for (int g8 = 0; g8 < NV; g8 += 8) {
+            const int n = nb + g8;
+            if (n >= p.N) continue;  // N % 8 == 0 is required
+            float* vv = v + g8;
+            if (p.bias) {
+                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    vv[q] += b0[q];
+                    vv[4 + q] += b1[q];
+                }
+            }
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] = gelu_erf(vv[q]);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] = fmaxf(vv[q], 0.0f);
+            }
+            // output / residual addressing
+            long long off;  // element offset for dense-style addressing
+            if (p.epi == EPI_CONVT) {
+                const int tap = n / p.Cout, co = n - tap * p.Cout;
+                const int dw = tap % p.kw, dh = (tap / p.kw) % p.kh, dt = tap / (p.kw * p.kh);
+                int wi = m % p.Wi;
+                int r = m / p.Wi;
+                int hi = r % p.Hi;
+                r /= p.Hi;
+                int ti = r % p.Ti;
+                int b = r / p.Ti;
+                const long long vox =
+                    (((long long)b * p.Ti * p.kt + (ti * p.kt + dt)) * (p.Hi * p.kh) + (hi * p.kh + dh)) * (p.Wi * p.kw) +
+                    (wi * p.kw + dw);
+                off = vox * p.Cout + co;
+            } else {
+                off = (long long)m * p.ldc + n;
+            }
+            if (p.res1) {
+                const long long roff = (long long)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr + n;
+                if (p.res_f32) {
+                    const f32x4 r0 = *(const f32x4*)((const float*)p.res1 + roff),
+                                r1 = *(const f32x4*)((const float*)p.res1 + roff + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        vv[q] += r0[q];
+                        vv[4 + q] += r1[q];
+                    }
+                    if (p.res2) {
+                        const f32x4 s0 = *(const f32x4*)((const float*)p.res2 + roff),
+                                    s1 = *(const f32x4*)((const float*)p.res2 + roff + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            vv[q] += s0[q];
+                            vv[4 + q] += s1[q];
+                        }
+                    }
+                } else {
+                    const T* rp = (const T*)p.res1 + roff;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) vv[q] += to_f32<T>(rp[q]);
+                    if (p.res2) {
+                        const T* sp = (const T*)p.res2 + roff;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) vv[q] += to_f32<T>(sp[q]);
+                    }
+                }
+            }
+            if (p.epi == EPI_QKV && n >= 2 * p.H * p.Dp) {
+                // V, stored transposed: vt[((b*H + h)*Dp + d)*S + s]
+                const int nv = n - 2 * p.H * p.Dp;
+                const int h = nv / p.Dp, d = nv - h * p.Dp;
+                const int b = m / p.S, s = m - b * p.S;
+                T* vp = (T*)p.vt + ((long long)(b * p.H + h) * p.Dp + d) * p.S + s;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vp[(long long)q * p.S] = from_f32<T>(vv[q]);
+                continue;
+            }
+            if (p.out_f32) {
+                float* op = p.out_f32 + off;
+                *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+                *(f32x4*)(op + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+            }
+            if (p.out_T) {
+                T* op = (T*)p.out_T + off;
+                if (ES == 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
+                    *(bf16x8*)op = o;
+                } else {
+                    *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+                    *(f32x4*)((float*)op + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+                }
+            }
+        }
+    }
+}
+
+// host launcher (gemm.hip)
+int launch_gemm(int dtype, int mode, const GemmParams& p, hipStream_t stream);

@@ -1,0 +1,183 @@
+"""torch.Tensor -> raw pointer plumbing over the kernel-level C ABI (include/l4p_hip.h).
+
+PyTorch is used here only for device memory and the current HIP stream; every FLOP runs in
+libl4p_hip.so.  These wrappers are what tests/ call for per-kernel parity and what the host mirror
+(l4p_amd.models.*) composes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, EPI_QKV, L4P_BF16, L4P_F32, GemmDesc
+
+DP = 96  # padded attention head dim used by the kernels
+
+
+def torch_dtype(dtype: int) -> torch.dtype:
+    return torch.bfloat16 if dtype == L4P_BF16 else torch.float32
+
+
+def code_of(t: torch.dtype) -> int:
+    if t == torch.bfloat16:
+        return L4P_BF16
+    if t == torch.float32:
+        return L4P_F32
+    raise ValueError(f"unsupported engine dtype {t}")
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "engine tensors must be contiguous device tensors"
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
+    """Zero-pad the leading (output-feature) dim of a packed weight to a multiple of ``mult``."""
+    n = w.shape[0]
+    npad = (n + mult - 1) // mult * mult
+    if npad == n:
+        return w.contiguous()
+    out = torch.zeros((npad,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    out[:n] = w
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, dtype: int,
+              want_T: bool = True, want_f32: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    assert x.dtype == torch.float32
+    M, Cc = x.shape
+    out_T = torch.empty((M, Cc), dtype=torch_dtype(dtype), device=x.device) if want_T else None
+    out_f = torch.empty((M, Cc), dtype=torch.float32, device=x.device) if want_f32 else None
+    lib = _lib.load()
+    _lib.check(lib.l4p_layernorm(_stream(), dtype, _p(x), _p(gamma), _p(beta), eps, _p(out_T), _p(out_f), M, Cc),
+               "l4p_layernorm")
+    return out_T, out_f
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, n: int, *, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+         res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, res_mod: int = 0,
+         out_f32: bool = False, out_T: bool = True, out: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """out[m][n] = act(a @ w[:n].T + bias) + res1 + res2.  ``w`` is [ceil128(n)][K]."""
+    dtype = code_of(a.dtype)
+    M, K = a.shape
+    assert w.shape[1] == K and w.shape[0] % 128 == 0 and w.shape[0] >= n and w.dtype == a.dtype
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = _p(a), K, _p(w), K
+    d.M, d.N, d.K = M, n, K
+    d.bias = _p(bias)
+    d.act = act
+    if res1 is not None:
+        d.res1 = _p(res1)
+        d.res2 = _p(res2)
+        d.res_f32 = 1 if res1.dtype == torch.float32 else 0
+        d.ldr = res1.shape[-1]
+        d.res_mod = res_mod
+    of = torch.empty((M, n), dtype=torch.float32, device=a.device) if out_f32 else None
+    oT = None
+    if out is not None:
+        if out.dtype == torch.float32 and dtype != L4P_F32:
+            of = out
+        else:
+            oT = out
+    elif out_T:
+        oT = torch.empty((M, n), dtype=a.dtype, device=a.device)
+    d.out_f32, d.out_T, d.ldc = _p(of), _p(oT), n
+    d.epi = EPI_DENSE
+    lib = _lib.load()
+    _lib.check(lib.l4p_gemm(_stream(), dtype, C.byref(d)), "l4p_gemm")
+    return oT, of
+
+
+def qkv_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, S: int, H: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fused qkv projection writing the attention layouts: qk [B,S,2,H,96], vt [B,H,96,S]."""
+    dtype = code_of(a.dtype)
+    M, K = a.shape
+    assert M == B * S and w.shape[0] >= 3 * H * DP
+    qk = torch.empty((B, S, 2, H, DP), dtype=a.dtype, device=a.device)
+    vt = torch.empty((B, H, DP, S), dtype=a.dtype, device=a.device)
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = _p(a), K, _p(w), K
+    d.M, d.N, d.K = M, 3 * H * DP, K
+    d.bias = _p(bias)
+    d.out_T, d.ldc = _p(qk), 2 * H * DP
+    d.epi = EPI_QKV
+    d.vt, d.S, d.H, d.Dp = _p(vt), S, H, DP
+    lib = _lib.load()
+    _lib.check(lib.l4p_gemm(_stream(), dtype, C.byref(d)), "l4p_gemm(qkv)")
+    return qk, vt
+
+
+def attention(qk: torch.Tensor, vt: torch.Tensor, head_dim: int, scale: Optional[float] = None) -> torch.Tensor:
+    B, S, two, H, dp = qk.shape
+    assert two == 2 and dp == DP and tuple(vt.shape) == (B, H, DP, S)
+    out = torch.empty((B * S, H * head_dim), dtype=qk.dtype, device=qk.device)
+    scale = head_dim ** -0.5 if scale is None else scale
+    lib = _lib.load()
+    _lib.check(lib.l4p_attention(_stream(), code_of(qk.dtype), _p(qk), _p(vt), _p(out), B, S, H, head_dim, scale),
+               "l4p_attention")
+    return out
+
+
+def patch_gather(rgb: torch.Tensor, patch: Tuple[int, int, int], kp: int, dtype: int) -> torch.Tensor:
+    B, Cin, T, H, W = rgb.shape
+    pt, ph, pw = patch
+    tokens = (T // pt) * (H // ph) * (W // pw)
+    out = torch.empty((B * tokens, kp), dtype=torch_dtype(dtype), device=rgb.device)
+    lib = _lib.load()
+    _lib.check(lib.l4p_patch_gather(_stream(), dtype, _p(rgb), _p(out), B, Cin, T, H, W, pt, ph, pw, kp),
+               "l4p_patch_gather")
+    return out
+
+
+def conv3d_k3(x: torch.Tensor, w: torch.Tensor, cout: int, *, stride: Tuple[int, int, int] = (1, 1, 1),
+              bias: Optional[torch.Tensor] = None, relu_in: bool = False, act: int = ACT_NONE,
+              res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3x3 conv, pad 1, channels-last: x [B,T,H,W,Cin] -> [B,To,Ho,Wo,cout]; w [ceil128(cout)][27*Cin]."""
+    dtype = code_of(x.dtype)
+    B, Ti, Hi, Wi, Cin = x.shape
+    st, sh, sw = stride
+    To, Ho, Wo = (Ti - 1) // st + 1, (Hi - 1) // sh + 1, (Wi - 1) // sw + 1
+    out = torch.empty((B, To, Ho, Wo, cout), dtype=x.dtype, device=x.device)
+    d = GemmDesc()
+    d.A, d.W, d.ldw = _p(x), _p(w), 27 * Cin
+    d.M, d.N, d.K = B * To * Ho * Wo, cout, 27 * Cin
+    d.Ti, d.Hi, d.Wi, d.Cin, d.To, d.Ho, d.Wo = Ti, Hi, Wi, Cin, To, Ho, Wo
+    d.st, d.sh, d.sw, d.relu_in = st, sh, sw, 1 if relu_in else 0
+    d.bias, d.act = _p(bias), act
+    if res1 is not None:
+        d.res1, d.res2, d.res_f32, d.ldr = _p(res1), _p(res2), 0, cout
+    d.out_T, d.ldc = _p(out), cout
+    lib = _lib.load()
+    _lib.check(lib.l4p_conv3d_k3(_stream(), dtype, C.byref(d)), "l4p_conv3d_k3")
+    return out
+
+
+def conv_transpose(x: torch.Tensor, w: torch.Tensor, cout: int, k: Tuple[int, int, int],
+                   bias_taps: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
+    """ConvTranspose3d with kernel == stride == k, channels-last.  w: [ceil128(taps*cout)][Cin], row = tap*cout+co;
+    bias_taps: float [taps*cout] (the conv bias repeated per tap)."""
+    dtype = code_of(x.dtype)
+    B, Ti, Hi, Wi, Cin = x.shape
+    kt, kh, kw = k
+    n = kt * kh * kw * cout
+    out = torch.empty((B, Ti * kt, Hi * kh, Wi * kw, cout), dtype=x.dtype, device=x.device)
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = _p(x), Cin, _p(w), Cin
+    d.M, d.N, d.K = B * Ti * Hi * Wi, n, Cin
+    d.Ti, d.Hi, d.Wi = Ti, Hi, Wi
+    d.bias, d.act = _p(bias_taps), act
+    d.out_T = _p(out)
+    d.epi = EPI_CONVT
+    d.kt, d.kh, d.kw, d.Cout = kt, kh, kw, cout
+    lib = _lib.load()
+    _lib.check(lib.l4p_gemm(_stream(), dtype, C.byref(d)), "l4p_gemm(convT)")
+    return out

@@ -1,0 +1,206 @@
+"""Per-kernel parity of the HIP kernels (through the C ABI) against plain PyTorch fp32 CPU ops on
+the SAME inputs (bf16-rounded for the bf16 mode).
+
+Tolerances (stated once, used everywhere in this file):
+  * L4P_F32 mode: max |y - ref| <= 1e-3 * max|ref|  (north_star's 1e-3 relative; measured ~1e-6)
+  * L4P_BF16 mode, float outputs (f32 accumulate): same 1e-3 bound
+  * L4P_BF16 mode, bf16 outputs: the result is additionally rounded to bf16 (half-ulp = 2^-9 =
+    1.95e-3 relative), so the bound is rel-L2 <= 3e-3 and max error <= 1 bf16 ulp of max|ref|.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from l4p_amd import ops
+from l4p_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, L4P_BF16, L4P_F32
+
+MODES = [L4P_F32, L4P_BF16]
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def as_mode(x, mode):
+    """Round to the engine storage type and return (device tensor, fp32 cpu view of the same values)."""
+    t = x.to(ops.torch_dtype(mode))
+    return t.cuda(), t.float()
+
+
+def check(y, ref, mode, bf16_out):
+    y = y.float().cpu()
+    scale = ref.abs().max().item() + 1e-30
+    err = (y - ref).abs().max().item()
+    if mode == L4P_BF16 and bf16_out:
+        rel_l2 = ((y - ref).norm() / (ref.norm() + 1e-30)).item()
+        assert rel_l2 <= 3e-3, f"rel-L2 {rel_l2:.3e}"
+        assert err <= scale * 2 ** -7, f"max err {err:.3e} vs scale {scale:.3e}"
+    else:
+        assert err <= 1e-3 * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("M,C", [(2048, 1408), (37, 352), (6, 176)])
+def test_layernorm(dev, mode, M, C):
+    x = rnd((M, C), 1, 3.0) + 0.5
+    g, b = rnd((C,), 2) * 0.2 + 1.0, rnd((C,), 3) * 0.1
+    ref = F.layer_norm(x, (C,), g, b, 1e-6)
+    yT, yf = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-6, mode, want_T=True, want_f32=True)
+    check(yf, ref, mode, False)
+    check(yT, ref, mode, True)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("M,N,K", [(2048, 1408, 1408), (2048, 6144, 1408), (2048, 1408, 6144), (300, 704, 1408),
+                                     (2048, 1408, 1216), (70, 176, 352), (256, 256, 176)])
+def test_gemm_bias(dev, mode, M, N, K):
+    a, a_ref = as_mode(rnd((M, K), 10), mode)
+    w, w_ref = as_mode(rnd((N, K), 11, K ** -0.5), mode)
+    bias = rnd((N,), 12)
+    ref = a_ref @ w_ref.t() + bias
+    yT, yf = ops.gemm(a, ops.pad_rows(w), N, bias=bias.cuda(), out_f32=True, out_T=True)
+    check(yf, ref, mode, False)
+    check(yT, ref, mode, True)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("act", [ACT_GELU, ACT_RELU])
+def test_gemm_act_residual(dev, mode, act):
+    M, N, K = 512, 1408, 704
+    a, a_ref = as_mode(rnd((M, K), 20), mode)
+    w, w_ref = as_mode(rnd((N, K), 21, K ** -0.5), mode)
+    bias = rnd((N,), 22)
+    r1, r2 = rnd((M, N), 23), rnd((M, N), 24)
+    z = a_ref @ w_ref.t() + bias
+    z = F.gelu(z) if act == ACT_GELU else F.relu(z)
+    # float residuals (encoder residual stream)
+    _, yf = ops.gemm(a, ops.pad_rows(w), N, bias=bias.cuda(), act=act, res1=r1.cuda(), res2=r2.cuda(), out_f32=True,
+                     out_T=False)
+    check(yf, z + r1 + r2, mode, False)
+    # T residuals (DPT skip connections)
+    r1T, r1_ref = as_mode(r1, mode)
+    r2T, r2_ref = as_mode(r2, mode)
+    yT, _ = ops.gemm(a, ops.pad_rows(w), N, bias=bias.cuda(), act=act, res1=r1T, res2=r2T)
+    check(yT, z + r1_ref + r2_ref, mode, True)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_gemm_broadcast_residual(dev, mode):
+    # pos-embed style: residual table indexed by m % res_mod
+    M, N, K, S = 512, 352, 192, 256
+    a, a_ref = as_mode(rnd((M, K), 30), mode)
+    w, w_ref = as_mode(rnd((N, K), 31, K ** -0.5), mode)
+    pos = rnd((S, N), 32)
+    ref = a_ref @ w_ref.t() + pos.repeat(M // S, 1)
+    _, yf = ops.gemm(a, ops.pad_rows(w), N, res1=pos.cuda(), res_mod=S, out_f32=True, out_T=False)
+    check(yf, ref, mode, False)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,S,H,Dh", [(1, 2048, 16, 88), (2, 256, 2, 88), (1, 128, 3, 64)])
+def test_qkv_attention(dev, mode, B, S, H, Dh):
+    """qkv GEMM epilogue layouts + fused attention vs softmax(q k^T / sqrt(d)) v."""
+    C = H * Dh
+    x, x_ref = as_mode(rnd((B * S, C), 40), mode)
+    wqkv = rnd((3 * C, C), 41, C ** -0.5)
+    qb, vb = rnd((C,), 42) * 0.1, rnd((C,), 43) * 0.1
+    # pack: [3][H][96][C] with zero rows for d >= Dh; bias = (q_bias, 0, v_bias)
+    wp = torch.zeros(3, H, ops.DP, C)
+    wp[:, :, :Dh] = wqkv.view(3, H, Dh, C)
+    bp = torch.zeros(3, H, ops.DP)
+    bp[0, :, :Dh] = qb.view(H, Dh)
+    bp[2, :, :Dh] = vb.view(H, Dh)
+    w, w_ref = as_mode(wp.view(3 * H * ops.DP, C), mode)
+    qk, vt = ops.qkv_gemm(x, ops.pad_rows(w), bp.view(-1).cuda(), B, S, H)
+    full = (x_ref @ w_ref.t() + bp.view(-1)).view(B, S, 3, H, ops.DP)
+    check(qk, full[:, :, :2], mode, True)
+    check(vt, full[:, :, 2].permute(0, 2, 3, 1), mode, True)
+    # attention on the values the kernel actually produced (rounded to T)
+    qk_ref, vt_ref = qk.float().cpu(), vt.float().cpu()
+    q = qk_ref[:, :, 0].permute(0, 2, 1, 3)  # B H S 96
+    k = qk_ref[:, :, 1].permute(0, 2, 1, 3)
+    v = vt_ref.permute(0, 1, 3, 2)  # B H S 96
+    attn = torch.softmax((q * Dh ** -0.5) @ k.transpose(-2, -1), dim=-1)
+    ref = (attn @ v)[..., :Dh].transpose(1, 2).reshape(B * S, C)
+    out = ops.attention(qk, vt, Dh)
+    check(out, ref, mode, True)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_attention_peaked_softmax(dev, mode):
+    """Force large running-max jumps across KV tiles (online-softmax rescale path)."""
+    B, S, H, Dh = 1, 512, 2, 88
+    g = torch.Generator().manual_seed(5)
+    qk = torch.randn(B, S, 2, H, ops.DP, generator=g)
+    qk[..., Dh:] = 0
+    # spike: a few keys late in the sequence dominate some queries
+    qk[0, 300:310, 1] *= 6.0
+    qk[0, 17, 0] *= 8.0
+    vt = torch.randn(B, H, ops.DP, S, generator=g)
+    qkT, qk_ref = as_mode(qk, mode)
+    vtT, vt_ref = as_mode(vt, mode)
+    q = qk_ref[:, :, 0].permute(0, 2, 1, 3)
+    k = qk_ref[:, :, 1].permute(0, 2, 1, 3)
+    v = vt_ref.permute(0, 1, 3, 2)
+    attn = torch.softmax((q.double() * Dh ** -0.5) @ k.double().transpose(-2, -1), dim=-1)
+    ref = (attn @ v.double())[..., :Dh].transpose(1, 2).reshape(B * S, H * Dh).float()
+    out = ops.attention(qkT, vtT, Dh)
+    check(out, ref, mode, True)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_patch_embed(dev, mode):
+    """gather + GEMM == Conv3d(kernel=stride=(2,14,14)) + flatten/transpose (modeling_finetune.py:269-283)."""
+    B, C = 1, 352
+    rgb = rnd((B, 3, 16, 224, 224), 50)
+    w = rnd((C, 3, 2, 14, 14), 51, 1176 ** -0.5)
+    bias = rnd((C,), 52)
+    kp = 1216
+    a = ops.patch_gather(rgb.cuda(), (2, 14, 14), kp, mode)
+    wp = torch.zeros(C, kp)
+    wp[:, :1176] = w.view(C, 1176)
+    wT, w_ref = as_mode(wp, mode)
+    rgb_ref = rgb.to(ops.torch_dtype(mode)).float()
+    ref = F.conv3d(rgb_ref, w_ref[:, :1176].view(C, 3, 2, 14, 14), bias, stride=(2, 14, 14)).flatten(2).transpose(1, 2)
+    _, yf = ops.gemm(a, ops.pad_rows(wT), C, bias=bias.cuda(), out_f32=True, out_T=False)
+    check(yf, ref.reshape(-1, C), mode, False)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("shape,cout,stride,relu_in", [((1, 4, 8, 8, 128), 256, (1, 1, 1), False),
+                                                      ((2, 3, 10, 6, 64), 128, (1, 1, 1), True),
+                                                      ((1, 8, 16, 16, 128), 128, (2, 2, 2), False)])
+def test_conv3d_k3(dev, mode, shape, cout, stride, relu_in):
+    B, T, H, W, Cin = shape
+    x, x_ref = as_mode(rnd(shape, 60), mode)
+    w = rnd((cout, Cin, 3, 3, 3), 61, (27 * Cin) ** -0.5)
+    bias = rnd((cout,), 62)
+    wT, w_ref = as_mode(w.permute(0, 2, 3, 4, 1).reshape(cout, 27 * Cin), mode)
+    w5 = w_ref.view(cout, 3, 3, 3, Cin).permute(0, 4, 1, 2, 3)
+    xin = x_ref.permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(F.relu(xin) if relu_in else xin, w5, bias, stride=stride, padding=1)
+    skip = rnd(tuple(ref.permute(0, 2, 3, 4, 1).shape), 63)
+    sT, s_ref = as_mode(skip, mode)
+    y = ops.conv3d_k3(x, ops.pad_rows(wT), cout, stride=stride, bias=bias.cuda(), relu_in=relu_in, act=ACT_RELU,
+                      res1=sT)
+    check(y, F.relu(ref).permute(0, 2, 3, 4, 1) + s_ref, mode, True)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k", [(2, 4, 4), (2, 2, 2), (1, 2, 2), (2, 1, 1)])
+def test_conv_transpose(dev, mode, k):
+    B, T, H, W, Cin, cout = 1, 4, 8, 8, 192, 64
+    x, x_ref = as_mode(rnd((B, T, H, W, Cin), 70), mode)
+    w = rnd((Cin, cout) + k, 71, Cin ** -0.5)  # ConvTranspose3d layout [Cin][Cout][kt][kh][kw]
+    bias = rnd((cout,), 72)
+    taps = k[0] * k[1] * k[2]
+    wT, w_ref = as_mode(w.permute(2, 3, 4, 1, 0).reshape(taps * cout, Cin), mode)
+    w5 = w_ref.view(k[0], k[1], k[2], cout, Cin).permute(4, 3, 0, 1, 2)
+    ref = F.conv_transpose3d(x_ref.permute(0, 4, 1, 2, 3), w5, bias, stride=k).permute(0, 2, 3, 4, 1)
+    y = ops.conv_transpose(x, ops.pad_rows(wT), cout, k, bias_taps=bias.repeat(taps).cuda())
+    check(y, ref, mode, True)
