@@ -108,6 +108,33 @@ int l4p_patch_gather(l4p_stream stream, int dtype, const float* rgb, void* out, 
 
 int l4p_cast(l4p_stream stream, int dtype, const float* x, void* y, long long n);
 
+/* Trilinear resize of channels-last data [B][Ti][Hi][Wi][C] -> [B][To][Ho][Wo][C] (C % 8 == 0).
+ * Replaces F.interpolate(mode="trilinear", align_corners=True) in the DPT decoders
+ * (dpt_block.py:229-234; dpt_head.py:79-83) and align_corners=False in the tracker
+ * (sparse_heads.py:645-647). */
+int l4p_upsample_trilinear(l4p_stream stream, int dtype, const void* x, void* y, int B, int Ti, int Hi, int Wi, int To,
+                           int Ho, int Wo, int C, int align_corners);
+
+/* DPT head2[2]: Conv3d 1x1x1 C(=128) -> Cout (<= 8) + optional exp; channels-last T in, NCDHW float out
+ * (dpt_block.py:413; dense_heads.py:73,179,215 with apply_fn 'exp' misc.py:23-24).
+ * w: float [Cout][C], bias: float [Cout], y: float [B][Cout][vox_per_b]. */
+int l4p_head_out(l4p_stream stream, int dtype, const void* x, const float* w, const float* bias, float* y,
+                 long long vox_per_b, int B, int C, int Cout, int post_exp);
+
+/* LstSqAffineAligner (aligner.py:29-66): least-squares scale/shift between two overlapping depth
+ * windows, in inverse depth (inverse=1: f = safe_inverse, misc.py:48-62) or directly (inverse=0).
+ * solve: sol[0..1] = argmin_{s,t} || s f(pred) + t - f(target) ||^2 over n floats; scratch = 6 doubles.
+ * apply: y = f(s f(x) + t). */
+int l4p_affine_align_solve(l4p_stream stream, const float* pred, const float* target, long long n, int inverse,
+                           double* scratch, float* sol);
+int l4p_affine_align_apply(l4p_stream stream, const float* x, float* y, long long n, int inverse, const float* sol);
+
+/* rays_to_cameras + pose inversion (geometry_utils.py:331-406, :249-328; dense_heads.py:346-348):
+ * rays float [B][6][T][h][w] (Pluecker direction|moment), K float [B][4][4][T] pixel intrinsics of an
+ * H x W image  ->  out float [B][16][T] = row-major world_T_cam per frame. */
+int l4p_rays_to_pose(l4p_stream stream, const float* rays, const float* K, float* out, int B, int T, int h, int w,
+                     int H, int W);
+
 /* ------------------------------------------------------------------------------------------------
  * Engine: holds the table of packed device weights and runs whole sub-networks with one call.
  * ---------------------------------------------------------------------------------------------- */

@@ -62,6 +62,11 @@ SIGNATURES = {
     "l4p_attention": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _F]),
     "l4p_patch_gather": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "l4p_cast": (_I, [_VP, _I, _VP, _VP, _LL]),
+    "l4p_upsample_trilinear": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "l4p_head_out": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _LL, _I, _I, _I, _I]),
+    "l4p_affine_align_solve": (_I, [_VP, _VP, _VP, _LL, _I, _VP, _VP]),
+    "l4p_affine_align_apply": (_I, [_VP, _VP, _VP, _LL, _I, _VP]),
+    "l4p_rays_to_pose": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     "l4p_create": (_I, [_I, _I, C.POINTER(_VP)]),
     "l4p_destroy": (_I, [_VP]),
     "l4p_bind_weight": (_I, [_VP, C.c_char_p, _VP, _LL]),

@@ -54,6 +54,27 @@ int l4p_cast(l4p_stream stream, int dtype, const float* x, void* y, long long n)
     return launch_cast(dtype, x, y, n, (hipStream_t)stream);
 }
 
+int l4p_upsample_trilinear(l4p_stream stream, int dtype, const void* x, void* y, int B, int Ti, int Hi, int Wi, int To,
+                           int Ho, int Wo, int C, int align_corners) {
+    return launch_upsample(dtype, x, y, B, Ti, Hi, Wi, To, Ho, Wo, C, align_corners, (hipStream_t)stream);
+}
+int l4p_head_out(l4p_stream stream, int dtype, const void* x, const float* w, const float* bias, float* y,
+                 long long vox_per_b, int B, int C, int Cout, int post_exp) {
+    return launch_head_out(dtype, x, w, bias, y, vox_per_b, B, C, Cout, post_exp, (hipStream_t)stream);
+}
+
+int l4p_affine_align_solve(l4p_stream stream, const float* pred, const float* target, long long n, int inverse,
+                           double* scratch, float* sol) {
+    return launch_affine_solve(pred, target, n, inverse, scratch, sol, (hipStream_t)stream);
+}
+int l4p_affine_align_apply(l4p_stream stream, const float* x, float* y, long long n, int inverse, const float* sol) {
+    return launch_affine_apply(x, y, n, inverse, sol, (hipStream_t)stream);
+}
+int l4p_rays_to_pose(l4p_stream stream, const float* rays, const float* K, float* out, int B, int T, int h, int w,
+                     int H, int W) {
+    return launch_rays_to_pose(rays, K, out, B, T, h, w, H, W, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------------------------

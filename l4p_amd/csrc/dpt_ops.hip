@@ -1,0 +1,174 @@
+// HBM-bound pieces of the DPT decoders: channels-last trilinear resize and the final 1x1x1
+// projection (+exp) that also converts channels-last T back to the reference's NCDHW float layout.
+#include "common.hpp"
+
+// -------------------------------------------------------------------------------------------------
+// Trilinear resize, channels-last [B][Ti][Hi][Wi][C] -> [B][To][Ho][Wo][C].
+// Replaces F.interpolate(mode="trilinear") with align_corners=True (dpt_block.py:229-234,
+// dpt_head.py:79-83) or False (sparse_heads.py:645-647).  Index/weight arithmetic follows ATen's
+// area_pixel_compute_source_index + guard_index_and_lambda in float.
+// One thread = 8 channels (16 B of bf16) of one output voxel; the 8 taps are 16-byte loads.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void src_index(int dst, int in, int out, bool align, int& i0, int& i1, float& lam) {
+    float src;
+    if (align) {
+        const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+        src = scale * (float)dst;
+    } else {
+        const float scale = (float)in / (float)out;
+        src = scale * ((float)dst + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+    }
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    lam = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+}
+
+template <typename T>
+__global__ void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Ti, int Hi, int Wi, int To, int Ho,
+                                int Wo, int C, int align) {
+    constexpr int V = 8;  // channels per thread
+    const int cv = C / V;
+    const long long total = (long long)B * To * Ho * Wo * cv;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        long long r = i / cv;
+        const int wo = (int)(r % Wo);
+        r /= Wo;
+        const int ho = (int)(r % Ho);
+        r /= Ho;
+        const int to = (int)(r % To);
+        const int b = (int)(r / To);
+        int t0, t1, h0, h1, w0, w1;
+        float lt, lh, lw;
+        src_index(to, Ti, To, align, t0, t1, lt);
+        src_index(ho, Hi, Ho, align, h0, h1, lh);
+        src_index(wo, Wi, Wo, align, w0, w1, lw);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        const T* xb = x + (long long)b * Ti * Hi * Wi * C + c;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const float wgt = (a ? lt : 1.f - lt) * (bb ? lh : 1.f - lh) * (cc ? lw : 1.f - lw);
+                    const T* p = xb + (((long long)(a ? t1 : t0) * Hi + (bb ? h1 : h0)) * Wi + (cc ? w1 : w0)) * C;
+                    if (sizeof(T) == 2) {
+                        const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+                        for (int k = 0; k < V; ++k) acc[k] += wgt * (float)v[k];
+                    } else {
+                        const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)((const float*)p + 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            acc[k] += wgt * v0[k];
+                            acc[4 + k] += wgt * v1[k];
+                        }
+                    }
+                }
+        T* yp = y + ((((long long)b * To + to) * Ho + ho) * Wo + wo) * C + c;
+        if (sizeof(T) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = (bf16_t)acc[k];
+            *(bf16x8*)yp = o;
+        } else {
+            *(f32x4*)yp = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+            *(f32x4*)((float*)yp + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+        }
+    }
+}
+
+int launch_upsample(int dtype, const void* x, void* y, int B, int Ti, int Hi, int Wi, int To, int Ho, int Wo, int C,
+                    int align, hipStream_t stream) {
+    if (C % 8) {
+        l4p_set_error("upsample: C=%d must be a multiple of 8", C);
+        return L4P_E_INVALID;
+    }
+    const long long total = (long long)B * To * Ho * Wo * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(upsample_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, B, Ti,
+                           Hi, Wi, To, Ho, Wo, C, align);
+    else
+        hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (float*)y, B, Ti, Hi,
+                           Wi, To, Ho, Wo, C, align);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// head2[2]: Conv3d 1x1x1 C -> Cout (Cout <= 8) + optional exp, channels-last T in, NCDHW float out
+// (dpt_block.py:413; dense_heads.py:73,179,215; misc.py:23-24).  One thread per voxel: the row is
+// 16-byte loads, the store is coalesced along the voxel index for each output channel.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void head_out_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       long long vox_per_b, int B, int Cout, int post_exp) {
+    __shared__ float ws[8 * C + 8];
+    for (int i = threadIdx.x; i < Cout * C; i += blockDim.x) ws[i] = w[i];
+    if (threadIdx.x < Cout) ws[8 * C + threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const long long total = vox_per_b * B;
+    for (long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x; m < total;
+         m += (long long)gridDim.x * blockDim.x) {
+        float acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+        const T* xp = x + m * C;
+#pragma unroll 4
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            float v[8];
+            if (sizeof(T) == 2) {
+                const bf16x8 t = *(const bf16x8*)(xp + c0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+            } else {
+                const f32x4 a = *(const f32x4*)(xp + c0), b = *(const f32x4*)((const float*)xp + c0 + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = a[k];
+                    v[4 + k] = b[k];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < Cout) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[o] += v[k] * ws[o * C + c0 + k];
+                }
+        }
+        const long long b = m / vox_per_b, v = m - b * vox_per_b;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < Cout) {
+                float r = acc[o] + ws[8 * C + o];
+                if (post_exp) r = expf(r);
+                y[(b * Cout + o) * vox_per_b + v] = r;
+            }
+    }
+}
+
+int launch_head_out(int dtype, const void* x, const float* w, const float* bias, float* y, long long vox_per_b, int B,
+                    int C, int Cout, int post_exp, hipStream_t stream) {
+    if (C != 128 || Cout < 1 || Cout > 8) {
+        l4p_set_error("head_out: supports C == 128 and 1 <= Cout <= 8 (C=%d Cout=%d)", C, Cout);
+        return L4P_E_INVALID;
+    }
+    const long long total = vox_per_b * B;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL((head_out_kernel<bf16_t, 128>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, w, bias, y,
+                           vox_per_b, B, Cout, post_exp);
+    else
+        hipLaunchKernelGGL((head_out_kernel<float, 128>), dim3(grid), dim3(256), 0, stream, (const float*)x, w, bias, y,
+                           vox_per_b, B, Cout, post_exp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -31,3 +31,12 @@ int launch_patch_gather(int dtype, const float* rgb, void* out, int B, int Cin, 
                         int pw, int Kp, hipStream_t stream);
 int launch_attention(int dtype, const void* qk, const void* vt, void* out, int B, int S, int H, int Dh, float scale,
                      hipStream_t stream);
+int launch_upsample(int dtype, const void* x, void* y, int B, int Ti, int Hi, int Wi, int To, int Ho, int Wo, int C,
+                    int align, hipStream_t stream);
+int launch_head_out(int dtype, const void* x, const float* w, const float* bias, float* y, long long vox_per_b, int B,
+                    int C, int Cout, int post_exp, hipStream_t stream);
+int launch_affine_solve(const float* pred, const float* tgt, long long n, int inverse, double* scratch, float* sol,
+                        hipStream_t stream);
+int launch_affine_apply(const float* x, float* y, long long n, int inverse, const float* sol, hipStream_t stream);
+int launch_rays_to_pose(const float* rays, const float* K, float* out, int B, int T, int h, int w, int H, int W,
+                        hipStream_t stream);

@@ -1,0 +1,70 @@
+"""Python handle on the C-ABI engine (include/l4p_hip.h): owns the packed-weight arena, binds it into
+libl4p_hip.so and runs whole sub-networks with one native call."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import L4P_BF16, L4P_F32, EncoderCfg
+from .ops import code_of, torch_dtype
+from .packing import PackedWeights
+from .weights import ModelCfg
+
+
+class Engine:
+    """One engine per (process, device, dtype)."""
+
+    def __init__(self, cfg: ModelCfg, weights: PackedWeights, dtype: int, device: torch.device):
+        if device.type != "cuda":
+            raise _lib.L4PHipError("the L4P engine runs on an AMD GPU only (device must be cuda:N); no CPU path exists")
+        self.lib = _lib.load()
+        self.cfg, self.weights, self.dtype, self.device = cfg, weights, dtype, device
+        self.tdtype = torch_dtype(dtype)
+        h = C.c_void_p()
+        _lib.check(self.lib.l4p_create(device.index or 0, dtype, C.byref(h)), "l4p_create")
+        self.handle = h
+        for name, t in weights.t.items():
+            if name.startswith("enc."):
+                _lib.check(self.lib.l4p_bind_weight(self.handle, name.encode(), t.data_ptr(), t.numel()), "l4p_bind_weight")
+        ec = EncoderCfg(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, head_dim=cfg.head_dim, mlp_hidden=cfg.mlp_hidden,
+                        in_chans=cfg.in_chans, frames=cfg.frames, img_h=cfg.img, img_w=cfg.img, pt=cfg.patch[0],
+                        ph=cfg.patch[1], pw=cfg.patch[2], patch_kp=int(weights.meta["patch_kp"]), ln_eps=cfg.ln_eps)
+        _lib.check(self.lib.l4p_encoder_configure(self.handle, C.byref(ec)), "l4p_encoder_configure")
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.l4p_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _workspace(self, B: int) -> torch.Tensor:
+        need = int(self.lib.l4p_encoder_workspace_bytes(self.handle, B))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def encoder_forward(self, rgb: torch.Tensor, taps_f32: Iterable[int] = (), taps_T: Iterable[int] = ()) -> Tuple[Dict[int, torch.Tensor], Dict[int, torch.Tensor]]:
+        """VideoMAEEncoder.forward (l4p_videomae.py:80-122) for the requested feature indices only.
+        Returns ({layer: float [B,P,C]}, {layer: T [B,P,C]})."""
+        assert rgb.is_cuda and rgb.dtype == torch.float32 and rgb.is_contiguous()
+        B = rgb.shape[0]
+        c = self.cfg
+        assert tuple(rgb.shape[1:]) == (c.in_chans, c.frames, c.img, c.img), f"bad clip shape {tuple(rgb.shape)}"
+        tf, tT = sorted(set(taps_f32)), sorted(set(taps_T))
+        layers = sorted(set(tf) | set(tT))
+        n = len(layers)
+        out_f = {l: torch.empty(B, c.tokens, c.dim, dtype=torch.float32, device=self.device) for l in tf}
+        out_T = {l: torch.empty(B, c.tokens, c.dim, dtype=self.tdtype, device=self.device) for l in tT}
+        lay = (C.c_int * n)(*layers)
+        pf = (C.c_void_p * n)(*[out_f[l].data_ptr() if l in out_f else None for l in layers])
+        pT = (C.c_void_p * n)(*[out_T[l].data_ptr() if l in out_T else None for l in layers])
+        ws = self._workspace(B)
+        _lib.check(self.lib.l4p_encoder_forward(self.handle, torch.cuda.current_stream().cuda_stream, rgb.data_ptr(), B,
+                                                ws.data_ptr(), ws.numel(), n, lay, pf, pT), "l4p_encoder_forward")
+        return out_f, out_T

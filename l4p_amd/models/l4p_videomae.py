@@ -1,0 +1,188 @@
+"""L4P_VideoMAE on the MI355X engine — host mirror of l4p/models/l4p_videomae.py.
+
+Same constructor arguments, ``forward(data, tasks)`` semantics, window slicing and output keys as the
+reference (l4p_videomae.py:125-330).  The module owns no torch parameters: ``load_state_dict`` accepts
+the reference checkpoint layout, repacks it into kernel layouts on the device
+and binds it into libl4p_hip.so.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _lib
+from .._lib import L4P_BF16, L4P_F32
+from ..engine import Engine
+from ..packing import PackedWeights, pack_state_dict
+from ..weights import ModelCfg, state_dict_schema
+from .task_heads.dense_heads import _Runtime, VideoMAEFlowDPTHead, VideoMAETraj3DDPTHead
+
+
+class EncoderFeatures:
+    """Stand-in for the reference's list of depth+1 per-layer features (l4p_videomae.py:106-122).
+    Only the layers some head asked for exist; they are held as float and/or engine dtype (T)."""
+
+    def __init__(self, depth: int, f32: Dict[int, torch.Tensor], T: Dict[int, torch.Tensor]):
+        self.depth, self._f32, self._T = depth, f32, T
+
+    def __len__(self) -> int:
+        return self.depth + 1
+
+    def _norm(self, i: int) -> int:
+        return i + self.depth + 1 if i < 0 else i
+
+    def T(self, i: int) -> torch.Tensor:
+        i = self._norm(i)
+        if i not in self._T:
+            raise KeyError(f"encoder feature {i} was not requested in engine dtype (available: {sorted(self._T)})")
+        return self._T[i]
+
+    def f32(self, i: int) -> torch.Tensor:
+        i = self._norm(i)
+        if i in self._f32:
+            return self._f32[i]
+        if i in self._T:
+            return self._T[i].float()
+        raise KeyError(f"encoder feature {i} was not requested (available: {sorted(set(self._f32) | set(self._T))})")
+
+    def __getitem__(self, i: int) -> torch.Tensor:
+        return self.f32(i)
+
+
+def _engine_dtype(name) -> int:
+    if name in (L4P_BF16, "bf16", "bf16-mixed", "16-mixed", "bf16-true", "16-true"):
+        return L4P_BF16  # the reference's fp16 autocast maps to the bf16 MFMA path (>= its precision class)
+    if name in (L4P_F32, "32", "32-true", "fp32", "f32"):
+        return L4P_F32
+    raise ValueError(f"unsupported precision {name!r}")
+
+
+class L4P_VideoMAE(torch.nn.Module):
+    """Main L4P model: shared video encoder + task heads (l4p_videomae.py:125-330)."""
+
+    def __init__(
+        self,
+        task_heads: torch.nn.ModuleDict,
+        video_encoder_ckpt_path: Optional[str] = None,
+        window_size: Tuple[int, int, int] = (16, 224, 224),
+        window_stride_T: int = 8,
+        freeze_video_encoder: bool = False,
+        freeze_heads: Optional[List[str]] = None,
+        unfreeze_blocks: Optional[List[int]] = None,
+        always_use_windowed_version: bool = False,
+        joint_alignment: bool = False,
+        cam_emb_placed_at_enc: Optional[str] = None,
+        cam_emb_type: str = "add",
+        model_cfg: Optional[ModelCfg] = None,
+        precision: str = "bf16",
+    ) -> None:
+        super().__init__()
+        if cam_emb_placed_at_enc is not None:
+            raise NotImplementedError("camera embeddings in the encoder are disabled in the shipped config (configs/model.yaml)")
+        if video_encoder_ckpt_path is not None:
+            raise NotImplementedError("encoder-only checkpoints are a training-time convenience; load the full state_dict")
+        self.cfg = model_cfg or ModelCfg.full()
+        self.task_heads = task_heads
+        self.window_size = tuple(window_size)
+        self.window_stride_T = window_stride_T
+        self.always_use_windowed_version = always_use_windowed_version
+        self.joint_alignment = joint_alignment
+        self.engine_dtype = _engine_dtype(precision)
+        self.engine: Optional[Engine] = None
+        self.weights: Optional[PackedWeights] = None
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        for key, head in self.task_heads.items():
+            head._engine_task = key
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def expected_keys(self) -> "OrderedDict[str, Tuple[int, ...]]":
+        return state_dict_schema(self.cfg, tasks=list(self.task_heads.keys()))
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True, assign: bool = False):
+        """Accepts the reference layout (keys relative to ``l4p_model.``; a leading ``l4p_model.`` is stripped),
+        checks it strictly against the schema, packs it for the engine and uploads it."""
+        sd = {(k[len("l4p_model."):] if k.startswith("l4p_model.") else k): v for k, v in state_dict.items()}
+        exp = self.expected_keys()
+        missing = [k for k in exp if k not in sd]
+        unexpected = [k for k in sd if k not in exp]
+        bad = [k for k in exp if k in sd and tuple(sd[k].shape) != tuple(exp[k])]
+        if bad or (strict and (missing or unexpected)):
+            raise RuntimeError(
+                f"Error(s) in loading state_dict for L4P_VideoMAE: missing={missing[:5]} ({len(missing)}), "
+                f"unexpected={unexpected[:5]} ({len(unexpected)}), shape mismatch={bad[:5]} ({len(bad)})")
+        if self.device.type != "cuda":
+            raise _lib.L4PHipError("no AMD GPU visible: the L4P engine has no CPU path")
+        self.set_weights(pack_state_dict(sd, self.cfg, torch.bfloat16 if self.engine_dtype == L4P_BF16 else torch.float32,
+                                         self.device, tasks=list(self.task_heads.keys())))
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def set_weights(self, weights: PackedWeights) -> None:
+        """Attach an already packed arena (e.g. received by RCCL broadcast, parallel.py)."""
+        self.weights = weights
+        self.engine = Engine(self.cfg, weights, self.engine_dtype, self.device)
+        rt = _Runtime(self.cfg, weights, self.engine_dtype)
+        for head in self.task_heads.values():
+            head._rt = rt
+
+    # ---- encoder ---------------------------------------------------------------------------------
+    def _taps(self, tasks: Sequence[str]) -> Tuple[List[int], List[int]]:
+        tT, tf = set(), set()
+        for t in tasks:
+            head = self.task_heads[t]
+            if isinstance(head, VideoMAEFlowDPTHead):
+                tT.update(head.required_taps())
+            else:
+                tf.add(self.cfg.depth)  # tracker reads enc_features[-1]  (sparse_heads.py:521)
+        return sorted(tf), sorted(tT)
+
+    def video_encoder(self, rgb_b3thw: torch.Tensor, taps_f32: Iterable[int] = (), taps_T: Iterable[int] = ()) -> EncoderFeatures:
+        if self.engine is None:
+            raise RuntimeError("weights not loaded: call load_state_dict / set_weights first")
+        rgb = rgb_b3thw.to(device=self.device, dtype=torch.float32).contiguous()
+        f32, T = self.engine.encoder_forward(rgb, taps_f32, taps_T)
+        return EncoderFeatures(self.cfg.depth, f32, T)
+
+    def encode_features(self, data: Dict[str, Any], tasks: Optional[Sequence[str]] = None) -> EncoderFeatures:
+        tf, tT = self._taps(tasks if tasks is not None else list(self.task_heads.keys()))
+        return self.video_encoder(data["rgb_b3thw"], tf, tT)
+
+    def forward_single_window(self, data: Dict[str, Any], tasks: List[str]) -> Dict[str, Any]:
+        feats = self.encode_features(data, tasks)
+        out: Dict[str, Any] = {"enc_features_bpc_list": feats}
+        for task in tasks:
+            out.update(self.task_heads[task](enc_features_bpc_list=feats, **data))
+        return out
+
+    # ---- main entry ------------------------------------------------------------------------------
+    def forward(self, data: Dict[str, Any], tasks: List[str]) -> Dict[str, Any]:
+        rgb = data["rgb_b3thw"]
+        B, _, T, H, W = rgb.shape
+        assert H == self.window_size[1] and W == self.window_size[2], "Supports only fixed spatial size"
+        data = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in data.items()}
+        if (not self.always_use_windowed_version) and (T == self.window_size[0]):
+            return self.forward_single_window(data, tasks)
+        assert T % self.window_stride_T == 0, "Temporal window needs to be a multiple of window stride, for now!"
+        time_strides = torch.arange(0, T - self.window_size[0] + 1, self.window_stride_T)
+        tf, tT = self._taps(tasks)
+        ws = self.window_size[0]
+        feats2d = [self.video_encoder(data["rgb_b3thw"][:, :, int(s):int(s) + ws], tf, tT) for s in time_strides]
+        out: Dict[str, Any] = {"enc_features_bpc_2dlist": feats2d}
+        joint_possible = "depth" in tasks and "camray" in tasks
+        if self.joint_alignment and joint_possible:
+            from .task_heads.dense_heads import joint_windowed_estimation
+
+            for task in ("track_2d", "dyn_mask", "flow_2d_backward"):
+                if task in tasks:
+                    out.update(self.task_heads[task].forward_windowed(
+                        enc_features_bpc_2dlist=feats2d, time_strides=time_strides, **data))
+            out.update(joint_windowed_estimation(["depth", "camray"], self.task_heads, enc_features_bpc_2dlist=feats2d,
+                                                 time_strides=time_strides, **data))
+        else:
+            if self.joint_alignment:
+                print("Joint alignment is not possible as depth or camray tasks are not present")
+            for task in tasks:
+                out.update(self.task_heads[task].forward_windowed(
+                    enc_features_bpc_2dlist=feats2d, time_strides=time_strides, **data))
+        return out

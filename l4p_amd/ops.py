@@ -181,3 +181,27 @@ def conv_transpose(x: torch.Tensor, w: torch.Tensor, cout: int, k: Tuple[int, in
     lib = _lib.load()
     _lib.check(lib.l4p_gemm(_stream(), dtype, C.byref(d)), "l4p_gemm(convT)")
     return out
+
+
+def upsample_trilinear(x: torch.Tensor, size: Tuple[int, int, int], align_corners: bool) -> torch.Tensor:
+    """Channels-last trilinear resize [B,Ti,Hi,Wi,C] -> [B,To,Ho,Wo,C]."""
+    B, Ti, Hi, Wi, Cc = x.shape
+    To, Ho, Wo = size
+    if (To, Ho, Wo) == (Ti, Hi, Wi):
+        return x
+    y = torch.empty((B, To, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.l4p_upsample_trilinear(_stream(), code_of(x.dtype), _p(x), _p(y), B, Ti, Hi, Wi, To, Ho, Wo, Cc,
+                                          1 if align_corners else 0), "l4p_upsample_trilinear")
+    return y
+
+
+def head_out(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, post_exp: bool) -> torch.Tensor:
+    """x [B,T,H,W,128] T -> float [B,Cout,T,H,W] = conv1x1(x) (+exp)."""
+    B, Tt, Hh, Ww, Cc = x.shape
+    cout = w.shape[0]
+    y = torch.empty((B, cout, Tt, Hh, Ww), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.l4p_head_out(_stream(), code_of(x.dtype), _p(x), _p(w), _p(bias), _p(y), Tt * Hh * Ww, B, Cc, cout,
+                                1 if post_exp else 0), "l4p_head_out")
+    return y

@@ -1,0 +1,546 @@
+"""ORACLE — test infrastructure only.
+
+A plain-PyTorch fp32 CPU restatement of the NVlabs/L4P inference algorithm (shared VideoMAE-v2
+encoder + dense DPT heads + ray/pose head + SAM-style tracker + window stitching), written
+functionally over a reference-format state_dict.  Every function cites the reference file:line it
+follows.  It is pinned against the real reference by tools/gen_golden.py (run in the build container,
+where /root/reference is importable) through the fixtures committed under tests/golden/.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product path (l4p_amd/*) never does and fails loudly when the HIP library is missing.
+
+Parity status: encoder, DPT heads, LstSq window stitching, tracker (incl. multi-window memory /
+re-seeding) and rays->camera with given intrinsics are pinned by golden vectors.  The two third-party
+RANSAC steps of the reference (cv2.findHomography / RQDecomp3x3, skimage.measure.ransac — unpinned
+versions, not installed here) are "parity unpinned": see DESIGN.md.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------------------
+# encoder
+# --------------------------------------------------------------------------------------------------
+def sinusoid_table(n_position: int, d_hid: int) -> Tensor:
+    """modeling_finetune.py:288-299 — float64 numpy table, cast to float32 at the end."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid, dtype=np.float64)[None, :]
+    ang = pos / np.power(10000.0, 2.0 * np.floor(j / 2.0) / d_hid)
+    tab = np.empty_like(ang)
+    tab[:, 0::2] = np.sin(ang[:, 0::2])
+    tab[:, 1::2] = np.cos(ang[:, 1::2])
+    return torch.tensor(tab, dtype=torch.float32).unsqueeze(0)
+
+
+def encoder_block(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int, eps: float) -> Tensor:
+    """Block.forward modeling_finetune.py:245-252 with Attention :169-190 and Mlp :62-69 (gamma_* = None)."""
+    B, N, C = x.shape
+    h = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+    qkv_bias = torch.cat((sd[p + "attn.q_bias"], torch.zeros_like(sd[p + "attn.v_bias"]), sd[p + "attn.v_bias"]))
+    qkv = F.linear(h, sd[p + "attn.qkv.weight"], qkv_bias).reshape(B, N, 3, heads, -1).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    scale = (C // heads) ** -0.5
+    attn = ((q * scale) @ k.transpose(-2, -1)).softmax(dim=-1)
+    a = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    x = x + F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    h = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+    h = F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+    return x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+
+
+def encoder_forward(sd: Dict[str, Tensor], rgb: Tensor, cfg, upto: Optional[int] = None) -> List[Tensor]:
+    """VideoMAEEncoder.forward l4p_videomae.py:80-122: returns [embeddings, after block 1, ..., norm(last)].
+    ``upto`` truncates the block loop (testing aid); the final norm is applied only at full depth."""
+    p = "video_encoder."
+    x = F.conv3d(rgb, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=tuple(cfg.patch))
+    x = x.flatten(2).transpose(1, 2)  # modeling_finetune.py:282
+    x = x + sinusoid_table(x.shape[1], cfg.dim)
+    feats = [x]
+    depth = cfg.depth if upto is None else upto
+    for i in range(depth):
+        feats.append(encoder_block(sd, f"{p}blocks.{i}.", feats[-1], cfg.heads, cfg.ln_eps))
+    if depth == cfg.depth:
+        feats[-1] = F.layer_norm(feats[-1], (cfg.dim,), sd[p + "norm.weight"], sd[p + "norm.bias"], cfg.ln_eps)
+    return feats
+
+
+# --------------------------------------------------------------------------------------------------
+# DPT decoder
+# --------------------------------------------------------------------------------------------------
+def _rcu(sd: Dict[str, Tensor], p: str, x: Tensor) -> Tensor:
+    """ResidualConvUnit_custom.forward dpt_block.py:131-157 (bn=False, ReLU pre-activations)."""
+    out = F.conv3d(F.relu(x), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    out = F.conv3d(F.relu(out), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    return out + x
+
+
+def _fusion(sd: Dict[str, Tensor], p: str, scale: Sequence[int], x0: Tensor, x1: Optional[Tensor] = None) -> Tensor:
+    """FeatureFusionBlock_custom.forward dpt_block.py:210-238."""
+    out = x0
+    if x1 is not None:
+        out = out + _rcu(sd, p + "resConfUnit1.", x1)
+    out = _rcu(sd, p + "resConfUnit2.", out)
+    out = F.interpolate(out, scale_factor=tuple(float(s) for s in scale), mode="trilinear", align_corners=True)
+    return F.conv3d(out, sd[p + "out_conv.weight"], sd[p + "out_conv.bias"])
+
+
+def _actpost(sd: Dict[str, Tensor], p: str, x: Tensor, sf: Sequence[int]) -> Tensor:
+    """act_postprocess[i] = Conv3d 1x1x1 + make_conv3d_custom  (dpt_block.py:255-278, :447-507)."""
+    x = F.conv3d(x, sd[p + "0.weight"], sd[p + "0.bias"])
+    if any(s > 0 for s in sf):
+        st = tuple(2 ** s for s in sf)
+        x = F.conv_transpose3d(x, sd[p + "1.weight"], sd[p + "1.bias"], stride=st)
+    elif any(s < 0 for s in sf):
+        st = tuple(2 ** (-s) for s in sf)
+        pad = tuple(s // 2 for s in st)
+        x = F.conv3d(x, sd[p + "1.weight"], sd[p + "1.bias"], stride=st, padding=pad)
+    return x
+
+
+def dpt_forward(sd: Dict[str, Tensor], task: str, feats: Sequence[Tensor], cfg, actpost, fusion,
+                output_size: Optional[Tuple[int, int, int]], image_size=(16, 224, 224)) -> Tensor:
+    """DPTOutputAdapter_fix.forward dpt_head.py:41-86.  feats is the encoder feature list."""
+    p = f"task_heads.{task}.task_head.dpt."
+    nt, nh, nw = cfg.grid
+    layers = []
+    for i, hook in enumerate(cfg.hooks):
+        tok = feats[hook]
+        B = tok.shape[0]
+        x = tok.reshape(B, nt, nh, nw, cfg.dim).permute(0, 4, 1, 2, 3).contiguous()  # b (nt nh nw) c -> b c nt nh nw
+        x = _actpost(sd, f"{p}act_postprocess.{i}.", x, actpost[i])
+        layers.append(F.conv3d(x, sd[f"{p}scratch.layer_rn.{i}.weight"], None, padding=1))
+    s = p + "scratch."
+    path4 = _fusion(sd, s + "refinenet4.", fusion[3], layers[3])[:, :, : layers[2].shape[2], : layers[2].shape[3]]
+    path3 = _fusion(sd, s + "refinenet3.", fusion[2], path4, layers[2])
+    path2 = _fusion(sd, s + "refinenet2.", fusion[1], path3, layers[1])
+    path1 = _fusion(sd, s + "refinenet1.", fusion[0], path2, layers[0])
+    out = F.conv3d(path1, sd[p + "head1.0.weight"], sd[p + "head1.0.bias"], padding=1)
+    osz = tuple(image_size) if output_size is None else tuple(output_size)
+    if tuple(out.shape[-3:]) != osz:
+        out = F.interpolate(out, size=osz, mode="trilinear", align_corners=True)
+    out = F.relu(F.conv3d(out, sd[p + "head2.0.weight"], sd[p + "head2.0.bias"], padding=1))
+    return F.conv3d(out, sd[p + "head2.2.weight"], sd[p + "head2.2.bias"])
+
+
+# --------------------------------------------------------------------------------------------------
+# small utilities (l4p/utils/misc.py, l4p/utils/geometry_utils.py)
+# --------------------------------------------------------------------------------------------------
+def safe_inverse(x: Tensor, keep_above: float = 0.0) -> Tensor:
+    """misc.py:48-62."""
+    out = torch.zeros_like(x)
+    m = x > keep_above
+    out[m] = 1.0 / x[m]
+    return out
+
+
+def normalize_intrinsics(K_b44t: Tensor, h: int, w: int) -> Tensor:
+    """geometry_utils.py:110-116."""
+    K = K_b44t.clone()
+    K[:, :2, 2] += 0.5
+    K[:, 0] = K[:, 0] / w
+    K[:, 1] = K[:, 1] / h
+    return K
+
+
+def denormalize_intrinsics(K_b44t: Tensor, h: int, w: int) -> Tensor:
+    """geometry_utils.py:119-125."""
+    K = K_b44t.clone()
+    K[:, 0] *= w
+    K[:, 1] *= h
+    K[:, :2, 2] -= 0.5
+    return K
+
+
+def lstsq_affine_solve(pred: Tensor, target: Tensor) -> Tensor:
+    """LstSqAffineAligner.solve with pre_post_fn='inverse' (aligner.py:45-56): scale/shift in 1/depth."""
+    a = safe_inverse(pred).reshape(pred.shape[0], -1, 1).float()
+    b = safe_inverse(target).reshape(target.shape[0], -1, 1).float()
+    A = torch.cat([a, torch.ones_like(a)], dim=-1)
+    return torch.linalg.lstsq(A, b, rcond=None).solution[..., 0]  # B x 2
+
+
+def lstsq_affine_apply(pred: Tensor, sol: Tensor) -> Tensor:
+    """LstSqAffineAligner.apply (aligner.py:58-66)."""
+    shp = (sol.shape[0],) + (1,) * (pred.ndim - 1)
+    return safe_inverse(sol[:, 0].reshape(shp) * safe_inverse(pred) + sol[:, 1].reshape(shp))
+
+
+def plucker_to_point_direction(rays_b6thw: Tensor) -> Tuple[Tensor, Tensor]:
+    """geometry_utils.py:308-328."""
+    d = rays_b6thw[:, :3]
+    m = rays_b6thw[:, 3:] / torch.linalg.norm(d, dim=1, keepdim=True)
+    return torch.cross(d, m, dim=1), d
+
+
+def intersect_skew_lines(points: Tensor, directions: Tensor) -> Tensor:
+    """geometry_utils.py:249-282 (mask = ones)."""
+    d = F.normalize(directions, dim=-1)
+    eye = torch.eye(3, dtype=points.dtype)[None, None]
+    P = eye - d[..., None] * d[..., None, :]
+    rhs = P.matmul(points[..., None]).sum(dim=-3)
+    return torch.linalg.lstsq(P.float().sum(dim=-3), rhs.float()).solution[..., 0]
+
+
+def kabsch_rotation(A: Tensor, Bm: Tensor) -> Tensor:
+    """compute_optimal_rotation_alignment geometry_utils.py:285-305: argmin_R ||A - B R||_F."""
+    Hm = (Bm.T @ A).float()
+    U, _, Vh = torch.linalg.svd(Hm, full_matrices=True)
+    s = torch.linalg.det(U @ Vh)
+    Sp = torch.diag(torch.tensor([1.0, 1.0, float(torch.sign(s))]))
+    return (U @ Sp @ Vh).T
+
+
+def rays_to_cameras(rays_b6thw: Tensor, Kn_b44t: Tensor) -> Tensor:
+    """geometry_utils.py:331-406 with ctr_only=False: extrinsics (cam_T_world) from a Pluecker ray map
+    and NORMALISED intrinsics."""
+    B, _, T, h, w = rays_b6thw.shape
+    rays = rays_b6thw.to(Kn_b44t.dtype)
+    origins, directions = plucker_to_point_direction(rays)
+    o = origins.permute(0, 2, 3, 4, 1).reshape(-1, h * w, 3)
+    d = directions.permute(0, 2, 3, 4, 1).reshape(-1, h * w, 3)
+    centers = intersect_skew_lines(o, d).reshape(B, T, 3)
+    K = denormalize_intrinsics(Kn_b44t, h, w)[:, :3, :3]
+    j, i = torch.meshgrid(torch.arange(h, dtype=rays.dtype), torch.arange(w, dtype=rays.dtype), indexing="ij")
+    pix = torch.stack([i.expand(B, -1, -1), j.expand(B, -1, -1), torch.ones_like(i).expand(B, -1, -1)], dim=-1)
+    rd = torch.einsum("btmn,bhwn->bthwm", torch.inverse(K.permute(0, 3, 1, 2)), pix)
+    rd = rd / rd.norm(dim=-1, keepdim=True)
+    E = torch.zeros_like(Kn_b44t)
+    E[:, 3, 3] = 1.0
+    for b in range(B):
+        for t in range(T):
+            E[b, :3, :3, t] = kabsch_rotation(rd[b, t].reshape(-1, 3), directions[b, :, t].reshape(3, -1).T)
+    tr = -torch.matmul(E[:, :3, :3].permute(0, 3, 1, 2), centers[..., None]).squeeze(3)
+    E[:, :3, -1] = tr.permute(0, 2, 1)
+    return E
+
+
+# --------------------------------------------------------------------------------------------------
+# tracker (sparse_heads.py + sam/*)
+# --------------------------------------------------------------------------------------------------
+def _pe_encoding(G: Tensor, coords01: Tensor) -> Tensor:
+    """PositionEmbeddingRandom3D._pe_encoding prompt_encoder.py:196-203."""
+    c = (2 * coords01 - 1) @ G
+    c = 2 * np.pi * c
+    return torch.cat([torch.sin(c), torch.cos(c)], dim=-1)
+
+
+def dense_pe(G: Tensor, size: Tuple[int, int, int]) -> Tensor:
+    """PositionEmbeddingRandom3D.forward prompt_encoder.py:205-219 -> [t*h*w, C] (token-major)."""
+    t, h, w = size
+    grid = torch.ones((t, h, w), dtype=torch.float32)
+    te = (grid.cumsum(0) - 0.5) / t
+    ye = (grid.cumsum(1) - 0.5) / h
+    xe = (grid.cumsum(2) - 0.5) / w
+    return _pe_encoding(G, torch.stack([te, xe, ye], dim=-1)).reshape(t * h * w, -1)
+
+
+def _sam_attention(sd: Dict[str, Tensor], p: str, q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
+    """sam/transformer.py:223-245."""
+    q = F.linear(q, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"])
+    k = F.linear(k, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
+    v = F.linear(v, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
+
+    def split(x):
+        b, n, c = x.shape
+        return x.reshape(b, n, heads, c // heads).transpose(1, 2)
+
+    q, k, v = split(q), split(k), split(v)
+    attn = torch.softmax((q @ k.permute(0, 1, 3, 2)) / math.sqrt(q.shape[-1]), dim=-1)
+    out = (attn @ v).transpose(1, 2)
+    out = out.reshape(out.shape[0], out.shape[1], -1)
+    return F.linear(out, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+
+
+def _ln(sd: Dict[str, Tensor], p: str, x: Tensor, eps: float = 1e-5) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[p + "weight"], sd[p + "bias"], eps)
+
+
+def two_way_transformer(sd: Dict[str, Tensor], p: str, src: Tensor, pos: Tensor, tokens: Tensor, depth: int,
+                        heads: int) -> Tuple[Tensor, Tensor]:
+    """TwoWayTransformer.forward sam/transformer.py:67-111 + TwoWayAttentionBlock.forward :156-187."""
+    queries, keys = tokens, src
+    for l in range(depth):
+        lp = f"{p}layers.{l}."
+        if l == 0:  # skip_first_layer_pe
+            queries = _sam_attention(sd, lp + "self_attn.", queries, queries, queries, heads)
+        else:
+            q = queries + tokens
+            queries = queries + _sam_attention(sd, lp + "self_attn.", q, q, queries, heads)
+        queries = _ln(sd, lp + "norm1.", queries)
+        q = queries + tokens
+        k = keys + pos
+        queries = _ln(sd, lp + "norm2.", queries + _sam_attention(sd, lp + "cross_attn_token_to_image.", q, k, keys, heads))
+        mlp = F.linear(F.relu(F.linear(queries, sd[lp + "mlp.lin1.weight"], sd[lp + "mlp.lin1.bias"])),
+                       sd[lp + "mlp.lin2.weight"], sd[lp + "mlp.lin2.bias"])
+        queries = _ln(sd, lp + "norm3.", queries + mlp)
+        q = queries + tokens
+        k = keys + pos
+        keys = _ln(sd, lp + "norm4.", keys + _sam_attention(sd, lp + "cross_attn_image_to_token.", k, q, queries, heads))
+    q = queries + tokens
+    k = keys + pos
+    queries = _ln(sd, p + "norm_final_attn.",
+                  queries + _sam_attention(sd, p + "final_attn_token_to_image.", q, k, keys, heads))
+    return queries, keys
+
+
+def track_single_window(sd: Dict[str, Tensor], cfg, enc_feat: Tensor, queries_n3: Tensor, labels_n: Tensor,
+                        prompt_feat_nc: Optional[Tensor], prompt_label_n: Optional[Tensor],
+                        task: str = "track_2d") -> Dict[str, Tensor]:
+    """VideoMAETrack2DSamHead.forward / forward_single_batch (sparse_heads.py:497-667) for batch 1.
+
+    enc_feat: [1 or N, P, C] keys (last encoder feature, plus per-query history when attending to the past).
+    Returns traj [N,2,T], vis [N,1,T], depth [N,1,T], prompt_features [N,C], enc_features_history [N,P,C].
+    """
+    p = f"task_heads.{task}."
+    N = queries_n3.shape[0]
+    C = cfg.dim
+    T, H, W = cfg.frames, cfg.img, cfg.img
+    G = sd[p + "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"]
+    # ---- PromptEncoder._embed_points with pad=True (prompt_encoder.py:99-121) ----
+    pts = torch.cat([queries_n3[:, None, :], torch.zeros(N, 1, 3)], dim=1)
+    lab = torch.cat([labels_n[:, None].float(), -torch.ones(N, 1)], dim=1)
+    c01 = pts.clone()
+    c01[:, :, 0] = c01[:, :, 0] / T
+    c01[:, :, 1] = c01[:, :, 1] / W
+    c01[:, :, 2] = c01[:, :, 2] / H
+    pe = _pe_encoding(G, c01.float())
+    pe[lab == -1] = 0.0
+    pe[lab == -1] += sd[p + "prompt_encoder.not_a_point_embed.weight"]
+    for i in range(2):
+        pe[lab == i] += sd[f"{p}prompt_encoder.point_embeddings.{i}.weight"]
+    # ---- PromptEncoder._embed_features (prompt_encoder.py:78-97) ----
+    if prompt_feat_nc is None:
+        prompt_feat_nc = torch.zeros(N, C)
+    if prompt_label_n is None:
+        prompt_label_n = torch.zeros(N)
+    feat = prompt_feat_nc[:, None, :]
+    fl = prompt_label_n[:, None]
+    fe = torch.zeros_like(feat)
+    fe[fl == 0] = feat[fl == 0] + sd[p + "prompt_encoder.prompt_feature_embeddings.0.weight"]
+    fe[fl == 1] = feat[fl == 1] + sd[p + "prompt_encoder.prompt_feature_embeddings.1.weight"]
+    sparse = torch.cat([pe, fe], dim=1)  # [N, 3, C]
+    # ---- MaskDecoder.predict_masks (mask_decoder.py:101-141) ----
+    m = p + "mask_decoder."
+    tokens = torch.cat([sd[m + "mask_tokens.weight"].unsqueeze(0).expand(N, -1, -1), sparse], dim=1)  # [N, 6, C]
+    src = (enc_feat.expand(N, -1, -1) if enc_feat.shape[0] == 1 else enc_feat).contiguous()  # mask_decoder.py:116-118
+    pos = dense_pe(G, cfg.grid).unsqueeze(0).expand(N, -1, -1)
+    hs, keys = two_way_transformer(sd, m + "transformer.", src, pos, tokens, cfg.sam_depth, cfg.sam_heads)
+    hyper = []
+    for i in range(3):
+        x = hs[:, i, :]
+        for j in range(3):
+            x = F.linear(x, sd[f"{m}output_hypernetworks_mlps.{i}.layers.{j}.weight"],
+                         sd[f"{m}output_hypernetworks_mlps.{i}.layers.{j}.bias"])
+            if j < 2:
+                x = F.relu(x)
+        hyper.append(x)
+    hyper_in = torch.stack(hyper, dim=1)  # [N, 3, d1]
+    nt, nh, nw = cfg.grid
+    vol = keys.transpose(1, 2).reshape(N, C, nt, nh, nw)
+    up = F.conv_transpose3d(vol, sd[m + "output_upscaling.0.weight"], sd[m + "output_upscaling.0.bias"], stride=2)
+    u = up.mean(1, keepdim=True)  # LayerNorm3d mask_decoder.py:152-157
+    s = (up - u).pow(2).mean(1, keepdim=True)
+    up = (up - u) / torch.sqrt(s + 1e-6)
+    up = sd[m + "output_upscaling.1.weight"][:, None, None, None] * up + sd[m + "output_upscaling.1.bias"][:, None, None, None]
+    up = F.gelu(up)
+    up = F.gelu(F.conv_transpose3d(up, sd[m + "output_upscaling.3.weight"], sd[m + "output_upscaling.3.bias"],
+                                   stride=(1, 2, 2)))
+    b_, c_, t_, h_, w_ = up.shape
+    masks = (hyper_in @ up.reshape(b_, c_, t_ * h_ * w_)).reshape(b_, -1, t_, h_, w_)
+    logits = F.interpolate(masks, size=(T, H, W), mode="trilinear", align_corners=False)  # sparse_heads.py:645-647
+    # ---- post-processing sparse_heads.py:572-589 ----
+    heat = torch.softmax(logits[:, 0].reshape(N, T, 1, H * W), dim=-1)
+    gx, gy = torch.meshgrid(torch.arange(W, dtype=torch.float32), torch.arange(H, dtype=torch.float32), indexing="xy")
+    grid = torch.stack([gx, gy], 0).reshape(2, -1) + 0.5
+    xy = torch.sum(heat * grid[None, None], dim=-1)  # [N, T, 2]
+    out = {
+        "traj": xy.permute(0, 2, 1),
+        "vis": logits[:, 1].mean(dim=[-1, -2]).unsqueeze(1),
+        "depth": torch.exp(logits[:, 2].mean(dim=[-1, -2])).unsqueeze(1),
+        "prompt_features": F.linear(hs[:, 5, :], sd[p + "prompt_feature_linear_layer.weight"],
+                                    sd[p + "prompt_feature_linear_layer.bias"]),
+        "history": F.linear(keys, sd[p + "processed_video_features_proj.weight"],
+                            sd[p + "processed_video_features_proj.bias"]),
+    }
+    return out
+
+
+def track_windowed(sd: Dict[str, Tensor], cfg, last_feats: Sequence[Tensor], queries_bn3: Tensor, labels_bn: Tensor,
+                   time_strides: Sequence[int], task: str = "track_2d", trace: Optional[list] = None) -> Dict[str, Tensor]:
+    """forward_windowed_core sparse_heads.py:213-495 for estimation_directions=[1], B=1, with
+    prompt_using_features / attend_to_past / modify_pointlabels_for_windowing as in configs/model.yaml.
+    last_feats[w] is enc_features_bpc_2dlist[w][-1] ([1,P,C]).  ``trace`` collects the per-window
+    integer/boolean state (labels, validity masks, re-seeded queries) for bit-exact checks."""
+    p = f"task_heads.{task}."
+    assert queries_bn3.shape[0] == 1
+    N = queries_bn3.shape[1]
+    ws = cfg.frames
+    T = int(time_strides[-1]) + ws
+    traj = torch.zeros(1, N, 2, T)
+    vis = -torch.ones(1, N, 1, T) * 10.0
+    dep = torch.zeros(1, N, 1, T)
+    pfeat = torch.zeros(N, cfg.dim)
+    plab = torch.zeros(N)
+    mask_tok = sd[p + "processed_video_mask_token.weight"][0]
+    hist = mask_tok[None, None, :].repeat(N, cfg.tokens, 1)
+    cur_q = queries_bn3[0].clone()
+    cur_lab = labels_bn[0].clone().float()
+    orig_q = queries_bn3[0]
+    nt, nh, nw = cfg.grid
+    for wi, start in enumerate(int(s) for s in time_strides):
+        q_off = cur_q.clone()
+        valid_t = (torch.arange(ws).repeat(N, 1).float() + start + 0.5 - q_off[:, 0:1]) >= 0  # [N, ws]
+        valid_n = valid_t.sum(-1) > 0
+        q_off[:, 0] -= start
+        cur_lab[~valid_n] = 0
+        cur_lab[valid_n] = 1
+        same = (cur_q == orig_q).sum(-1) > 0  # sparse_heads.py:330-331 (any coordinate equal)
+        cur_lab[same] = 1
+        cur_lab[torch.logical_and(valid_n, ~same)] = 2
+        keys_in = last_feats[wi][0].unsqueeze(0) + hist  # [N,P,C]
+        if trace is not None:
+            trace.append({"labels": cur_lab.clone(), "valid_t": valid_t.clone(), "queries": q_off.clone(),
+                          "prompt_labels": plab.clone()})
+        o = track_single_window(sd, cfg, keys_in, q_off, cur_lab, pfeat, plab, task)
+        vt = valid_t[:, None, :]
+        vis[0, :, :, start:start + ws][vt] = o["vis"][vt]
+        traj[0, :, 0:1, start:start + ws][vt] = o["traj"][:, 0:1][vt]
+        traj[0, :, 1:2, start:start + ws][vt] = o["traj"][:, 1:2][vt]
+        dep[0, :, :, start:start + ws][vt] = o["depth"][vt]
+        if wi == len(time_strides) - 1:
+            continue
+        nxt = int(time_strides[wi + 1])
+        pfeat[valid_n] = o["prompt_features"][valid_n]
+        plab[valid_n] = 1
+        # memory tokens: keep the 2nd temporal half, pad with the learned mask token (sparse_heads.py:406-448)
+        h5 = o["history"].reshape(N, nt, nh, nw, cfg.dim)
+        hist = torch.cat([h5[:, nt // 2:], mask_tok.expand(N, nt // 2, nh, nw, cfg.dim)], dim=1).reshape(N, cfg.tokens, cfg.dim)
+        # re-seed the query at the most visible overlap frame (sparse_heads.py:455-486)
+        ov_vis = vis[0, :, 0, nxt:start + ws]
+        ov_traj = traj[0, :, :, nxt:start + ws]
+        best = torch.argmax(ov_vis, dim=-1)  # [N]
+        new_q = torch.stack([best.float() + nxt + 0.5, ov_traj[torch.arange(N), 0, best], ov_traj[torch.arange(N), 1, best]], dim=-1)
+        use = new_q[:, 0] > cur_q[:, 0]
+        cur_q[use] = new_q[use]
+        if trace is not None:
+            trace[-1]["best_vis_id"] = best.clone()
+            trace[-1]["reseeded"] = use.clone()
+    return {f"{task}_traj_est_bn2t": traj, f"{task}_vis_est_bn1t": vis, f"{task}_depth_est_bn1t": dep}
+
+
+# --------------------------------------------------------------------------------------------------
+# whole model (L4P_VideoMAE.forward l4p_videomae.py:256-330)
+# --------------------------------------------------------------------------------------------------
+class OracleModel:
+    """Functional restatement of L4P_VideoMAE(always_use_windowed_version=True, joint_alignment=True) with the
+    five heads of configs/model.yaml.  ``use_intrinsics`` mirrors task_heads['camray'].use_intrinsics."""
+
+    def __init__(self, sd: Dict[str, Tensor], cfg, use_intrinsics: bool = True, max_queries: int = 192):
+        self.sd, self.cfg = sd, cfg
+        self.use_intrinsics = use_intrinsics
+        self.max_queries = max_queries
+        # actpost / fusion scale factors: dense_heads.py:30-31 and :269-271
+        self._actpost = lambda t: ((1, 0, 0), (1, 0, 0), (0, 0, 0), (-1, -1, -1)) if t == "camray" else ((1, 2, 2), (1, 1, 1), (0, 0, 0), (-1, -1, -1))
+        self._fusion = lambda t: ((1, 1, 1), (1, 1, 1), (2, 1, 1), (2, 2, 2)) if t == "camray" else ((1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2))
+
+    # ---- dense heads: dense_heads.py:66-74,172-182,208-217,292-352 -------------------------------
+    def dense_single(self, task: str, feats: Sequence[Tensor], intrinsics_b44t: Optional[Tensor]) -> Dict[str, Tensor]:
+        cfg = self.cfg
+        osz = (16, 16, 16) if task == "camray" else None
+        raw = dpt_forward(self.sd, task, feats, cfg, self._actpost(task), self._fusion(task), osz)
+        if task == "flow_2d_backward":
+            return {"flow_2d_backward_est_b2thw": raw[:, :2]}
+        if task == "depth":
+            return {"depth_est_b1thw": torch.exp(raw[:, :1])}
+        if task == "dyn_mask":
+            return {"dyn_mask_est_b1thw": raw}
+        if task == "camray":
+            if not self.use_intrinsics:
+                raise NotImplementedError("K estimation uses cv2 RANSAC in the reference: parity unpinned")
+            T, H, W = cfg.frames, cfg.img, cfg.img
+            E = rays_to_cameras(raw.float(), normalize_intrinsics(intrinsics_b44t, H, W).float())
+            pose = torch.linalg.inv(E.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+            return {"traj3d_est_b16t": pose.reshape(pose.shape[0], 16, T)}
+        raise KeyError(task)
+
+    def dense_windowed(self, task: str, feats2d: Sequence[Sequence[Tensor]], strides: Sequence[int],
+                       intrinsics_b44t: Tensor) -> Dict[str, Tensor]:
+        """VideoMAEFlowDPTHead.forward_windowed dense_heads.py:76-143."""
+        ws = self.cfg.frames
+        T = int(strides[-1]) + ws
+        buf, key = None, None
+        for wi, st in enumerate(int(s) for s in strides):
+            o = self.dense_single(task, feats2d[wi], intrinsics_b44t[..., st:st + ws])
+            key = next(k for k in o if "intrinsics" not in k)
+            out = o[key]
+            if buf is None:
+                shp = list(out.shape)
+                shp[2] = T
+                buf = torch.zeros(*shp)
+            if wi > 0 and task == "depth":
+                ov = int(strides[wi - 1]) + ws - st
+                sol = lstsq_affine_solve(out[:, :, :ov], buf[:, :, st:st + ov])
+                out = lstsq_affine_apply(out, sol)
+            if task == "flow_2d_backward" and wi > 0:
+                buf[:, :, st + 1:st + ws] = out[:, :, 1:]
+            else:
+                buf[:, :, st:st + ws] = out
+        return {key: buf}
+
+    def joint_depth_camray(self, feats2d, strides, intrinsics_b44t) -> Dict[str, Tensor]:
+        """joint_windowed_estimation dense_heads.py:360-492 — single-window case only (the multi-window seam
+        alignment is skimage RANSAC: parity unpinned)."""
+        if len(strides) != 1:
+            raise NotImplementedError("KabaschUmeyama3DAligner needs skimage.measure.ransac: parity unpinned")
+        out = {}
+        out.update(self.dense_single("depth", feats2d[0], intrinsics_b44t[..., :self.cfg.frames]))
+        out.update(self.dense_single("camray", feats2d[0], intrinsics_b44t[..., :self.cfg.frames]))
+        # no estimated K when use_intrinsics: the input K is echoed (dense_heads.py:419-422)
+        ws = self.cfg.frames
+        out["traj3d_intrinsics_est_b16t"] = intrinsics_b44t[..., :ws].clone().reshape(1, 16, ws)
+        return out
+
+    def track(self, feats2d, strides, queries_bn3: Tensor, labels_bn: Tensor, trace=None) -> Dict[str, Tensor]:
+        """forward_windowed sparse_heads.py:162-211 (chunks of max_queries)."""
+        last = [f[-1] for f in feats2d]
+        N = queries_bn3.shape[1]
+        if N < self.max_queries:
+            return track_windowed(self.sd, self.cfg, last, queries_bn3, labels_bn, strides, trace=trace)
+        outs = []
+        for i in range(int(math.ceil(N / self.max_queries))):
+            sl = slice(i * self.max_queries, (i + 1) * self.max_queries)
+            outs.append(track_windowed(self.sd, self.cfg, last, queries_bn3[:, sl], labels_bn[:, sl], strides, trace=trace))
+        return {k: torch.cat([o[k] for o in outs], dim=1) for k in outs[0]}
+
+    def forward(self, batch: Dict[str, Tensor], tasks: Sequence[str], trace=None) -> Dict[str, Tensor]:
+        cfg = self.cfg
+        rgb = batch["rgb_b3thw"]
+        B, _, T, H, W = rgb.shape
+        assert H == cfg.img and W == cfg.img
+        assert T % 8 == 0
+        strides = list(range(0, T - cfg.frames + 1, 8))
+        feats2d = [encoder_forward(self.sd, rgb[:, :, s:s + cfg.frames], cfg) for s in strides]
+        out: Dict[str, Tensor] = {}
+        K = batch["intrinsics_b44t"]
+        if "depth" in tasks and "camray" in tasks:
+            for task in ("track_2d", "dyn_mask", "flow_2d_backward"):
+                if task in tasks:
+                    out.update(self._one(task, feats2d, strides, batch, trace))
+            out.update(self.joint_depth_camray(feats2d, strides, K))
+        else:
+            for task in tasks:
+                out.update(self._one(task, feats2d, strides, batch, trace))
+        return out
+
+    def _one(self, task, feats2d, strides, batch, trace):
+        if task == "track_2d":
+            return self.track(feats2d, strides, batch["track_2d_pointquerries_bn3"], batch["track_2d_pointlabels_bn"], trace)
+        return self.dense_windowed(task, feats2d, strides, batch["intrinsics_b44t"])

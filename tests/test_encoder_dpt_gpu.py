@@ -1,0 +1,82 @@
+"""End-to-end parity on the GPU: encoder + dense DPT heads of the MINI geometry (704-wide, 4 blocks)
+against (a) the oracle run live on the host CPU and (b) the golden vectors produced by the real
+reference (tests/golden/mini_T16_all.npz).
+
+Tolerances: L4P_F32 engine — 1e-3 * max|ref| (north_star; measured ~1e-5).  L4P_BF16 engine — the
+bf16 storage/MFMA drift of a 4-block encoder + 20-conv decoder: rel-L2 <= 3e-2 (reported, not the
+1e-3 gate; see DESIGN.md "precision modes").
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from l4p_amd._lib import L4P_BF16, L4P_F32
+from l4p_amd.models.utils import build_model
+from l4p_amd.weights import ModelCfg, seeded_state_dict
+from tests.golden_utils import make_batch, sample_indices
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def mini():
+    cfg = ModelCfg.mini()
+    sd = seeded_state_dict(cfg)
+    return cfg, sd
+
+
+def build(cfg, sd, precision):
+    m = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision=precision, model_cfg=cfg)
+    # hooks of the mini geometry
+    for k, h in m.l4p_model.task_heads.items():
+        if hasattr(h, "hooks_idx"):
+            h.hooks_idx = list(cfg.hooks)
+    m.l4p_model.task_heads["camray"].use_intrinsics = True  # as demo.py:215 (cv2-free path)
+    m.load_state_dict({"l4p_model." + k: v for k, v in sd.items()})
+    return m
+
+
+def rel_l2(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("precision,tol_max,tol_l2", [("32-true", 1e-3, 1e-3), ("bf16", None, 3e-2)])
+def test_mini_encoder_and_dense_heads_vs_oracle_and_golden(dev, mini, precision, tol_max, tol_l2):
+    from oracle.l4p_oracle import OracleModel, encoder_forward
+
+    cfg, sd = mini
+    model = build(cfg, sd, precision)
+    batch = make_batch(16, 8)
+    gold = np.load(os.path.join(GOLD, "mini_T16_all.npz"))
+    tasks = ["depth", "flow_2d_backward", "dyn_mask", "camray"]
+    with torch.no_grad():
+        out = model.forward({k: v.clone() for k, v in batch.items()}, tasks)
+        feats = out["enc_features_bpc_2dlist"][0]
+        ofeats = encoder_forward(sd, batch["rgb_b3thw"], cfg)
+        oout = OracleModel(sd, cfg, use_intrinsics=True).forward(batch, tasks)
+    torch.cuda.synchronize()
+    # encoder hooks vs oracle (full tensors) and vs the reference's golden samples
+    for li in cfg.hooks:
+        f = feats.f32(li).cpu()
+        assert rel_l2(f, ofeats[li]) <= tol_l2, (li, rel_l2(f, ofeats[li]))
+        if tol_max is not None:
+            assert (f - ofeats[li]).abs().max() <= tol_max * ofeats[li].abs().max()
+            g = torch.from_numpy(gold[f"feat{li}"])
+            s = f.reshape(-1)[sample_indices(f.numel())]
+            assert (s - g).abs().max() <= tol_max * g.abs().max(), li
+    for key in ["depth_est_b1thw", "flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw", "traj3d_est_b16t",
+                "traj3d_intrinsics_est_b16t"]:
+        y, ref = out[key].float().cpu(), oout[key]
+        assert y.shape == ref.shape, key
+        e = rel_l2(y, ref)
+        assert e <= tol_l2, (key, e)
+        if tol_max is not None:
+            assert (y - ref).abs().max() <= tol_max * ref.abs().max(), key
+            g = torch.from_numpy(gold[key]).reshape(-1)
+            s = y.reshape(-1)[sample_indices(y.numel())] if y.numel() > 4096 else y.reshape(-1)
+            assert (s - g).abs().max() <= tol_max * g.abs().max(), key
