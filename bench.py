@@ -1,0 +1,249 @@
+"""Throughput benchmark of the L4P hot path on MI355X (contract in the task statement).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one forward of the hot path (shared encoder + the workload's heads) over one batch of
+synthetic 16x224x224 clips already resident in HBM.  One process per GPU, clips sharded with no
+collective in the step (weak scaling: per-GPU batch fixed); the only collective is the one-off RCCL
+broadcast of the packed weight arena before the timed region.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs): c2 = depth head only, bf16, batch 1 (default; configs[1]);
+c3 = all heads, bf16, batch 4 (configs[2]).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from l4p_amd import _lib  # noqa: E402
+from l4p_amd.models.utils import build_model  # noqa: E402
+from l4p_amd.packing import pack_state_dict  # noqa: E402
+from l4p_amd.parallel import broadcast_weights, init_distributed  # noqa: E402
+from l4p_amd.weights import ModelCfg, actpost_of, fusion_of, seeded_state_dict  # noqa: E402
+
+PEAK_BF16_MFMA = 2.5e15  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+ALL_TASKS = ["flow_2d_backward", "track_2d", "depth", "dyn_mask", "camray"]
+
+
+def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int):
+    """FLOPs (2*MAC, padding excluded) of one 16-frame window per kernel class, from the model graph
+    (SURVEY.md §2.1 / BASELINE.md §4)."""
+    S, D, Hd, H, dh = cfg.tokens, cfg.dim, cfg.mlp_hidden, cfg.heads, cfg.head_dim
+    kraw = cfg.in_chans * cfg.patch[0] * cfg.patch[1] * cfg.patch[2]
+    dense = [t for t in tasks if t in cfg.dense_tasks]
+    depth_run = max(cfg.hooks) if dense and "track_2d" not in tasks else cfg.depth
+    gemm = 2.0 * S * kraw * D + depth_run * 2.0 * S * (D * 3 * D + D * D + 2 * D * Hd)
+    attn = depth_run * 4.0 * S * S * dh * H
+    conv = 0.0
+    nt, nh, nw = cfg.grid
+    for t in dense:
+        ap, fu = actpost_of(t), fusion_of(t)
+        shapes = []
+        for i in range(4):
+            L = cfg.layer_dims[i]
+            gemm += 2.0 * S * D * L
+            g = [nt, nh, nw]
+            if any(s > 0 for s in ap[i]):
+                k = [2 ** s for s in ap[i]]
+                gemm += 2.0 * S * L * L * k[0] * k[1] * k[2]
+                g = [g[j] * k[j] for j in range(3)]
+            elif any(s < 0 for s in ap[i]):
+                g = [(g[j] - 1) // (2 ** (-ap[i][j])) + 1 for j in range(3)]
+                conv += 2.0 * g[0] * g[1] * g[2] * 27 * L * L
+            vox = g[0] * g[1] * g[2]
+            conv += 2.0 * vox * 27 * L * cfg.feature_dim
+            shapes.append(g)
+        F_ = cfg.feature_dim
+        cur = None
+        for r, i in ((4, 3), (3, 2), (2, 1), (1, 0)):
+            g = shapes[i]
+            vox = g[0] * g[1] * g[2]
+            n_rcu = 1 if r == 4 else 2
+            conv += n_rcu * 2 * 2.0 * vox * 27 * F_ * F_
+            gemm += 2.0 * vox * F_ * F_  # out_conv (applied before the up-sampling here)
+            cur = [g[j] * fu[i][j] for j in range(3)]
+        vox = cur[0] * cur[1] * cur[2]
+        conv += 2.0 * vox * 27 * F_ * (F_ // 2)
+        osz = (16, 16, 16) if t == "camray" else (cfg.frames, cfg.img, cfg.img)
+        vo = osz[0] * osz[1] * osz[2]
+        conv += 2.0 * vo * 27 * (F_ // 2) * cfg.last_dim
+    track = 73.81e9 * n_queries if "track_2d" in tasks else 0.0
+    return {"gemm": gemm, "conv3d": conv, "attention": attn, "track": track}
+
+
+def read_prof(lib):
+    out = {}
+    for c in range(lib.l4p_prof_num_classes()):
+        ms, n = C.c_double(0), C.c_longlong(0)
+        _lib.check(lib.l4p_prof_read(c, C.byref(ms), C.byref(n)), "l4p_prof_read")
+        out[lib.l4p_prof_class_name(c).decode()] = (ms.value, n.value)
+    return out
+
+
+def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 4):
+    """Oracle (plain PyTorch fp32 port of the reference algorithm) on the host cores, 1 clip, BOUNDED sample:
+    patch embed + ``sample_blocks`` of the ``depth`` identical encoder blocks are timed and the block time is
+    scaled by depth/sample_blocks; the heads are timed in full on the features of that shortened encoder."""
+    from oracle import l4p_oracle as orc
+
+    threads = min(os.cpu_count() or 1, 64)  # torch CPU ops stop scaling (and regress) far below 256 threads
+    torch.set_num_threads(threads)
+    rgb = batch_cpu["rgb_b3thw"]
+    with torch.no_grad():
+        t0 = time.time()
+        feats = orc.encoder_forward(sd, rgb, cfg, upto=0)
+        t_embed = time.time() - t0
+        t0 = time.time()
+        x = feats[0]
+        for i in range(sample_blocks):
+            x = orc.encoder_block(sd, f"video_encoder.blocks.{i}.", x, cfg.heads, cfg.ln_eps)
+        t_blocks = (time.time() - t0) / sample_blocks
+        fl = [x] * (cfg.depth + 1)  # same shapes/statistics class as the real hooks; values are irrelevant for timing
+        om = orc.OracleModel(sd, cfg, use_intrinsics=True)
+        t0 = time.time()
+        for t in tasks:
+            om.dense_single(t, fl, batch_cpu["intrinsics_b44t"])
+        t_heads = time.time() - t0
+    dt = t_embed + t_blocks * cfg.depth + t_heads
+    return {"value": round(16.0 / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": (f"1 clip (16x224x224), tasks={'+'.join(tasks)}: oracle (plain PyTorch fp32 port of the reference) on the host CPU; "
+                       f"timed patch-embed {t_embed:.2f}s + {sample_blocks}/{cfg.depth} encoder blocks ({t_blocks:.2f}s each, scaled x{cfg.depth}) "
+                       f"+ heads in full {t_heads:.2f}s -> {dt:.1f}s per clip")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default: 1 for c2, 4 for c3)")
+    ap.add_argument("--queries", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = init_distributed()
+    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    lib = _lib.load()
+
+    cfg = ModelCfg.full()
+    tasks = ["depth"] if args.workload == "c2" else list(ALL_TASKS)
+    B = args.batch or (1 if args.workload == "c2" else 4)
+
+    model = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision="bf16")
+    net = model.l4p_model
+    net.task_heads = torch.nn.ModuleDict({t: net.task_heads[t] for t in tasks})
+    if "camray" in tasks:
+        net.task_heads["camray"].use_intrinsics = True
+    sd, pw = None, None
+    if rank == 0:
+        sd = seeded_state_dict(cfg, tasks=tasks)
+        pw = pack_state_dict(sd, cfg, torch.bfloat16, device, tasks=tasks)
+    pw = broadcast_weights(pw, device)  # RCCL over xGMI, once
+    net.set_weights(pw)
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    rgb = torch.randn([B, 3, 16, 224, 224], generator=g, dtype=torch.float32)
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 224.0
+    K[0, 2] = K[1, 2] = 112.0
+    batch = {"rgb_b3thw": rgb.to(device), "intrinsics_b44t": K[None, :, :, None].repeat(B, 1, 1, 16).to(device)}
+    if "track_2d" in tasks:
+        nq = args.queries
+        q = torch.zeros(1, nq, 3)
+        for i in range(nq):
+            q[0, i] = torch.tensor([0.5, 14.0 + 28.0 * (i % 8) + 0.5, 14.0 + 28.0 * ((i // 8) % 8) + 0.5])
+        batch["track_2d_pointquerries_bn3"] = q.to(device)
+        batch["track_2d_pointlabels_bn"] = torch.ones(1, nq, device=device)
+
+    def step():
+        with torch.no_grad():
+            return model.forward(batch, tasks)
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_prof:
+        lib.l4p_prof_reset()
+        lib.l4p_prof_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    lib.l4p_prof_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank != 0:
+        return
+    frames = world * B * 16 * args.steps
+    res = {
+        "metric": "frames/sec, 16x224x224 clip (workload heads, see config); encoder MFMA-roofline %",
+        "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (randn clips, name-seeded random weights of the VideoMAE-v2-giant + DPT geometry)",
+        "config": {"workload": ("configs[1]: single MI355X, depth head only, bf16, batch=1 16-frame 224x224 clip" if args.workload == "c2"
+                                 else f"configs[2]: all heads (depth+flow+track2d/3d+motion-seg+pose), bf16, batch={B} clips, {args.queries} track queries"),
+                   "clips_per_gpu_per_step": B, "tasks": tasks, "parallelism": f"dp{world} (clips sharded, no collective in the step)"},
+    }
+    if not args.no_prof:
+        prof = read_prof(lib)
+        fl = algorithmic_flops(cfg, tasks, args.queries if "track_2d" in tasks else 0)
+        classes = {}
+        for name, (ms, n) in prof.items():
+            if n == 0:
+                continue
+            per_step_ms = ms / args.steps
+            ent = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n / args.steps,
+                   "avg_launch_us": round(ms / n * 1e3, 3)}
+            if name in fl and fl[name] > 0:
+                ent["tflops"] = round(fl[name] * B / (per_step_ms * 1e-3) / 1e12, 2)
+            classes[name] = ent
+        mfma = [k for k in ("gemm", "conv3d", "attention") if k in classes]
+        dom = max(mfma, key=lambda k: classes[k]["ms_per_step"])
+        kern = {"gemm": "gemm_kernel<bf16,MODE0> (linear / 1x1x1 conv / ConvTranspose GEMM)",
+                "conv3d": "gemm_kernel<bf16,MODE1> (implicit-GEMM 3x3x3 conv)", "attention": "attn_kernel<bf16,96,64>"}
+
+        def roof(k):
+            a = classes[k]["tflops"]
+            return {"kernel": kern[k], "bound": "mfma", "achieved": a, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
+                    "frac": round(a / (PEAK_BF16_MFMA / 1e12), 4), "traffic": None,
+                    "avg_launch_us": classes[k]["avg_launch_us"], "launches_per_step": classes[k]["launches_per_step"],
+                    "algorithmic_flops_per_step": fl[k] * B}
+
+        res["roofline"] = roof(dom)
+        if "attention" in classes and dom != "attention":
+            res["roofline_attention"] = roof("attention")
+        res["kernel_classes"] = classes
+    if world == 1 and not args.no_cpu_baseline:
+        bc = {k: (v[:1].cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        cpu_tasks = [t for t in tasks if t != "track_2d"]  # dense heads only: the tracker port is timed in tests, not here
+        res["cpu_baseline"] = cpu_baseline(sd, cfg, cpu_tasks, bc)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

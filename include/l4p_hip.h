@@ -43,6 +43,16 @@ typedef struct l4p_engine l4p_engine;
 const char* l4p_last_error(void);
 int l4p_abi_version(void);
 
+/* Optional per-kernel-class timing: when enabled every kernel launch is bracketed by a HIP event pair
+ * recorded on the launch stream (bench.py's live roofline numbers).  Classes: gemm, conv3d, attention,
+ * layernorm, elementwise, track.  l4p_prof_read sums the pair durations of one class since the last
+ * reset; the caller synchronises the stream first. */
+int l4p_prof_enable(int on);
+int l4p_prof_reset(void);
+int l4p_prof_num_classes(void);
+const char* l4p_prof_class_name(int cls);
+int l4p_prof_read(int cls, double* total_ms, long long* count);
+
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level entry points (also the unit-parity surface of tests/).
  * ---------------------------------------------------------------------------------------------- */

@@ -56,6 +56,11 @@ _VP, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 SIGNATURES = {
     "l4p_last_error": (C.c_char_p, []),
     "l4p_abi_version": (_I, []),
+    "l4p_prof_enable": (_I, [_I]),
+    "l4p_prof_reset": (_I, []),
+    "l4p_prof_num_classes": (_I, []),
+    "l4p_prof_class_name": (C.c_char_p, [_I]),
+    "l4p_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "l4p_gemm": (_I, [_VP, _I, C.POINTER(GemmDesc)]),
     "l4p_conv3d_k3": (_I, [_VP, _I, C.POINTER(GemmDesc)]),
     "l4p_layernorm": (_I, [_VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I]),

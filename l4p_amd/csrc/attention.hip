@@ -215,6 +215,7 @@ static int launch_attn_t(const void* qk, const void* vt, void* out, int B, int S
         attr_set = true;
     }
     const float c_scale = scale * 1.4426950408889634f;
+    ProfScope prof(PROF_ATTENTION, stream);
     hipLaunchKernelGGL(kern, dim3(S / 128, H, B), dim3(256), lds, stream, (const T*)qk, (const T*)vt, (T*)out, S, H,
                        Dh, c_scale);
     HIP_TRY(hipGetLastError());

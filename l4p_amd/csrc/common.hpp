@@ -59,6 +59,8 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+#include "prof.hpp"
+
 // host-side error plumbing (defined in api.hip)
 void l4p_set_error(const char* fmt, ...);
 #define HIP_TRY(expr)                                                                  \

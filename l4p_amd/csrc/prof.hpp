@@ -1,0 +1,29 @@
+// Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's live
+// roofline measurement).  Disabled by default: a ProfScope is then two predictable branches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum ProfClass {
+    PROF_GEMM = 0,      // gemm_kernel<..., MODE 0>: linears, 1x1x1 convs, ConvTranspose-as-GEMM
+    PROF_CONV3D,        // gemm_kernel<..., MODE 1>: implicit-GEMM 3x3x3 conv
+    PROF_ATTENTION,     // attn_kernel
+    PROF_LAYERNORM,
+    PROF_ELEMENTWISE,   // cast / patch gather / upsample / head_out / alignment / pose
+    PROF_TRACK,         // tracker-specific small kernels
+    PROF_NUM
+};
+
+void prof_begin(int cls, hipStream_t stream);
+void prof_end(int cls, hipStream_t stream);
+extern bool g_prof_on;
+
+struct ProfScope {
+    int cls;
+    hipStream_t s;
+    ProfScope(int c, hipStream_t st) : cls(c), s(st) {
+        if (g_prof_on) prof_begin(cls, s);
+    }
+    ~ProfScope() {
+        if (g_prof_on) prof_end(cls, s);
+    }
+};

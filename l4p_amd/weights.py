@@ -255,6 +255,9 @@ def seeded_tensor(name: str, shape: Tuple[int, ...]) -> torch.Tensor:
         return 0.05 * t
     if len(shape) == 2 and shape[0] in (1, 3) and "embed" in cname or cname.endswith("_token.weight") or cname.endswith("mask_tokens.weight"):
         return 0.5 * t  # nn.Embedding tables
+    if cname.endswith("head2.2.weight"):
+        # final 1x1x1 projection: keep the logits O(1) so exp() (depth) stays well conditioned
+        return t * 0.25 * (float(shape[1]) ** -0.5)
     if _is_conv_transpose(cname):
         fan_in = shape[0]
     else:

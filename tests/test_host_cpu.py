@@ -1,0 +1,107 @@
+"""CPU: host-side logic — state-dict schema vs the reference manifests, packing layouts, config
+instantiation, the C ABI surface, loud failure without a GPU."""
+import json
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from l4p_amd import _lib, packing
+from l4p_amd.weights import ModelCfg, seeded_state_dict, seeded_tensor, state_dict_schema
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name,cfg", [("mini", ModelCfg.mini()), ("full", ModelCfg.full())])
+def test_schema_matches_reference_manifest(name, cfg):
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", f"manifest_{name}.json")))
+    sch = state_dict_schema(cfg)
+    assert set(sch) == set(man)
+    for k, shp in sch.items():
+        assert list(shp) == man[k], k
+    if name == "full":
+        assert len(sch) == 916
+
+
+def test_seeded_weights_deterministic_and_aliased():
+    a = seeded_tensor("task_heads.depth.task_head.dpt.scratch.layer2_rn.weight", (256, 512, 3, 3, 3))
+    b = seeded_tensor("task_heads.depth.task_head.dpt.scratch.layer_rn.1.weight", (256, 512, 3, 3, 3))
+    assert torch.equal(a, b)  # same module object in the reference (dpt_block.py:44-88)
+    assert torch.equal(seeded_tensor("video_encoder.norm.weight", (8,)), seeded_tensor("video_encoder.norm.weight", (8,)))
+
+
+def test_abi_header_symbols_are_bound_and_exported():
+    hdr = open(os.path.join(ROOT, "include", "l4p_hip.h")).read()
+    declared = set(re.findall(r"\b(l4p_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"l4p_stream"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), sorted(declared ^ set(_lib.SIGNATURES))
+    lib = _lib.load()  # resolves every symbol; raises if the .so lacks one
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.l4p_abi_version() >= 1
+    assert lib.l4p_prof_num_classes() >= 3
+
+
+def test_packing_conv_and_convT_matrices_reproduce_torch_ops():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 8, 3, 4, 5, generator=g)
+    w = torch.randn(6, 8, 3, 3, 3, generator=g)
+    ref = F.conv3d(x, w, padding=1)
+    wm = packing.conv3_matrix(w)  # [Co][27*Ci], k = tap*Ci + ci
+    xp = F.pad(x, (1, 1, 1, 1, 1, 1))
+    cols = []
+    for dt in range(3):
+        for dh in range(3):
+            for dw in range(3):
+                cols.append(xp[:, :, dt:dt + 3, dh:dh + 4, dw:dw + 5])
+    col = torch.stack(cols, 1).reshape(1, 27 * 8, -1)  # [1][tap*Ci][vox]
+    out = (wm @ col[0]).reshape(1, 6, 3, 4, 5)
+    assert torch.allclose(out, ref, atol=1e-4)
+    wt = torch.randn(8, 6, 2, 2, 2, generator=g)
+    reft = F.conv_transpose3d(x, wt, stride=2)
+    m = packing.convT_matrix(wt)  # [taps*Co][Ci], row = tap*Co + co
+    y = (m @ x.reshape(8, -1)).reshape(2, 2, 2, 6, 3, 4, 5)  # dt dh dw co t h w
+    y = y.permute(3, 4, 0, 5, 1, 6, 2).reshape(1, 6, 6, 8, 10)
+    assert torch.allclose(y, reft, atol=1e-4)
+
+
+def test_pack_encoder_layouts_on_cpu():
+    cfg = ModelCfg(dim=176, depth=1, heads=2, mlp_hidden=768, hooks=(1, 1, 1, 1))
+    sd = seeded_state_dict(cfg, tasks=[])
+    pw = packing.pack_state_dict(sd, cfg, torch.float32, torch.device("cpu"), tasks=[])
+    assert pw.meta["patch_kp"] == 1216
+    qkv = pw["enc.blk0.qkv.w"]
+    assert qkv.shape == (640, 176)  # 3*2*96 = 576 rows padded to 640
+    w = qkv[:576].view(3, 2, 96, 176)
+    assert torch.equal(w[:, :, :88], sd["video_encoder.blocks.0.attn.qkv.weight"].view(3, 2, 88, 176))
+    assert float(w[:, :, 88:].abs().max()) == 0.0
+    b = pw["enc.blk0.qkv.b"].view(3, 2, 96)
+    assert torch.equal(b[0, :, :88], sd["video_encoder.blocks.0.attn.q_bias"].view(2, 88))
+    assert float(b[1].abs().max()) == 0.0  # zero k bias, modeling_finetune.py:171-175
+    pos = pw["enc.pos"]
+    from oracle.l4p_oracle import sinusoid_table
+
+    assert torch.equal(pos, sinusoid_table(2048, 176)[0])
+    # arena views are disjoint and 256-byte aligned
+    offs = sorted((off, name) for name, shp, dt, off in pw.layout)
+    assert all(o % 256 == 0 for o, _ in offs)
+
+
+def test_config_surface_and_loud_failure_without_gpu():
+    from l4p_amd.models.utils import build_model
+
+    m = build_model(os.path.join(ROOT, "configs", "model.yaml"), max_queries=64, precision="16-mixed")
+    assert type(m).__name__ == "L4PLitModule" and m.tasks == ["flow_2d_backward", "track_2d", "depth", "dyn_mask", "camray"]
+    net = m.l4p_model
+    assert net.always_use_windowed_version and net.joint_alignment
+    assert net.task_heads["track_2d"].max_queries == 64
+    assert net.task_heads["camray"].use_intrinsics is False  # shipped default, flipped by the caller (demo.py:215)
+    assert net.task_heads["depth"].hooks_idx == [14, 21, 28, 36]
+    with pytest.raises(RuntimeError):  # strict key check happens before any device work
+        m.load_state_dict({"l4p_model.video_encoder.norm.weight": torch.zeros(1408)})
+    if not torch.cuda.is_available():
+        with pytest.raises((RuntimeError, _lib.L4PHipError)):
+            net.forward({"rgb_b3thw": torch.zeros(1, 3, 16, 224, 224)}, ["depth"])

@@ -121,20 +121,25 @@ def run_case(name: str, cfg: ModelCfg, model, sd, T: int, tasks, nq: int, out_di
     batch = make_batch(T, nq)
     trace_ref = []
 
-    def pre_hook(mod, args, kwargs):
-        if "track_2d_promptfeaturelabels_bn" in kwargs:  # the per-window call made by forward_windowed_core
+    # forward_windowed_core calls self.forward(...) directly (no module hooks fire), so shadow the bound method
+    head = model.task_heads["track_2d"]
+    orig_forward = head.forward
+
+    def spy_forward(*a, **kwargs):
+        if "track_2d_promptfeaturelabels_bn" in kwargs:  # the per-window call
             trace_ref.append({
                 "labels": kwargs["track_2d_pointlabels_bn"][0].clone(),
                 "queries": kwargs["track_2d_pointquerries_bn3"][0].clone(),
                 "prompt_labels": kwargs["track_2d_promptfeaturelabels_bn"][0].clone(),
             })
+        return orig_forward(*a, **kwargs)
 
-    h = model.task_heads["track_2d"].register_forward_pre_hook(pre_hook, with_kwargs=True)
+    head.forward = spy_forward
     t0 = time.time()
     with torch.no_grad():
         out = model.forward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, list(tasks))
     t_ref = time.time() - t0
-    h.remove()
+    del head.forward
     feats2d = out.pop("enc_features_bpc_2dlist")
 
     trace_or = []
