@@ -95,6 +95,11 @@ typedef struct l4p_gemm_desc {
     /* L4P_EPI_CONVT: n = tap*Cout + co, tap = (dt*kh + dh)*kw + dw; A rows are the (Ti,Hi,Wi) grid;
      * output is channels-last [B][Ti*kt][Hi*kh][Wi*kw][Cout] */
     int kt, kh, kw, Cout;
+    /* optional row re-mapping (0 = off): logical row m lives at physical row
+     * (m / gr) * gs + go + (m % gr) — used to read / write one temporal half of per-query token blocks
+     * (tracker memory tokens, sparse_heads.py:406-448).  a_*: rows of A, c_*: rows of out / residual. */
+    int a_gr, a_gs, a_go;
+    int c_gr, c_gs, c_go;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
@@ -144,6 +149,59 @@ int l4p_affine_align_apply(l4p_stream stream, const float* x, float* y, long lon
  * H x W image  ->  out float [B][16][T] = row-major world_T_cam per frame. */
 int l4p_rays_to_pose(l4p_stream stream, const float* rays, const float* K, float* out, int B, int T, int h, int w,
                      int H, int W);
+
+/* ------------------------------------------------------------------------------------------------
+ * SAM-style point tracker (sparse_heads.py, sam/{prompt_encoder,transformer,mask_decoder}.py).
+ * The projections of the two-way transformer run through l4p_gemm; these are the remaining pieces.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* LayerNorm with the tracker's fused extras: y = LN(x) [then GELU if act == L4P_ACT_GELU, as in
+ * mask_decoder.py:60-62]; out_f32 = y, out_T = T(y), out_T2 = T(y + add[row % add_mod]) — the
+ * "queries + query_pe" / "keys + key_pe" operands of sam/transformer.py:166-185. */
+int l4p_layernorm_ex(l4p_stream stream, int dtype, const float* x, const float* gamma, const float* beta, float eps,
+                     void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act);
+
+/* PromptEncoder (prompt_encoder.py:78-121,196-203) + token concat (mask_decoder.py:107-113):
+ * tokens float [N][6][C] = 3 mask tokens | point PE + label embedding | not-a-point | feature prompt. */
+int l4p_track_tokens(l4p_stream stream, const float* queries, const float* labels, const float* pfeat,
+                     const float* plabel, const float* gauss, const float* mask_tokens, const float* point_emb0,
+                     const float* point_emb1, const float* not_a_point, const float* feat_emb0, const float* feat_emb1,
+                     float* tokens, int N, int C, int T, int H, int W);
+
+/* keys = enc_features[-1] (broadcast over queries) + per-query history (sparse_heads.py:341-346):
+ * k32 float, kT = T(keys), kP = T(keys + dense_pe), each [N][P][C]. */
+int l4p_track_keys_init(l4p_stream stream, int dtype, const float* enc, const float* hist, const float* pos,
+                        float* k32, void* kT, void* kP, int N, int P, int C);
+
+/* Broadcast a C-vector into `rows` rows of a float matrix (row map as in l4p_gemm_desc.a_*): the learned
+ * mask token of the memory mechanism (sparse_heads.py:262-265,418-427). */
+int l4p_fill_rows(l4p_stream stream, float* out, const float* v, long long rows, int C, long long group_rows,
+                  long long group_stride, long long group_off);
+
+/* Attention of sam/transformer.py:223-245 after the projections. kind 0: 6 prompt tokens among themselves
+ * (q,k,v,out [N][6][D]); kind 1: tokens -> image (q [N][6][D], k,v [N][P][D], out [N][6][D]);
+ * kind 2: image -> tokens (q [N][P][D], k,v [N][6][D], out [N][P][D]). */
+int l4p_small_attn(l4p_stream stream, int dtype, int kind, const void* q, const void* k, const void* v, void* out,
+                   int N, int P, int D, int heads);
+
+/* masks[n][m][vox] = hyper[n][m][:] . up[n][vox][:]  (mask_decoder.py:139); up channels-last T. */
+int l4p_mask_product(l4p_stream stream, int dtype, const void* up, const float* hyper, float* masks, int N,
+                     long long vox, int C);
+
+/* Fused read-out (sparse_heads.py:572-589,645-647): trilinear (align_corners=False) resize of masks
+ * [N][3][T][h][w] to H x W, soft-argmax of channel 0 (traj [N][2][T]), spatial mean of channel 1
+ * (vis [N][T]) and exp(mean) of channel 2 (depth [N][T]); the up-sampled logits are never stored. */
+int l4p_track_readout(l4p_stream stream, const float* masks, float* traj, float* vis, float* depth, int N, int T,
+                      int h, int w, int H, int W);
+
+/* Sliding-window state of forward_windowed_core (sparse_heads.py:303-335 prepare; :366-393,:455-486 commit).
+ * Integer / boolean results (valid masks, labels {0,1,2}, argmax index) are bit-exact w.r.t. the reference. */
+int l4p_track_prepare(l4p_stream stream, const float* cur_q, const float* orig_q, int start, int ws, float* q_off,
+                      float* labels, unsigned char* valid_t, unsigned char* valid_n, int N);
+int l4p_track_commit(l4p_stream stream, const float* w_traj, const float* w_vis, const float* w_depth,
+                     const unsigned char* valid_t, const unsigned char* valid_n, float* traj, float* vis, float* depth,
+                     int T, int start, int ws, int next_start, int last_window, float* cur_q, float* plabel,
+                     const float* new_pfeat, float* pfeat, int* best_out, int N, int C);
 
 /* ------------------------------------------------------------------------------------------------
  * Engine: holds the table of packed device weights and runs whole sub-networks with one call.

@@ -37,6 +37,8 @@ class GemmDesc(C.Structure):
         ("epi", C.c_int),
         ("vt", C.c_void_p), ("S", C.c_int), ("H", C.c_int), ("Dp", C.c_int),
         ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("Cout", C.c_int),
+        ("a_gr", C.c_int), ("a_gs", C.c_int), ("a_go", C.c_int),
+        ("c_gr", C.c_int), ("c_gs", C.c_int), ("c_go", C.c_int),
     ]
 
 
@@ -72,6 +74,15 @@ SIGNATURES = {
     "l4p_affine_align_solve": (_I, [_VP, _VP, _VP, _LL, _I, _VP, _VP]),
     "l4p_affine_align_apply": (_I, [_VP, _VP, _VP, _LL, _I, _VP]),
     "l4p_rays_to_pose": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
+    "l4p_layernorm_ex": (_I, [_VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I, _VP, _I, _VP, _I]),
+    "l4p_track_tokens": (_I, [_VP] * 13 + [_I] * 5),
+    "l4p_track_keys_init": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I]),
+    "l4p_fill_rows": (_I, [_VP, _VP, _VP, _LL, _I, _LL, _LL, _LL]),
+    "l4p_small_attn": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I]),
+    "l4p_mask_product": (_I, [_VP, _I, _VP, _VP, _VP, _I, _LL, _I]),
+    "l4p_track_readout": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
+    "l4p_track_prepare": (_I, [_VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _I]),
+    "l4p_track_commit": (_I, [_VP] * 9 + [_I] * 5 + [_VP] * 5 + [_I, _I]),
     "l4p_create": (_I, [_I, _I, C.POINTER(_VP)]),
     "l4p_destroy": (_I, [_VP]),
     "l4p_bind_weight": (_I, [_VP, C.c_char_p, _VP, _LL]),

@@ -1,0 +1,73 @@
+// C ABI entry points of the tracker kernels (track.hip) and the extended LayerNorm.
+#include "engine.hpp"
+
+int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const float* beta, float eps, void* out_T,
+                        float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act,
+                        hipStream_t stream);
+int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
+                        const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
+                        const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
+                        int W, hipStream_t stream);
+int launch_track_keys_init(int dtype, const float* enc, const float* hist, const float* pos, float* k32, void* kT,
+                           void* kP, int N, int P, int C, hipStream_t stream);
+int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
+                     long long group_off, hipStream_t stream);
+int launch_small_attn(int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P, int D,
+                      int heads, hipStream_t stream);
+int launch_mask_product(int dtype, const void* up, const float* hyper, float* masks, int N, long long vox, int Cc,
+                        hipStream_t stream);
+int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
+                         int W, hipStream_t stream);
+int launch_track_prepare(const float* cur_q, const float* orig_q, int start, int ws, float* q_off, float* labels,
+                         unsigned char* valid_t, unsigned char* valid_n, int N, hipStream_t stream);
+int launch_track_commit(const float* w_traj, const float* w_vis, const float* w_depth, const unsigned char* valid_t,
+                        const unsigned char* valid_n, float* traj, float* vis, float* depth, int T, int start, int ws,
+                        int next_start, int last_window, float* cur_q, float* plabel, const float* new_pfeat, float* pfeat,
+                        int* best_out, int N, int C, hipStream_t stream);
+
+extern "C" {
+
+int l4p_layernorm_ex(l4p_stream s, int dtype, const float* x, const float* gamma, const float* beta, float eps,
+                     void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act) {
+    return launch_layernorm_ex(dtype, x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, (hipStream_t)s);
+}
+int l4p_track_tokens(l4p_stream s, const float* queries, const float* labels, const float* pfeat, const float* plabel,
+                     const float* gauss, const float* mask_tokens, const float* point_emb0, const float* point_emb1,
+                     const float* not_a_point, const float* feat_emb0, const float* feat_emb1, float* tokens, int N, int C,
+                     int T, int H, int W) {
+    return launch_track_tokens(queries, labels, pfeat, plabel, gauss, mask_tokens, point_emb0, point_emb1, not_a_point,
+                               feat_emb0, feat_emb1, tokens, N, C, T, H, W, (hipStream_t)s);
+}
+int l4p_track_keys_init(l4p_stream s, int dtype, const float* enc, const float* hist, const float* pos, float* k32,
+                        void* kT, void* kP, int N, int P, int C) {
+    return launch_track_keys_init(dtype, enc, hist, pos, k32, kT, kP, N, P, C, (hipStream_t)s);
+}
+int l4p_fill_rows(l4p_stream s, float* out, const float* v, long long rows, int C, long long group_rows,
+                  long long group_stride, long long group_off) {
+    return launch_fill_rows(out, v, rows, C, group_rows, group_stride, group_off, (hipStream_t)s);
+}
+int l4p_small_attn(l4p_stream s, int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P,
+                   int D, int heads) {
+    return launch_small_attn(dtype, kind, q, k, v, out, N, P, D, heads, (hipStream_t)s);
+}
+int l4p_mask_product(l4p_stream s, int dtype, const void* up, const float* hyper, float* masks, int N, long long vox,
+                     int C) {
+    return launch_mask_product(dtype, up, hyper, masks, N, vox, C, (hipStream_t)s);
+}
+int l4p_track_readout(l4p_stream s, const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w,
+                      int H, int W) {
+    return launch_track_readout(masks, traj, vis, depth, N, T, h, w, H, W, (hipStream_t)s);
+}
+int l4p_track_prepare(l4p_stream s, const float* cur_q, const float* orig_q, int start, int ws, float* q_off,
+                      float* labels, unsigned char* valid_t, unsigned char* valid_n, int N) {
+    return launch_track_prepare(cur_q, orig_q, start, ws, q_off, labels, valid_t, valid_n, N, (hipStream_t)s);
+}
+int l4p_track_commit(l4p_stream s, const float* w_traj, const float* w_vis, const float* w_depth,
+                     const unsigned char* valid_t, const unsigned char* valid_n, float* traj, float* vis, float* depth, int T,
+                     int start, int ws, int next_start, int last_window, float* cur_q, float* plabel, const float* new_pfeat,
+                     float* pfeat, int* best_out, int N, int C) {
+    return launch_track_commit(w_traj, w_vis, w_depth, valid_t, valid_n, traj, vis, depth, T, start, ws, next_start,
+                               last_window, cur_q, plabel, new_pfeat, pfeat, best_out, N, C, (hipStream_t)s);
+}
+
+}  // extern "C"

@@ -11,7 +11,9 @@
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        T* __restrict__ out_T, float* __restrict__ out_f32, int M, int C) {
+                                                        T* __restrict__ out_T, float* __restrict__ out_f32, int M, int C,
+                                                        const float* __restrict__ add, int add_mod, T* __restrict__ out_T2,
+                                                        int act) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -51,6 +53,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 y;
 #pragma unroll
             for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd * g[k] + bb[k];
+            if (act == L4P_ACT_GELU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = gelu_erf(y[k]);
+            }
+            if (out_T2) {  // T(y + add[row % add_mod]): the "+ positional / + prompt token" operand of the tracker
+                const f32x4 a = ((const f32x4*)(add + (long long)(row % add_mod) * C))[idx];
+                if (sizeof(T) == 2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (bf16_t)(y[k] + a[k]);
+                    ((bf16x4*)((bf16_t*)out_T2 + (long long)row * C))[idx] = o;
+                } else {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = y[k] + a[k];
+                    ((f32x4*)((float*)out_T2 + (long long)row * C))[idx] = o;
+                }
+            }
             if (out_f32) ((f32x4*)(out_f32 + (long long)row * C))[idx] = y;
             if (out_T) {
                 if (sizeof(T) == 2) {
@@ -66,22 +86,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-int launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, float eps, void* out_T,
-                     float* out_f32, int M, int C, hipStream_t stream) {
-    if (C % 4 || C > 2048) {
-        l4p_set_error("layernorm: C=%d must be a multiple of 4 and <= 2048", C);
+int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const float* beta, float eps, void* out_T,
+                        float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act,
+                        hipStream_t stream) {
+    if (C % 4 || C > 2048 || (out_T2 && (!add || add_mod <= 0))) {
+        l4p_set_error("layernorm: C=%d must be a multiple of 4 and <= 2048 (and out_T2 needs add/add_mod)", C);
         return L4P_E_INVALID;
     }
     const dim3 grid((M + 3) / 4), block(256);
     ProfScope prof(PROF_LAYERNORM, stream);
     if (dtype == L4P_BF16)
         hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                           out_f32, M, C);
+                           out_f32, M, C, add, add_mod, (bf16_t*)out_T2, act);
     else
         hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, block, 0, stream, x, gamma, beta, eps, (float*)out_T,
-                           out_f32, M, C);
+                           out_f32, M, C, add, add_mod, (float*)out_T2, act);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, float eps, void* out_T,
+                     float* out_f32, int M, int C, hipStream_t stream) {
+    return launch_layernorm_ex(dtype, x, gamma, beta, eps, out_T, out_f32, M, C, nullptr, 0, nullptr, L4P_ACT_NONE, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

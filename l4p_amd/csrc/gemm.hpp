@@ -60,7 +60,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         int m = m0 + crow + i * (NT / 8);
         if (m >= p.M) m = p.M - 1;
         if (MODE == 0) {
-            a_base[i] = (const T*)p.A + (long long)m * p.lda + cc * EPC;
+            const long long pm = p.a_gr > 0 ? (long long)(m / p.a_gr) * p.a_gs + p.a_go + (m % p.a_gr) : m;
+            a_base[i] = (const T*)p.A + pm * p.lda + cc * EPC;
             a_mask[i] = 0;
         } else {
             int wo = m % p.Wo;
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
                     (wi * p.kw + dw);
                 off = vox * p.Cout + co;
             } else {
-                off = (long long)m * p.ldc + n;
+                const long long pm = p.c_gr > 0 ? (long long)(m / p.c_gr) * p.c_gs + p.c_go + (m % p.c_gr) : m;
+                off = pm * p.ldc + n;
             }
             if (p.res1) {
                 const long long roff = (long long)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr + n;

@@ -1,0 +1,663 @@
+// Kernels specific to the SAM-style point tracker (reference sparse_heads.py, sam/*.py).
+// The heavy projections run in gemm.hpp; what lives here is the small-token attention in its three
+// shapes, prompt-token construction, the per-query key initialisation, the hyper-network mask
+// product, the fused (trilinear up-sampling + soft-argmax + spatial means) read-out that never
+// materialises the [N,3,16,224,224] logits, and the integer/boolean sliding-window bookkeeping.
+#include "common.hpp"
+
+template <typename T> struct Vec8;  // 8 consecutive elements of T as floats
+template <> struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+        const bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+        bf16x8 t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (bf16_t)v[k];
+        *(bf16x8*)p = t;
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = a[k];
+            v[4 + k] = b[k];
+        }
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
+        *(f32x4*)(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    }
+};
+
+template <typename T> struct Vec4;  // 4 consecutive elements (head dims only need % 4 == 0)
+template <> struct Vec4<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+        const bf16x4 t = *(const bf16x4*)p;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (float)t[k];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+        bf16x4 t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = (bf16_t)v[k];
+        *(bf16x4*)p = t;
+    }
+};
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const f32x4 a = *(const f32x4*)p;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = a[k];
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+};
+
+// -------------------------------------------------------------------------------------------------
+// Prompt tokens (prompt_encoder.py:78-121,196-203,221-232; mask_decoder.py:107-113):
+// tokens[n] = [mask_tok0, mask_tok1, mask_tok2, point PE + label emb, not-a-point, feature + feature emb]
+// queries [N][3] = (t, x, y) in window time / pixels; labels [N] float {0,1,2}; pfeat [N][C]; plabel [N].
+// -------------------------------------------------------------------------------------------------
+__global__ void track_tokens_kernel(const float* __restrict__ queries, const float* __restrict__ labels,
+                                    const float* __restrict__ pfeat, const float* __restrict__ plabel,
+                                    const float* __restrict__ gauss, const float* __restrict__ mask_tokens,
+                                    const float* __restrict__ point_emb0, const float* __restrict__ point_emb1,
+                                    const float* __restrict__ not_a_point, const float* __restrict__ feat_emb0,
+                                    const float* __restrict__ feat_emb1, float* __restrict__ tokens, int N, int C, float T,
+                                    float H, float W) {
+    const int n = blockIdx.x;
+    const int half = C / 2;
+    const float ct = 2.f * (queries[n * 3 + 0] / T) - 1.f;
+    const float cx = 2.f * (queries[n * 3 + 1] / W) - 1.f;
+    const float cy = 2.f * (queries[n * 3 + 2] / H) - 1.f;
+    const float lab = labels[n], pl = plabel[n];
+    float* out = tokens + (long long)n * 6 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        out[0 * C + c] = mask_tokens[0 * C + c];
+        out[1 * C + c] = mask_tokens[1 * C + c];
+        out[2 * C + c] = mask_tokens[2 * C + c];
+        const int j = c < half ? c : c - half;
+        float a = ct * gauss[j];
+        a += cx * gauss[half + j];
+        a += cy * gauss[2 * half + j];
+        a = 6.283185307179586f * a;
+        float pe = c < half ? sinf(a) : cosf(a);
+        if (lab == 0.f) pe += point_emb0[c];
+        if (lab == 1.f) pe += point_emb1[c];
+        out[3 * C + c] = pe;
+        out[4 * C + c] = not_a_point[c];
+        float fe = 0.f;
+        if (pl == 0.f) fe = pfeat[(long long)n * C + c] + feat_emb0[c];
+        if (pl == 1.f) fe = pfeat[(long long)n * C + c] + feat_emb1[c];
+        out[5 * C + c] = fe;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// keys = enc_last (broadcast over queries) + history   (sparse_heads.py:341-346), emitted as
+// float (residual master), T (values) and T(keys + dense PE) (keys of the attention).
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void track_keys_init_kernel(const float* __restrict__ enc, const float* __restrict__ hist,
+                                       const float* __restrict__ pos, float* __restrict__ k32, T* __restrict__ kT,
+                                       T* __restrict__ kP, long long per_q8, long long total8) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = (i % per_q8) * 8;
+        float a[8], h[8], p[8], s[8];
+        Vec8<float>::load(enc + e, a);
+        Vec8<float>::load(hist + i * 8, h);
+        Vec8<float>::load(pos + e, p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += h[k];
+        Vec8<float>::store(k32 + i * 8, a);
+        Vec8<T>::store(kT + i * 8, a);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = a[k] + p[k];
+        Vec8<T>::store(kP + i * 8, s);
+    }
+}
+
+// out[r][:] = v[:] for r in [0, rows): broadcast fill (history mask token, sparse_heads.py:418-427)
+__global__ void fill_rows_kernel(float* __restrict__ out, const float* __restrict__ v, long long rows, int C,
+                                 long long group_rows, long long group_stride, long long group_off) {
+    const long long total = rows * (C / 4);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / (C / 4);
+        const int c4 = (int)(i % (C / 4));
+        const long long row = (r / group_rows) * group_stride + group_off + (r % group_rows);
+        ((f32x4*)(out + row * C))[c4] = ((const f32x4*)v)[c4];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Attention among the 6 prompt tokens (sam/transformer.py:223-245, self_attn): q,k,v [N][6][D], heads x hd.
+// One wave per (query n, head); lanes split the head dim.
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void self_attn6_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                        const T* __restrict__ v, T* __restrict__ out, int D, int hd,
+                                                        float scale) {
+    const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const long long base = (long long)n * 6 * D + (long long)h * hd;
+    float s[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float acc = 0.f;
+            for (int d = lane; d < hd; d += 64) acc += (float)q[base + (long long)i * D + d] * (float)k[base + (long long)j * D + d];
+            s[i][j] = wave_sum(acc) * scale;
+        }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float m = s[i][0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) m = fmaxf(m, s[i][j]);
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            s[i][j] = expf(s[i][j] - m);
+            z += s[i][j];
+        }
+        const float iz = 1.f / z;
+        for (int d = lane; d < hd; d += 64) {
+            float o = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) o += s[i][j] * iz * (float)v[base + (long long)j * D + d];
+            out[base + (long long)i * D + d] = from_f32<T>(o);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Prompt tokens attending to the P image tokens (cross_attn_token_to_image / final attention):
+// q [N][6][D], k, v [N][P][D] -> out [N][6][D]; D = heads*hd, hd % 8 == 0, hd <= 96.
+// One workgroup per (n, head): scores for all 6 x P pairs live in LDS, softmax per token, then P.V with
+// the head dim split in 8-wide column groups and the keys split across thread groups.
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                       const T* __restrict__ v, T* __restrict__ out, int P, int D, int hd,
+                                                       float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = (float*)smem;      // [6][P]
+    float* qs = sc + 6 * P;        // [6][hd]
+    float* red = qs + 6 * 96;      // [256] scratch, later [ngroups][6][hd]
+    const int n = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const T* qp = q + (long long)n * 6 * D + (long long)h * hd;
+    const T* kp = k + (long long)n * P * D + (long long)h * hd;
+    const T* vp = v + (long long)n * P * D + (long long)h * hd;
+    for (int i = tid; i < 6 * hd; i += 256) qs[(i / hd) * 96 + (i % hd)] = (float)qp[(long long)(i / hd) * D + (i % hd)];
+    __syncthreads();
+    // scores
+    for (int p = tid; p < P; p += 256) {
+        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int d0 = 0; d0 < hd; d0 += 4) {
+            float kv[4];
+            Vec4<T>::load(kp + (long long)p * D + d0, kv);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i] += qs[i * 96 + d0 + e] * kv[e];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sc[i * P + p] = acc[i] * scale;
+    }
+    __syncthreads();
+    // softmax over P for each of the 6 tokens (in place: sc <- exp(s - max); z kept in registers of all threads)
+    float zinv[6];
+    for (int i = 0; i < 6; ++i) {
+        float m = -INFINITY;
+        for (int p = tid; p < P; p += 256) m = fmaxf(m, sc[i * P + p]);
+        m = wave_max(m);
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        float z = 0.f;
+        for (int p = tid; p < P; p += 256) {
+            const float e = expf(sc[i * P + p] - m);
+            sc[i * P + p] = e;
+            z += e;
+        }
+        z = wave_sum(z);
+        if ((tid & 63) == 0) red[tid >> 6] = z;
+        __syncthreads();
+        zinv[i] = 1.f / (red[0] + red[1] + red[2] + red[3]);
+        __syncthreads();
+    }
+    // P.V: column group cg (4 dims) x key group kg
+    const int ncg = hd / 4;
+    const int nkg = 256 / ncg;
+    const int cg = tid % ncg, kg = tid / ncg;
+    float o[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[i][e] = 0.f;
+    if (kg < nkg) {
+        for (int p = kg; p < P; p += nkg) {
+            float vv[4];
+            Vec4<T>::load(vp + (long long)p * D + cg * 4, vv);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float w = sc[i * P + p];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[i][e] += w * vv[e];
+            }
+        }
+    }
+    __syncthreads();
+    // reduce across key groups through LDS (reuse sc: scores are no longer needed)
+    float* acc = sc;  // [nkg][6][hd]
+    if (kg < nkg) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[(kg * 6 + i) * hd + cg * 4 + e] = o[i][e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 6 * hd; idx += 256) {
+        const int i = idx / hd, d = idx % hd;
+        float s = 0.f;
+        for (int g = 0; g < nkg; ++g) s += acc[(g * 6 + i) * hd + d];
+        out[(long long)n * 6 * D + (long long)i * D + (long long)h * hd + d] = from_f32<T>(s * zinv[i]);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Image tokens attending to the 6 prompt tokens (cross_attn_image_to_token):
+// q [N][P][D], k, v [N][6][D] -> out [N][P][D].  One thread per (image token, head).
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void i2t_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                       const T* __restrict__ v, T* __restrict__ out, int P, int D, int hd,
+                                                       int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ks = (float*)smem;  // [6][D]
+    float* vs = ks + 6 * D;    // [6][D]
+    const int n = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < 6 * D; i += 256) {
+        ks[i] = (float)k[(long long)n * 6 * D + i];
+        vs[i] = (float)v[(long long)n * 6 * D + i];
+    }
+    __syncthreads();
+    const int work = blockIdx.x * 256 + tid;  // (p, h)
+    if (work >= P * heads) return;
+    const int p = work / heads, h = work % heads;
+    const T* qp = q + ((long long)n * P + p) * D + (long long)h * hd;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int d0 = 0; d0 < hd; d0 += 4) {
+        float qv[4];
+        Vec4<T>::load(qp + d0, qv);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[i] += qv[e] * ks[i * D + h * hd + d0 + e];
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        s[i] *= scale;
+        m = fmaxf(m, s[i]);
+    }
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        s[i] = expf(s[i] - m);
+        z += s[i];
+    }
+    const float iz = 1.f / z;
+    T* op = out + ((long long)n * P + p) * D + (long long)h * hd;
+    for (int d0 = 0; d0 < hd; d0 += 4) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) a += s[i] * vs[i * D + h * hd + d0 + e];
+            o[e] = a * iz;
+        }
+        Vec4<T>::store(op + d0, o);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// masks[n][m][vox] = sum_c hyper[n][m][c] * up[n][vox][c]   (mask_decoder.py:139), up channels-last T.
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mask_product_kernel(const T* __restrict__ up, const float* __restrict__ hyper,
+                                                           float* __restrict__ masks, long long vox, int Cc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* hs = (float*)smem;  // [3][Cc]
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < 3 * Cc; i += 256) hs[i] = hyper[(long long)n * 3 * Cc + i];
+    __syncthreads();
+    for (long long p = blockIdx.x * 256LL + threadIdx.x; p < vox; p += (long long)gridDim.x * 256) {
+        const T* xp = up + ((long long)n * vox + p) * Cc;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int c0 = 0; c0 < Cc; c0 += 8) {
+            float x[8];
+            Vec8<T>::load(xp + c0, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a0 += x[e] * hs[c0 + e];
+                a1 += x[e] * hs[Cc + c0 + e];
+                a2 += x[e] * hs[2 * Cc + c0 + e];
+            }
+        }
+        masks[((long long)n * 3 + 0) * vox + p] = a0;
+        masks[((long long)n * 3 + 1) * vox + p] = a1;
+        masks[((long long)n * 3 + 2) * vox + p] = a2;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Read-out (sparse_heads.py:572-589,645-647) fused: trilinear resize (align_corners=False; identity in
+// time when Tl == T) of the low-res logits [N][3][Tl][h][w] to H x W, then per (n, t):
+//   channel 0 -> soft-argmax xy over H*W with pixel-centre grid (+0.5);  channel 1 -> spatial mean (vis);
+//   channel 2 -> exp(spatial mean) (depth).
+// One workgroup per (n, t); the three low-res maps sit in LDS.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void src_idx_nc(int dst, int in, int out, int& i0, int& i1, float& lam) {
+    float src = ((float)in / (float)out) * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    lam = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void track_readout_kernel(const float* __restrict__ masks, float* __restrict__ traj,
+                                                            float* __restrict__ vis, float* __restrict__ depth, int T,
+                                                            int h, int w, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lo = (float*)smem;  // [3][h*w]
+    __shared__ float red[4][8];
+    const int n = blockIdx.x / T, t = blockIdx.x % T, tid = threadIdx.x;
+    const int hw = h * w;
+    for (int i = tid; i < 3 * hw; i += 256) {
+        const int m = i / hw, r = i % hw;
+        lo[i] = masks[(((long long)n * 3 + m) * T + t) * hw + r];
+    }
+    __syncthreads();
+    auto sample = [&](int m, int y, int x) -> float {
+        int y0, y1, x0, x1;
+        float ly, lx;
+        src_idx_nc(y, h, H, y0, y1, ly);
+        src_idx_nc(x, w, W, x0, x1, lx);
+        const float* b = lo + m * hw;
+        const float top = (1.f - lx) * b[y0 * w + x0] + lx * b[y0 * w + x1];
+        const float bot = (1.f - lx) * b[y1 * w + x0] + lx * b[y1 * w + x1];
+        return (1.f - ly) * top + ly * bot;
+    };
+    // pass 1: max of channel 0, sums of channels 1 and 2
+    float mx = -INFINITY, s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < H * W; i += 256) {
+        const int y = i / W, x = i % W;
+        mx = fmaxf(mx, sample(0, y, x));
+        s1 += sample(1, y, x);
+        s2 += sample(2, y, x);
+    }
+    mx = wave_max(mx);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((tid & 63) == 0) {
+        red[tid >> 6][0] = mx;
+        red[tid >> 6][1] = s1;
+        red[tid >> 6][2] = s2;
+    }
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    s1 = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    s2 = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    __syncthreads();
+    // pass 2: soft-argmax
+    float z = 0.f, sx = 0.f, sy = 0.f;
+    for (int i = tid; i < H * W; i += 256) {
+        const int y = i / W, x = i % W;
+        const float e = expf(sample(0, y, x) - mx);
+        z += e;
+        sx += e * ((float)x + 0.5f);
+        sy += e * ((float)y + 0.5f);
+    }
+    z = wave_sum(z);
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    if ((tid & 63) == 0) {
+        red[tid >> 6][0] = z;
+        red[tid >> 6][1] = sx;
+        red[tid >> 6][2] = sy;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        z = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        sx = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        sy = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+        traj[((long long)n * 2 + 0) * T + t] = sx / z;
+        traj[((long long)n * 2 + 1) * T + t] = sy / z;
+        vis[(long long)n * T + t] = s1 / (float)(H * W);
+        depth[(long long)n * T + t] = expf(s2 / (float)(H * W));
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Sliding-window bookkeeping (forward_windowed_core, sparse_heads.py:303-335, :366-393, :455-486).
+// All integer / boolean decisions are made here, bit-for-bit as the reference's float comparisons.
+//   prepare: q_off = cur_q with time shifted by -start; valid_t[n][j] = (j + start + 0.5 - cur_q.t >= 0);
+//            valid_n = any(valid_t); label = 0/1 by valid_n, then 1 if ANY coordinate of cur_q equals the
+//            original query (:330-332), else 2 if valid (:334-335).
+//   commit : masked scatter of the window estimates into the clip buffers; prompt feature carry;
+//            re-seed the query at argmax visibility over the overlap with the next window.
+// -------------------------------------------------------------------------------------------------
+__global__ void track_prepare_kernel(const float* __restrict__ cur_q, const float* __restrict__ orig_q, int start, int ws,
+                                     float* __restrict__ q_off, float* __restrict__ labels,
+                                     unsigned char* __restrict__ valid_t, unsigned char* __restrict__ valid_n, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float qt = cur_q[n * 3], qx = cur_q[n * 3 + 1], qy = cur_q[n * 3 + 2];
+    bool any = false;
+    for (int j = 0; j < ws; ++j) {
+        const float tj = (float)(j + start) + 0.5f;  // arange + start + 0.5 (exact in float)
+        const bool ok = (tj - qt) >= 0.f;
+        valid_t[n * ws + j] = ok ? 1 : 0;
+        any |= ok;
+    }
+    valid_n[n] = any ? 1 : 0;
+    q_off[n * 3] = qt - (float)start;
+    q_off[n * 3 + 1] = qx;
+    q_off[n * 3 + 2] = qy;
+    float lab = any ? 1.f : 0.f;
+    const bool same = (qt == orig_q[n * 3]) || (qx == orig_q[n * 3 + 1]) || (qy == orig_q[n * 3 + 2]);
+    if (same) lab = 1.f;
+    if (any && !same) lab = 2.f;
+    labels[n] = lab;
+}
+
+__global__ void track_commit_kernel(const float* __restrict__ w_traj, const float* __restrict__ w_vis,
+                                    const float* __restrict__ w_depth, const unsigned char* __restrict__ valid_t,
+                                    const unsigned char* __restrict__ valid_n, float* __restrict__ traj,
+                                    float* __restrict__ vis, float* __restrict__ depth, int T, int start, int ws, int next_start,
+                                    int last_window, float* __restrict__ cur_q, float* __restrict__ plabel,
+                                    int* __restrict__ best_out, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    for (int j = 0; j < ws; ++j) {
+        if (!valid_t[n * ws + j]) continue;
+        vis[(long long)n * T + start + j] = w_vis[n * ws + j];
+        depth[(long long)n * T + start + j] = w_depth[n * ws + j];
+        traj[((long long)n * 2 + 0) * T + start + j] = w_traj[(n * 2 + 0) * ws + j];
+        traj[((long long)n * 2 + 1) * T + start + j] = w_traj[(n * 2 + 1) * ws + j];
+    }
+    if (last_window) return;
+    if (valid_n[n]) plabel[n] = 1.f;
+    // argmax (first maximum) of the stitched visibility over [next_start, start + ws)
+    int best = 0;
+    float bv = vis[(long long)n * T + next_start];
+    for (int j = 1; j < start + ws - next_start; ++j) {
+        const float v = vis[(long long)n * T + next_start + j];
+        if (v > bv) {
+            bv = v;
+            best = j;
+        }
+    }
+    if (best_out) best_out[n] = best;
+    const float nt = (float)best + (float)next_start + 0.5f;
+    if (nt > cur_q[n * 3]) {
+        cur_q[n * 3] = nt;
+        cur_q[n * 3 + 1] = traj[((long long)n * 2 + 0) * T + next_start + best];
+        cur_q[n * 3 + 2] = traj[((long long)n * 2 + 1) * T + next_start + best];
+    }
+}
+
+// prompt feature carry: pfeat[n] = new[n] where valid_n (sparse_heads.py:389-393)
+__global__ void masked_rows_copy_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                        const unsigned char* __restrict__ mask, int N, int C) {
+    const long long total = (long long)N * (C / 4);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (C / 4));
+        if (mask[n]) ((f32x4*)dst)[i] = ((const f32x4*)src)[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+#define GRID1D(total, cap) ((int)(((total) + 255) / 256 < (cap) ? ((total) + 255) / 256 : (cap)))
+
+int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
+                        const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
+                        const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
+                        int W, hipStream_t stream) {
+    ProfScope prof(PROF_TRACK, stream);
+    hipLaunchKernelGGL(track_tokens_kernel, dim3(N), dim3(256), 0, stream, queries, labels, pfeat, plabel, gauss,
+                       mask_tokens, pe0, pe1, nap, fe0, fe1, tokens, N, C, (float)T, (float)H, (float)W);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_track_keys_init(int dtype, const float* enc, const float* hist, const float* pos, float* k32, void* kT,
+                           void* kP, int N, int P, int C, hipStream_t stream) {
+    if (C % 8) {
+        l4p_set_error("track_keys_init: C %% 8 != 0");
+        return L4P_E_INVALID;
+    }
+    const long long per_q8 = (long long)P * C / 8, total8 = per_q8 * N;
+    ProfScope prof(PROF_TRACK, stream);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(track_keys_init_kernel<bf16_t>, dim3(GRID1D(total8, 16384)), dim3(256), 0, stream, enc, hist,
+                           pos, k32, (bf16_t*)kT, (bf16_t*)kP, per_q8, total8);
+    else
+        hipLaunchKernelGGL(track_keys_init_kernel<float>, dim3(GRID1D(total8, 16384)), dim3(256), 0, stream, enc, hist, pos,
+                           k32, (float*)kT, (float*)kP, per_q8, total8);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
+                     long long group_off, hipStream_t stream) {
+    ProfScope prof(PROF_TRACK, stream);
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(GRID1D(rows * (C / 4), 16384)), dim3(256), 0, stream, out, v, rows, C,
+                       group_rows, group_stride, group_off);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_small_attn(int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P, int D,
+                      int heads, hipStream_t stream) {
+    const int hd = D / heads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (hd * heads != D || (kind != 0 && (hd % 4 || hd > 96))) {
+        l4p_set_error("small_attn: unsupported head geometry D=%d heads=%d", D, heads);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_TRACK, stream);
+    if (kind == 0) {  // 6 x 6 self attention
+        if (dtype == L4P_BF16)
+            hipLaunchKernelGGL(self_attn6_kernel<bf16_t>, dim3(N, heads), dim3(64), 0, stream, (const bf16_t*)q,
+                               (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, D, hd, scale);
+        else
+            hipLaunchKernelGGL(self_attn6_kernel<float>, dim3(N, heads), dim3(64), 0, stream, (const float*)q,
+                               (const float*)k, (const float*)v, (float*)out, D, hd, scale);
+    } else if (kind == 1) {  // tokens -> image
+        const int ncg = hd / 4, nkg = 256 / ncg;
+        size_t lds = (size_t)(6 * P + 6 * 96 + 256) * 4;
+        const size_t need2 = (size_t)nkg * 6 * hd * 4;
+        if (need2 > (size_t)6 * P * 4) lds += need2 - (size_t)6 * P * 4;
+        auto kb = t2i_attn_kernel<bf16_t>;
+        auto kf = t2i_attn_kernel<float>;
+        if (dtype == L4P_BF16) {
+            HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kb, dim3(N, heads), dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, scale);
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kf, dim3(N, heads), dim3(256), lds, stream, (const float*)q, (const float*)k,
+                               (const float*)v, (float*)out, P, D, hd, scale);
+        }
+    } else {  // image -> tokens
+        const size_t lds = (size_t)12 * D * 4;
+        const dim3 grid((P * heads + 255) / 256, N);
+        if (dtype == L4P_BF16)
+            hipLaunchKernelGGL(i2t_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, heads, scale);
+        else
+            hipLaunchKernelGGL(i2t_attn_kernel<float>, grid, dim3(256), lds, stream, (const float*)q, (const float*)k,
+                               (const float*)v, (float*)out, P, D, hd, heads, scale);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_mask_product(int dtype, const void* up, const float* hyper, float* masks, int N, long long vox, int Cc,
+                        hipStream_t stream) {
+    if (Cc % 8) {
+        l4p_set_error("mask_product: C %% 8 != 0");
+        return L4P_E_INVALID;
+    }
+    const dim3 grid(GRID1D(vox, 1024), N);
+    const size_t lds = (size_t)3 * Cc * 4;
+    ProfScope prof(PROF_TRACK, stream);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(mask_product_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)up, hyper, masks, vox, Cc);
+    else
+        hipLaunchKernelGGL(mask_product_kernel<float>, grid, dim3(256), lds, stream, (const float*)up, hyper, masks, vox, Cc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
+                         int W, hipStream_t stream) {
+    const size_t lds = (size_t)3 * h * w * 4;
+    ProfScope prof(PROF_TRACK, stream);
+    hipLaunchKernelGGL(track_readout_kernel, dim3(N * T), dim3(256), lds, stream, masks, traj, vis, depth, T, h, w, H, W);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_track_prepare(const float* cur_q, const float* orig_q, int start, int ws, float* q_off, float* labels,
+                         unsigned char* valid_t, unsigned char* valid_n, int N, hipStream_t stream) {
+    ProfScope prof(PROF_TRACK, stream);
+    hipLaunchKernelGGL(track_prepare_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, cur_q, orig_q, start, ws, q_off,
+                       labels, valid_t, valid_n, N);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_track_commit(const float* w_traj, const float* w_vis, const float* w_depth, const unsigned char* valid_t,
+                        const unsigned char* valid_n, float* traj, float* vis, float* depth, int T, int start, int ws,
+                        int next_start, int last_window, float* cur_q, float* plabel, const float* new_pfeat, float* pfeat,
+                        int* best_out, int N, int C, hipStream_t stream) {
+    ProfScope prof(PROF_TRACK, stream);
+    hipLaunchKernelGGL(track_commit_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, w_traj, w_vis, w_depth, valid_t,
+                       valid_n, traj, vis, depth, T, start, ws, next_start, last_window, cur_q, plabel, best_out, N);
+    if (!last_window && new_pfeat && pfeat)
+        hipLaunchKernelGGL(masked_rows_copy_kernel, dim3(GRID1D((long long)N * (C / 4), 4096)), dim3(256), 0, stream, pfeat,
+                           new_pfeat, valid_n, N, C);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -1,24 +1,323 @@
-"""SAM-style point tracker on the MI355X engine — host mirror of l4p/models/task_heads/sparse_heads.py."""
+"""SAM-style 2D/3D point tracker on the MI355X engine — host mirror of
+l4p/models/task_heads/sparse_heads.py (+ sam/prompt_encoder.py, sam/transformer.py, sam/mask_decoder.py).
+
+Same class name, constructor arguments, ``forward_windowed`` / ``forward`` signatures and output keys as
+the reference.  All arithmetic — projections (MFMA GEMM), the three small-token attention shapes,
+LayerNorms, up-scaling ConvTransposes, hyper-network product, the fused up-sample + soft-argmax read-out
+and the integer/boolean sliding-window bookkeeping — runs in libl4p_hip.so; the Python below only
+sequences kernels over device buffers (no host synchronisation inside a window).
+"""
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+import ctypes as C
+import math
+from typing import Dict, List, Literal, Optional, Tuple
 
 import torch
 
+from ... import _lib, ops
+from ..._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, GemmDesc
+from ...ops import _p, _stream
+
+
+def _gemm(a: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, n: int, *, bias=None, act=ACT_NONE, res1=None,
+          out_f32: Optional[torch.Tensor] = None, out_T: Optional[torch.Tensor] = None, ldc: Optional[int] = None,
+          a_map=None, c_map=None, a_off: int = 0, f32_off: int = 0) -> None:
+    """Raw l4p_gemm call with explicit strides / row maps (see include/l4p_hip.h)."""
+    d = GemmDesc()
+    es = a.element_size()
+    d.A, d.lda, d.W, d.ldw = a.data_ptr() + a_off * es, lda, _p(w), K
+    d.M, d.N, d.K = M, n, K
+    d.bias, d.act = _p(bias), act
+    if res1 is not None:
+        d.res1, d.res_f32, d.ldr = _p(res1), 1, n
+    d.out_f32 = None if out_f32 is None else out_f32.data_ptr() + 4 * f32_off
+    d.out_T = _p(out_T)
+    d.ldc = n if ldc is None else ldc
+    d.epi = EPI_DENSE
+    if a_map is not None:
+        d.a_gr, d.a_gs, d.a_go = a_map
+    if c_map is not None:
+        d.c_gr, d.c_gs, d.c_go = c_map
+    _lib.check(_lib.load().l4p_gemm(_stream(), ops.code_of(a.dtype), C.byref(d)), "l4p_gemm")
+
 
 class VideoMAETrack2DSamHead(torch.nn.Module):
-    def __init__(self, task_name: str = "track_2d", prompt_embed_dim: int = 1408,
-                 image_size: Tuple[int, int, int] = (16, 224, 224), patch_size: Tuple[int, int, int] = (2, 14, 14),
-                 estimate_vis: bool = False, estimate_depth: bool = False, sam_head_depth: int = 2,
-                 decoding_out_dim_factor: int = 8, num_prompt_points: int = 2, num_point_embeddings: int = 2,
-                 modify_pointlabels_for_windowing: bool = False, prompt_using_features: bool = False,
-                 attend_to_past: bool = False, depth_fn: str = "linear", vis_fn: str = "linear",
-                 estimation_directions: List[int] = [1, -1], max_queries: int = 192):
+    def __init__(
+        self,
+        task_name: str = "track_2d",
+        prompt_embed_dim: int = 1408,
+        image_size: Tuple[int, int, int] = (16, 224, 224),
+        patch_size: Tuple[int, int, int] = (2, 14, 14),
+        estimate_vis: bool = False,
+        estimate_depth: bool = False,
+        sam_head_depth: int = 2,
+        decoding_out_dim_factor: int = 8,
+        num_prompt_points: int = 2,
+        num_point_embeddings: int = 2,
+        modify_pointlabels_for_windowing: bool = False,
+        prompt_using_features: bool = False,
+        attend_to_past: bool = False,
+        depth_fn: str = "linear",
+        vis_fn: str = "linear",
+        estimation_directions: List[Literal[1, -1]] = [1, -1],
+        max_queries: int = 192,
+    ):
         super().__init__()
+        # the engine implements the configuration shipped in configs/model.yaml:53-66
+        if not (estimate_vis and estimate_depth and prompt_using_features and attend_to_past and
+                modify_pointlabels_for_windowing and num_point_embeddings == 2 and num_prompt_points == 2 and
+                depth_fn == "exp" and vis_fn == "linear"):
+            raise NotImplementedError("tracker options other than those of configs/model.yaml are not built into the engine")
         self.task_name = task_name
+        self.prompt_embed_dim = prompt_embed_dim
+        self.image_size = tuple(image_size)
+        self.patch_size = tuple(patch_size)
+        self.sam_head_depth = sam_head_depth
+        self.decoding_out_dim_factor = decoding_out_dim_factor
+        self.estimation_directions = list(estimation_directions)
         self.max_queries = max_queries
+        self.image_embedding_size = tuple(int(image_size[i] / patch_size[i]) for i in range(3))
+        self.video_tokens_size = self.image_embedding_size[0] * self.image_embedding_size[1] * self.image_embedding_size[2]
+        self.task_suffix = "_track_2d"
         self._rt = None
         self._engine_task = ""
+        self.trace: Optional[list] = None  # set to [] to record per-window labels / queries (tests)
 
-    def forward_windowed(self, *a, **k):
-        raise NotImplementedError("tracker head: under construction")
+    # ------------------------------------------------------------------------------------------------
+    def _w(self, k: str) -> torch.Tensor:
+        return self._rt.weights["trk." + k]
+
+    def _ln(self, x32: torch.Tensor, key: str, add: Optional[torch.Tensor], add_mod: int, want_T: bool = True,
+            want_T2: bool = True, eps: float = 1e-5, act: int = ACT_NONE, out32: Optional[torch.Tensor] = None):
+        M, Cc = x32.shape
+        td = ops.torch_dtype(self._rt.dtype)
+        oT = torch.empty((M, Cc), dtype=td, device=x32.device) if want_T else None
+        oT2 = torch.empty((M, Cc), dtype=td, device=x32.device) if (want_T2 and add is not None) else None
+        o32 = x32 if out32 is None else out32
+        _lib.check(_lib.load().l4p_layernorm_ex(_stream(), self._rt.dtype, _p(x32), _p(self._w(key + ".g")),
+                                                _p(self._w(key + ".b")), eps, _p(oT), _p(o32), M, Cc, _p(add), add_mod,
+                                                _p(oT2), act), "l4p_layernorm_ex")
+        return o32, oT, oT2
+
+    def _proj(self, x: torch.Tensor, key: str, n: int, **kw) -> torch.Tensor:
+        M, K = x.shape
+        out = torch.empty((M, n), dtype=x.dtype, device=x.device)
+        _gemm(x, M, K, K, self._w(key + ".w"), n, bias=self._w(key + ".b"), out_T=out, **kw)
+        return out
+
+    def _attn(self, kind: int, q, k, v, N: int, P: int, D: int) -> torch.Tensor:
+        out = torch.empty_like(q)
+        _lib.check(_lib.load().l4p_small_attn(_stream(), ops.code_of(q.dtype), kind, _p(q), _p(k), _p(v), _p(out), N, P, D,
+                                              self._rt.cfg.sam_heads), "l4p_small_attn")
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    def _window(self, enc_last: torch.Tensor, hist: torch.Tensor, q_off: torch.Tensor, labels: torch.Tensor,
+                pfeat: torch.Tensor, plabel: torch.Tensor, need_history: bool):
+        """forward / forward_single_batch (sparse_heads.py:497-667) for N queries of one clip.
+        enc_last: float [P,C]; hist: float [N,P,C]; returns window traj [N,2,T], vis [N,T], depth [N,T],
+        new prompt features [N,C]; updates ``hist`` in place when ``need_history``."""
+        rt = self._rt
+        cfg, dt = rt.cfg, rt.dtype
+        lib = _lib.load()
+        dev = enc_last.device
+        td = ops.torch_dtype(dt)
+        N = q_off.shape[0]
+        P, Cc = cfg.tokens, cfg.dim
+        Dh = Cc // 2
+        T, H, W = self.image_size
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        tok32 = torch.empty((6 * N, Cc), **f32)
+        _lib.check(lib.l4p_track_tokens(_stream(), _p(q_off), _p(labels), _p(pfeat), _p(plabel), _p(self._w("gauss")),
+                                        _p(self._w("mask_tokens")), _p(self._w("point_emb0")), _p(self._w("point_emb1")),
+                                        _p(self._w("not_a_point")), _p(self._w("feat_emb0")), _p(self._w("feat_emb1")),
+                                        _p(tok32), N, Cc, T, H, W), "l4p_track_tokens")
+        tokT = torch.empty((6 * N, Cc), dtype=td, device=dev)
+        _lib.check(lib.l4p_cast(_stream(), dt, _p(tok32), _p(tokT), tok32.numel()), "l4p_cast")
+
+        pos = self._w("dense_pe")
+        k32 = torch.empty((N * P, Cc), **f32)
+        kT = torch.empty((N * P, Cc), dtype=td, device=dev)
+        kP = torch.empty((N * P, Cc), dtype=td, device=dev)
+        _lib.check(lib.l4p_track_keys_init(_stream(), dt, _p(enc_last), _p(hist), _p(pos), _p(k32), _p(kT), _p(kP), N, P, Cc),
+                   "l4p_track_keys_init")
+
+        q32: Optional[torch.Tensor] = None
+        qT, qP = tokT, tokT
+        x32 = torch.empty((6 * N, Cc), **f32)
+        for l in range(cfg.sam_depth):
+            lo = f"l{l}."
+            # --- self attention of the prompt tokens (transformer.py:159-166) ---
+            sq = self._proj(qP, lo + "self.q", Cc)
+            sk = self._proj(qP, lo + "self.k", Cc)
+            sv = self._proj(qT, lo + "self.v", Cc)
+            sa = self._attn(0, sq, sk, sv, N, 6, Cc)
+            _gemm(sa, 6 * N, Cc, Cc, self._w(lo + "self.out.w"), Cc, bias=self._w(lo + "self.out.b"), res1=q32, out_f32=x32)
+            q32, qT, qP = self._ln(x32, lo + "norm1", tok32, 6 * N, out32=torch.empty_like(x32))
+            # --- tokens -> image (transformer.py:168-173) ---
+            tq = self._proj(qP, lo + "t2i.q", Dh)
+            tk = self._proj(kP, lo + "t2i.k", Dh)
+            tv = self._proj(kT, lo + "t2i.v", Dh)
+            ta = self._attn(1, tq, tk, tv, N, P, Dh)
+            del tk, tv
+            _gemm(ta, 6 * N, Dh, Dh, self._w(lo + "t2i.out.w"), Cc, bias=self._w(lo + "t2i.out.b"), res1=q32, out_f32=x32)
+            q32, qT, qP = self._ln(x32, lo + "norm2", tok32, 6 * N, out32=torch.empty_like(x32))
+            # --- MLP (transformer.py:175-178), ReLU ---
+            hdn = self._proj(qT, lo + "mlp1", cfg.sam_mlp, act=ACT_RELU)
+            _gemm(hdn, 6 * N, cfg.sam_mlp, cfg.sam_mlp, self._w(lo + "mlp2.w"), Cc, bias=self._w(lo + "mlp2.b"), res1=q32,
+                  out_f32=x32)
+            q32, qT, qP = self._ln(x32, lo + "norm3", tok32, 6 * N, out32=torch.empty_like(x32))
+            # --- image -> tokens (transformer.py:180-185): keys are updated in place ---
+            iq = self._proj(kP, lo + "i2t.q", Dh)
+            ik = self._proj(qP, lo + "i2t.k", Dh)
+            iv = self._proj(qT, lo + "i2t.v", Dh)
+            ia = self._attn(2, iq, ik, iv, N, P, Dh)
+            del iq
+            _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), res1=k32, out_f32=k32)
+            del ia
+            _lib.check(lib.l4p_layernorm_ex(_stream(), dt, _p(k32), _p(self._w(lo + "norm4.g")), _p(self._w(lo + "norm4.b")),
+                                            1e-5, _p(kT), _p(k32), N * P, Cc, _p(pos), P, _p(kP), ACT_NONE),
+                       "l4p_layernorm_ex")
+        # --- final tokens -> image attention (transformer.py:103-109) ---
+        fq = self._proj(qP, "final.q", Dh)
+        fk = self._proj(kP, "final.k", Dh)
+        fv = self._proj(kT, "final.v", Dh)
+        fa = self._attn(1, fq, fk, fv, N, P, Dh)
+        del fk, fv, kP
+        _gemm(fa, 6 * N, Dh, Dh, self._w("final.out.w"), Cc, bias=self._w("final.out.b"), res1=q32, out_f32=x32)
+        _, hsT, _ = self._ln(x32, "norm_final", None, 0, want_T2=False)
+
+        # --- hyper-network MLPs on the 3 mask tokens (mask_decoder.py:130-133,160-180) ---
+        d1 = Cc // self.decoding_out_dim_factor
+        hyper = torch.empty((N, 3, d1), **f32)
+        for i in range(3):
+            h1 = torch.empty((N, Cc), dtype=td, device=dev)
+            _gemm(hsT, N, Cc, 6 * Cc, self._w(f"hyper{i}.0.w"), Cc, bias=self._w(f"hyper{i}.0.b"), act=ACT_RELU, out_T=h1,
+                  a_off=i * Cc)
+            h2 = self._proj(h1, f"hyper{i}.1", Cc, act=ACT_RELU)
+            _gemm(h2, N, Cc, Cc, self._w(f"hyper{i}.2.w"), d1, bias=self._w(f"hyper{i}.2.b"), out_f32=hyper, ldc=3 * d1,
+                  f32_off=i * d1)
+        # prompt feature for the next window (sparse_heads.py:650-658): io token 5
+        new_pfeat = torch.empty((N, Cc), **f32)
+        _gemm(hsT, N, Cc, 6 * Cc, self._w("prompt_lin.w"), Cc, bias=self._w("prompt_lin.b"), out_f32=new_pfeat, a_off=5 * Cc)
+
+        # --- memory tokens for the next window (sparse_heads.py:406-448,660-665): project the 2nd temporal half of the
+        #     processed video tokens into the 1st half of the history, pad the rest with the learned mask token ---
+        if need_history:
+            half = P // 2
+            _gemm(kT, N * half, Cc, Cc, self._w("history_proj.w"), Cc, bias=self._w("history_proj.b"), out_f32=hist,
+                  a_map=(half, P, half), c_map=(half, P, 0))
+            _lib.check(lib.l4p_fill_rows(_stream(), _p(hist), _p(self._w("history_mask_token")), N * half, Cc, half, P, half),
+                       "l4p_fill_rows")
+
+        # --- output up-scaling (mask_decoder.py:58-66,136-137) on channels-last tokens ---
+        nt, nh, nw = cfg.grid
+        d0 = min(2 * Cc // self.decoding_out_dim_factor, Cc)
+        u0 = torch.empty((N * nt * 2 * nh * 2 * nw * 2, d0), **f32)
+        dsc = GemmDesc()
+        dsc.A, dsc.lda, dsc.W, dsc.ldw = _p(kT), Cc, _p(self._w("up0.w")), Cc
+        dsc.M, dsc.N, dsc.K = N * P, 8 * d0, Cc
+        dsc.Ti, dsc.Hi, dsc.Wi = nt, nh, nw
+        dsc.bias = _p(self._w("up0.b"))
+        dsc.out_f32 = _p(u0)
+        dsc.epi, dsc.kt, dsc.kh, dsc.kw, dsc.Cout = EPI_CONVT, 2, 2, 2, d0
+        _lib.check(lib.l4p_gemm(_stream(), dt, C.byref(dsc)), "l4p_gemm(up0)")
+        del kT, k32
+        u0T = torch.empty(u0.shape, dtype=td, device=dev)
+        _lib.check(lib.l4p_layernorm_ex(_stream(), dt, _p(u0), _p(self._w("up_ln.g")), _p(self._w("up_ln.b")), 1e-6, _p(u0T),
+                                        None, u0.shape[0], d0, None, 0, None, ACT_GELU), "l4p_layernorm_ex(up)")
+        del u0
+        u1 = ops.conv_transpose(u0T.view(N, nt * 2, nh * 2, nw * 2, d0), self._w("up1.w"), d1, (1, 2, 2),
+                                bias_taps=self._w("up1.b"), act=ACT_GELU)
+        del u0T
+        Tl, hl, wl = nt * 2, nh * 4, nw * 4
+        masks = torch.empty((N, 3, Tl, hl, wl), **f32)
+        _lib.check(lib.l4p_mask_product(_stream(), dt, _p(u1), _p(hyper), _p(masks), N, Tl * hl * wl, d1), "l4p_mask_product")
+        del u1
+        assert Tl == T, "temporal size of the decoded masks must equal the window length"
+        traj = torch.empty((N, 2, T), **f32)
+        vis = torch.empty((N, T), **f32)
+        dep = torch.empty((N, T), **f32)
+        _lib.check(lib.l4p_track_readout(_stream(), _p(masks), _p(traj), _p(vis), _p(dep), N, T, hl, wl, H, W),
+                   "l4p_track_readout")
+        return traj, vis, dep, new_pfeat
+
+    # ------------------------------------------------------------------------------------------------
+    def forward_windowed(self, enc_features_bpc_2dlist, track_2d_pointquerries_bn3: torch.Tensor,
+                         track_2d_pointlabels_bn: torch.Tensor, time_strides: Optional[torch.Tensor] = None,
+                         **kwargs) -> Dict[str, torch.Tensor]:
+        """Chunks of ``max_queries`` (sparse_heads.py:162-211)."""
+        N = track_2d_pointquerries_bn3.shape[1]
+        if N < self.max_queries:
+            return self.forward_windowed_core(enc_features_bpc_2dlist, track_2d_pointquerries_bn3, track_2d_pointlabels_bn,
+                                              time_strides, **kwargs)
+        outs = []
+        for i in range(int(math.ceil(N / self.max_queries))):
+            sl = slice(i * self.max_queries, (i + 1) * self.max_queries)
+            outs.append(self.forward_windowed_core(enc_features_bpc_2dlist, track_2d_pointquerries_bn3[:, sl],
+                                                   track_2d_pointlabels_bn[:, sl], time_strides, **kwargs))
+        return {k: torch.cat([o[k] for o in outs], dim=1) for k in outs[0]}
+
+    def forward_windowed_core(self, enc_features_bpc_2dlist, track_2d_pointquerries_bn3: torch.Tensor,
+                              track_2d_pointlabels_bn: torch.Tensor, time_strides: Optional[torch.Tensor] = None,
+                              **kwargs) -> Dict[str, torch.Tensor]:
+        """Causal sliding-window tracking (sparse_heads.py:213-495), estimation_directions == [1]."""
+        if self._rt is None:
+            raise RuntimeError("tracker head has no weights: call load_state_dict on the model first")
+        assert len(self.estimation_directions) == 1 and self.estimation_directions[0] == 1, (
+            "Currently only positive direction estimation is supported for sliding window tracking.")
+        if time_strides is None:
+            time_strides = torch.zeros(1, dtype=torch.long)
+        lib = _lib.load()
+        cfg = self._rt.cfg
+        dev = enc_features_bpc_2dlist[0].f32(-1).device
+        ws = self.image_size[0]
+        B = track_2d_pointquerries_bn3.shape[0]
+        N = track_2d_pointquerries_bn3.shape[1]
+        T = int(time_strides[-1]) + ws
+        P, Cc = cfg.tokens, cfg.dim
+        f32 = dict(dtype=torch.float32, device=dev)
+        traj_all = torch.zeros(B, N, 2, T, **f32)
+        vis_all = torch.full((B, N, 1, T), -10.0, **f32)
+        dep_all = torch.zeros(B, N, 1, T, **f32)
+        nwin = len(time_strides)
+        for b in range(B):  # the reference asserts B == 1 (sparse_heads.py:241); clips are independent here
+            orig_q = track_2d_pointquerries_bn3[b].to(**f32).contiguous()
+            cur_q = orig_q.clone()
+            pfeat = torch.zeros(N, Cc, **f32)
+            plabel = torch.zeros(N, **f32)
+            hist = torch.empty(N * P, Cc, **f32)
+            _lib.check(lib.l4p_fill_rows(_stream(), _p(hist), _p(self._w("history_mask_token")), N * P, Cc, N * P, 0, 0),
+                       "l4p_fill_rows")
+            q_off = torch.empty(N, 3, **f32)
+            labels = torch.empty(N, **f32)
+            valid_t = torch.empty(N, ws, dtype=torch.uint8, device=dev)
+            valid_n = torch.empty(N, dtype=torch.uint8, device=dev)
+            best = torch.zeros(N, dtype=torch.int32, device=dev)
+            traj_b, vis_b, dep_b = traj_all[b], vis_all[b, :, 0], dep_all[b, :, 0]
+            for wi in range(nwin):
+                start = int(time_strides[wi])
+                last = wi == nwin - 1
+                nxt = int(time_strides[wi + 1]) if not last else start
+                _lib.check(lib.l4p_track_prepare(_stream(), _p(cur_q), _p(orig_q), start, ws, _p(q_off), _p(labels),
+                                                 _p(valid_t), _p(valid_n), N), "l4p_track_prepare")
+                if self.trace is not None:
+                    self.trace.append({"labels": labels.clone(), "queries": q_off.clone(), "prompt_labels": plabel.clone(),
+                                       "valid_t": valid_t.clone()})
+                enc_last = enc_features_bpc_2dlist[wi].f32(-1)[b].contiguous()
+                w_traj, w_vis, w_dep, new_pfeat = self._window(enc_last, hist, q_off, labels, pfeat, plabel, not last)
+                _lib.check(lib.l4p_track_commit(_stream(), _p(w_traj), _p(w_vis), _p(w_dep), _p(valid_t), _p(valid_n),
+                                                traj_b.data_ptr(), vis_b.data_ptr(), dep_b.data_ptr(), T, start, ws, nxt,
+                                                1 if last else 0, _p(cur_q), _p(plabel), _p(new_pfeat), _p(pfeat), _p(best),
+                                                N, Cc), "l4p_track_commit")
+                if self.trace is not None and not last:
+                    self.trace[-1]["best_vis_id"] = best.clone()
+        return {f"{self.task_name}_traj_est_bn2t": traj_all, f"{self.task_name}_vis_est_bn1t": vis_all,
+                f"{self.task_name}_depth_est_bn1t": dep_all}
+
+    def forward(self, enc_features_bpc_list, track_2d_pointquerries_bn3: torch.Tensor, track_2d_pointlabels_bn: torch.Tensor,
+                **kwargs) -> Dict[str, torch.Tensor]:
+        """Single-window entry (l4p_videomae.py:251): same as one window of the sliding tracker."""
+        return self.forward_windowed_core([enc_features_bpc_list], track_2d_pointquerries_bn3, track_2d_pointlabels_bn, None)

@@ -146,7 +146,16 @@ def pack_dpt(pk: Packer, sd: Dict[str, torch.Tensor], c: ModelCfg, task: str):
 def pack_track(pk: Packer, sd: Dict[str, torch.Tensor], c: ModelCfg, task: str = "track_2d"):
     p = f"task_heads.{task}."
     o = "trk."
-    pk.F(o + "gauss", sd[p + "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"])
+    G = sd[p + "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].float()
+    pk.F(o + "gauss", G)
+    # dense positional encoding of the (t, x, y) cell centres: a constant of G, so it is tabulated at pack time
+    # exactly as PositionEmbeddingRandom3D.forward does (prompt_encoder.py:205-219) -> [P][C], token-major
+    nt, nh, nw = c.grid
+    ones = torch.ones((nt, nh, nw), dtype=torch.float32)
+    te, ye, xe = (ones.cumsum(0) - 0.5) / nt, (ones.cumsum(1) - 0.5) / nh, (ones.cumsum(2) - 0.5) / nw
+    coords = 2 * torch.stack([te, xe, ye], dim=-1) - 1
+    ang = 2 * np.pi * (coords @ G)
+    pk.F(o + "dense_pe", torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1).reshape(nt * nh * nw, -1))
     for i in range(2):
         pk.F(f"{o}point_emb{i}", sd[f"{p}prompt_encoder.point_embeddings.{i}.weight"].reshape(-1))
         pk.F(f"{o}feat_emb{i}", sd[f"{p}prompt_encoder.prompt_feature_embeddings.{i}.weight"].reshape(-1))
