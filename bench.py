@@ -169,8 +169,8 @@ def main():
         q = torch.zeros(1, nq, 3)
         for i in range(nq):
             q[0, i] = torch.tensor([0.5, 14.0 + 28.0 * (i % 8) + 0.5, 14.0 + 28.0 * ((i // 8) % 8) + 0.5])
-        batch["track_2d_pointquerries_bn3"] = q.to(device)
-        batch["track_2d_pointlabels_bn"] = torch.ones(1, nq, device=device)
+        batch["track_2d_pointquerries_bn3"] = q.repeat(B, 1, 1).to(device)  # every clip tracks its own nq queries
+        batch["track_2d_pointlabels_bn"] = torch.ones(B, nq, device=device)
 
     def step():
         with torch.no_grad():

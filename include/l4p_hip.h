@@ -100,6 +100,9 @@ typedef struct l4p_gemm_desc {
      * (tracker memory tokens, sparse_heads.py:406-448).  a_*: rows of A, c_*: rows of out / residual. */
     int a_gr, a_gs, a_go;
     int c_gr, c_gs, c_go;
+    /* optional second T output = relu(v), same addressing as out_T: the pre-activated operand of the next
+     * ResidualConvUnit conv (dpt_block.py:139-146), so that conv can stream its input without a fused ReLU */
+    void* out_relu_T;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);

@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("Cout", C.c_int),
         ("a_gr", C.c_int), ("a_gs", C.c_int), ("a_go", C.c_int),
         ("c_gr", C.c_int), ("c_gs", C.c_int), ("c_go", C.c_int),
+        ("out_relu_T", C.c_void_p),
     ]
 
 

@@ -26,7 +26,13 @@ enum { ACT_NONE = L4P_ACT_NONE, ACT_GELU = L4P_ACT_GELU, ACT_RELU = L4P_ACT_RELU
 // The kernel parameter block IS the public descriptor (include/l4p_hip.h): plain pointers and ints.
 typedef l4p_gemm_desc GemmParams;
 
-template <typename T, int BM, int BN, int WM, int WN, int MODE>
+// 16 zero bytes in global memory: the source of LDS-DMA chunks that must read as zero (conv padding, k tail)
+__device__ __attribute__((aligned(16))) static const unsigned g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+// GLDS = true: tiles are staged with global_load_lds (LDS-DMA, no VGPR round trip, no ds_write); the LDS image is
+// lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk and again on the fragment reads.
+// GLDS = false: global -> register -> ds_write staging (needed for the fused input ReLU of the conv loader).
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int ES = sizeof(T);
@@ -49,7 +55,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int crow = tid >> 3, cc = tid & 7;  // this thread's (row, chunk) inside a staging pass
+    const int crow = tid >> 3, cc = tid & 7;  // this thread's (row, LDS slot) inside a staging pass
+    // chunk of the 128-byte source row this thread fetches: with LDS-DMA the swizzle moves to the source side
+    const int cs = GLDS ? (cc ^ ((crow >> 1) & 7)) : cc;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- per-thread source addressing -------------------------------------------------------
     const T* a_base[A_IT];
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         if (m >= p.M) m = p.M - 1;
         if (MODE == 0) {
             const long long pm = p.a_gr > 0 ? (long long)(m / p.a_gr) * p.a_gs + p.a_go + (m % p.a_gr) : m;
-            a_base[i] = (const T*)p.A + pm * p.lda + cc * EPC;
+            a_base[i] = (const T*)p.A + pm * p.lda + cs * EPC;
             a_mask[i] = 0;
         } else {
             int wo = m % p.Wo;
@@ -81,13 +90,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
             }
             a_mask[i] = mask;
             long long vox = (((long long)b * p.Ti + ti) * p.Hi + hi) * p.Wi + wi;
-            a_base[i] = (const T*)p.A + vox * p.Cin + cc * EPC;
+            a_base[i] = (const T*)p.A + vox * p.Cin + cs * EPC;
         }
     }
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
         int n = n0 + crow + i * (NT / 8);
-        w_base[i] = (const T*)p.W + (long long)n * p.ldw + cc * EPC;
+        w_base[i] = (const T*)p.W + (long long)n * p.ldw + cs * EPC;
     }
 
     const int nk = (p.K + BK - 1) / BK;
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 
     auto load_tile = [&](int kt) {
         if (MODE == 0) {
-            const int k = kt * BK + cc * EPC;
+            const int k = kt * BK + cs * EPC;
             const bool kin = k < p.K;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
@@ -151,6 +160,41 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         }
     };
 
+    // LDS-DMA staging: one global_load_lds per 16-byte chunk; destination = wave-uniform base + lane*16
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto issue_tile = [&](int kt, int buf) {
+        const char* zero = (const char*)g_zero_chunk;
+        if (MODE == 0) {
+            const bool kin = (kt * BK + cs * EPC) < p.K;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const char* src = kin ? (const char*)(a_base[i] + kt * BK) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (wave_u * 64 + i * NT) * 16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < W_IT; ++i) {
+                const char* src = kin ? (const char*)(w_base[i] + kt * BK) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ws + buf * BN * 128 + (wave_u * 64 + i * NT) * 16), 16, 0, 0);
+            }
+        } else {
+            const int tap = kt / kpc;
+            const int ci0 = (kt - tap * kpc) * BK;
+            const int dt = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+            const long long toff = (((long long)dt * p.Hi + dh) * p.Wi + dw) * p.Cin + ci0;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const bool ok = (a_mask[i] >> tap) & 1u;
+                const char* src = ok ? (const char*)(a_base[i] + toff) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * 128 + (wave_u * 64 + i * NT) * 16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < W_IT; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(const char*)(w_base[i] + kt * BK),
+                                                 (lptr_t)(Ws + buf * BN * 128 + (wave_u * 64 + i * NT) * 16), 16, 0, 0);
+        }
+    };
+
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -165,13 +209,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) wrow[j] = wn * (TN * 16) + 4 * TN * (li >> 2) + 4 * j + (li & 3);
 
-    load_tile(0);
-    store_tile(0);
+    if (GLDS) {
+        issue_tile(0, 0);
+    } else {
+        load_tile(0);
+        store_tile(0);
+    }
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) {
+            if (GLDS)
+                issue_tile(kt + 1, cur ^ 1);
+            else
+                load_tile(kt + 1);
+        }
         const char* Ab = As + cur * BM * 128;
         const char* Wb = Ws + cur * BN * 128;
 #pragma unroll
@@ -199,7 +252,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma16(wf[j], xf[i], acc[i][j]);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (!GLDS && kt + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
     }
 
@@ -298,6 +351,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
                 float* op = p.out_f32 + off;
                 *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
                 *(f32x4*)(op + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+            }
+            if (p.out_relu_T) {  // second output: relu(v) as T (pre-activated input of the next ResidualConvUnit conv)
+                T* op = (T*)p.out_relu_T + off;
+                if (ES == 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)fmaxf(vv[q], 0.f);
+                    *(bf16x8*)op = o;
+                } else {
+                    *(f32x4*)op = (f32x4){fmaxf(vv[0], 0.f), fmaxf(vv[1], 0.f), fmaxf(vv[2], 0.f), fmaxf(vv[3], 0.f)};
+                    *(f32x4*)((float*)op + 4) = (f32x4){fmaxf(vv[4], 0.f), fmaxf(vv[5], 0.f), fmaxf(vv[6], 0.f), fmaxf(vv[7], 0.f)};
+                }
             }
             if (p.out_T) {
                 T* op = (T*)p.out_T + off;

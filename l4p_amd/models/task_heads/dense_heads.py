@@ -28,10 +28,13 @@ class _Runtime:
         self.cfg, self.weights, self.dtype = cfg, weights, dtype
 
 
-def _conv_rcu(W, key: str, x: torch.Tensor, feat: int, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """ResidualConvUnit_custom (dpt_block.py:131-157): conv2(relu(conv1(relu(x)))) + x  [+ extra]."""
-    y = ops.conv3d_k3(x, W[key + ".c1.w"], feat, bias=W[key + ".c1.b"], relu_in=True, act=ACT_RELU)
-    return ops.conv3d_k3(y, W[key + ".c2.w"], feat, bias=W[key + ".c2.b"], res1=x, res2=extra)
+def _conv_rcu(W, key: str, x: torch.Tensor, x_relu: torch.Tensor, feat: int, extra: Optional[torch.Tensor] = None,
+              relu_copy: bool = False):
+    """ResidualConvUnit_custom (dpt_block.py:131-157): conv2(relu(conv1(relu(x)))) + x  [+ extra].
+    relu(x) comes pre-computed from the epilogue of the kernel that produced x (so conv1 streams its input by
+    LDS-DMA); conv1's own ReLU is an output activation; the skip adds ride conv2's epilogue."""
+    y = ops.conv3d_k3(x_relu, W[key + ".c1.w"], feat, bias=W[key + ".c1.b"], act=ACT_RELU)
+    return ops.conv3d_k3(y, W[key + ".c2.w"], feat, bias=W[key + ".c2.b"], res1=x, res2=extra, relu_copy=relu_copy)
 
 
 def dpt_decode(W, cfg: ModelCfg, task: str, hooks: Sequence[torch.Tensor], out_ch: int,
@@ -54,22 +57,23 @@ def dpt_decode(W, cfg: ModelCfg, task: str, hooks: Sequence[torch.Tensor], out_c
             a = ops.conv_transpose(a, Wt(f"act{i}.1.w"), Li, tuple(2 ** s for s in sf), bias_taps=Wt(f"act{i}.1.b"))
         elif any(s < 0 for s in sf):
             a = ops.conv3d_k3(a, Wt(f"act{i}.1.w"), Li, stride=tuple(2 ** (-s) for s in sf), bias=Wt(f"act{i}.1.b"))
-        layers.append(ops.conv3d_k3(a, Wt(f"rn{i}.w"), F_))
+        layers.append(ops.conv3d_k3(a, Wt(f"rn{i}.w"), F_, relu_copy=True))  # (x, relu(x))
 
-    def fuse(r: int, x0: torch.Tensor, x1: Optional[torch.Tensor], scale: Sequence[int]) -> torch.Tensor:
+    def fuse(r: int, x0, x1, scale: Sequence[int]) -> torch.Tensor:
         key = f"{pre}ref{r}"
-        out = x0
         if x1 is not None:
-            out = _conv_rcu(W, key + ".rcu1", x1, F_, extra=x0)  # x0 + RCU1(x1)
-        out = _conv_rcu(W, key + ".rcu2", out, F_)
+            out, out_relu = _conv_rcu(W, key + ".rcu1", x1[0], x1[1], F_, extra=x0, relu_copy=True)  # x0 + RCU1(x1)
+        else:
+            out, out_relu = x0
+        out = _conv_rcu(W, key + ".rcu2", out, out_relu, F_)
         b_, t_, h_, w_, _ = out.shape
         o, _ = ops.gemm(out.view(-1, F_), W[key + ".out.w"], F_, bias=W[key + ".out.b"])
         o = o.view(b_, t_, h_, w_, F_)
         return ops.upsample_trilinear(o, (t_ * scale[0], h_ * scale[1], w_ * scale[2]), align_corners=True)
 
     p4 = fuse(4, layers[3], None, fu[3])
-    if p4.shape[1] != layers[2].shape[1] or p4.shape[2] != layers[2].shape[2]:
-        p4 = p4[:, : layers[2].shape[1], : layers[2].shape[2]].contiguous()  # dpt_head.py:70-72
+    if p4.shape[1] != layers[2][0].shape[1] or p4.shape[2] != layers[2][0].shape[2]:
+        p4 = p4[:, : layers[2][0].shape[1], : layers[2][0].shape[2]].contiguous()  # dpt_head.py:70-72
     p3 = fuse(3, p4, layers[2], fu[2])
     p2 = fuse(2, p3, layers[1], fu[1])
     p1 = fuse(1, p2, layers[0], fu[0])
@@ -252,8 +256,9 @@ def joint_windowed_estimation(task_names: List[str], task_heads: torch.nn.Module
             cur[name] = o[f"{head.task_name}_est_{head.task_suffix}"]
             if name == "camray":
                 kkey = f"{head.task_name}_intrinsics_est_{head.task_suffix}"
+                # the reference hard-codes batch 1 here (dense_heads.py:421); clips are independent, so B is kept
                 cur["camray_intrinsics_est"] = (o[kkey] if kkey in o else
-                                                intrinsics_b44t[..., st:st + ws].clone().reshape(1, 16, ws))
+                                                intrinsics_b44t[..., st:st + ws].clone().reshape(-1, 16, ws))
         for k, v in cur.items():
             if est[k] is None:
                 shp = list(v.shape)
@@ -264,8 +269,8 @@ def joint_windowed_estimation(task_names: List[str], task_heads: torch.nn.Module
             ov = int(time_strides[win_id - 1]) + ws - st
             pred = {n: cur[n][:, :, :ov] for n in task_names}
             target = {n: est[n][:, :, st:st + ov] for n in task_names}
-            pred["camray_intrinsics"] = cur["camray_intrinsics_est"][:, :, :ov].reshape(1, 4, 4, ov).clone()
-            target["camray_intrinsics"] = est["camray_intrinsics_est"][:, :, st:st + ov].reshape(1, 4, 4, ov)
+            pred["camray_intrinsics"] = cur["camray_intrinsics_est"][:, :, :ov].reshape(-1, 4, 4, ov).clone()
+            target["camray_intrinsics"] = est["camray_intrinsics_est"][:, :, st:st + ov].reshape(-1, 4, 4, ov)
             aligner.solve(pred, target, img_info)
             cur = aligner.apply(cur)
         for k, v in cur.items():

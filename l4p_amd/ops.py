@@ -140,8 +140,9 @@ def patch_gather(rgb: torch.Tensor, patch: Tuple[int, int, int], kp: int, dtype:
 
 def conv3d_k3(x: torch.Tensor, w: torch.Tensor, cout: int, *, stride: Tuple[int, int, int] = (1, 1, 1),
               bias: Optional[torch.Tensor] = None, relu_in: bool = False, act: int = ACT_NONE,
-              res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """3x3x3 conv, pad 1, channels-last: x [B,T,H,W,Cin] -> [B,To,Ho,Wo,cout]; w [ceil128(cout)][27*Cin]."""
+              res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, relu_copy: bool = False):
+    """3x3x3 conv, pad 1, channels-last: x [B,T,H,W,Cin] -> [B,To,Ho,Wo,cout]; w [ceil128(cout)][27*Cin].
+    ``relu_copy=True`` additionally returns relu(out) (written by the same epilogue)."""
     dtype = code_of(x.dtype)
     B, Ti, Hi, Wi, Cin = x.shape
     st, sh, sw = stride
@@ -156,9 +157,11 @@ def conv3d_k3(x: torch.Tensor, w: torch.Tensor, cout: int, *, stride: Tuple[int,
     if res1 is not None:
         d.res1, d.res2, d.res_f32, d.ldr = _p(res1), _p(res2), 0, cout
     d.out_T, d.ldc = _p(out), cout
+    out_relu = torch.empty_like(out) if relu_copy else None
+    d.out_relu_T = _p(out_relu)
     lib = _lib.load()
     _lib.check(lib.l4p_conv3d_k3(_stream(), dtype, C.byref(d)), "l4p_conv3d_k3")
-    return out
+    return (out, out_relu) if relu_copy else out
 
 
 def conv_transpose(x: torch.Tensor, w: torch.Tensor, cout: int, k: Tuple[int, int, int],

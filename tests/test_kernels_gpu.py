@@ -204,3 +204,22 @@ def test_conv_transpose(dev, mode, k):
     ref = F.conv_transpose3d(x_ref.permute(0, 4, 1, 2, 3), w5, bias, stride=k).permute(0, 2, 3, 4, 1)
     y = ops.conv_transpose(x, ops.pad_rows(wT), cout, k, bias_taps=bias.repeat(taps).cuda())
     check(y, ref, mode, True)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_conv3d_relu_copy_and_kpadded_gemm(dev, mode):
+    """LDS-DMA path extras: second relu(out) output of the epilogue; K tails that are not a multiple of the k-tile."""
+    B, T, H, W, Cin, cout = 1, 4, 12, 12, 128, 256
+    x, x_ref = as_mode(rnd((B, T, H, W, Cin), 80), mode)
+    w = rnd((cout, Cin, 3, 3, 3), 81, (27 * Cin) ** -0.5)
+    wT, w_ref = as_mode(w.permute(0, 2, 3, 4, 1).reshape(cout, 27 * Cin), mode)
+    ref = F.conv3d(x_ref.permute(0, 4, 1, 2, 3), w_ref.view(cout, 3, 3, 3, Cin).permute(0, 4, 1, 2, 3), padding=1).permute(0, 2, 3, 4, 1)
+    y, yr = ops.conv3d_k3(x, ops.pad_rows(wT), cout, relu_copy=True)
+    check(y, ref, mode, True)
+    check(yr, F.relu(ref), mode, True)
+    # dense GEMM with K = 352 (5.5 k-tiles of 64) and K = 88
+    for K in (352, 88):
+        a, a_ref = as_mode(rnd((300, K), 82), mode)
+        wk, wk_ref = as_mode(rnd((176, K), 83, K ** -0.5), mode)
+        yT, _ = ops.gemm(a, ops.pad_rows(wk), 176)
+        check(yT, a_ref @ wk_ref.t(), mode, True)
