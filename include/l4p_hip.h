@@ -89,7 +89,9 @@ typedef struct l4p_gemm_desc {
     void* out_T;    /* optional T output      [M][ldc] */
     long long ldc;
     int epi;
-    /* L4P_EPI_QKV: n < 2*H*Dp -> out_T[m][n] (q|k, ldc = 2*H*Dp); n >= 2*H*Dp -> vt[b][h][d][s] */
+    /* L4P_EPI_QKV (Dp = 96): n < H*Dp -> q: out_T[m][n] (ldc = H*Dp); H*Dp <= n < 2*H*Dp -> k: kt, tiled
+     * in 8-element groups [b][h][S/KVB][Dp/16][KVB][half ^ ((key>>3)&1)], KVB = 64 (bf16) / 32 (f32);
+     * n >= 2*H*Dp -> v transposed: vt[b][h][d][s] */
     void* vt;
     int S, H, Dp;
     /* L4P_EPI_CONVT: n = tap*Cout + co, tap = (dt*kh + dh)*kw + dw; A rows are the (Ti,Hi,Wi) grid;
@@ -103,6 +105,8 @@ typedef struct l4p_gemm_desc {
     /* optional second T output = relu(v), same addressing as out_T: the pre-activated operand of the next
      * ResidualConvUnit conv (dpt_block.py:139-146), so that conv can stream its input without a fused ReLU */
     void* out_relu_T;
+    /* L4P_EPI_QKV: K destination in the attention kernel's tile order (see l4p_attention) */
+    void* k_tiled;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
@@ -115,9 +119,10 @@ int l4p_layernorm(l4p_stream stream, int dtype, const float* x, const float* gam
                   void* out_T, float* out_f32, int M, int C);
 
 /* Fused softmax(q k^T * scale) v for the encoder (modeling_finetune.py:180-186).
- * qk: [B][S][2][H][96] T, vt: [B][H][96][S] T (both written by L4P_EPI_QKV), out: [B*S][H*Dh] T. */
-int l4p_attention(l4p_stream stream, int dtype, const void* qk, const void* vt, void* out, int B, int S, int H, int Dh,
-                  float scale);
+ * q: [B*S][H*96] T, kt: tiled K, vt: [B][H][96][S] T (all three written by L4P_EPI_QKV), out: [B*S][H*Dh] T.
+ * Dh in {88, 64} (head dim < 96: one padding row of V^T carries the softmax denominator). */
+int l4p_attention(l4p_stream stream, int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S,
+                  int H, int Dh, float scale);
 
 /* Tubelet gather of PatchEmbed's Conv3d(kernel=stride) (modeling_finetune.py:269-283):
  * rgb [B][Cin][T][H][W] float -> out [B*nT*nH*nW][Kp] T, zero-padded columns >= Cin*pt*ph*pw. */

@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("a_gr", C.c_int), ("a_gs", C.c_int), ("a_go", C.c_int),
         ("c_gr", C.c_int), ("c_gs", C.c_int), ("c_go", C.c_int),
         ("out_relu_T", C.c_void_p),
+        ("k_tiled", C.c_void_p),
     ]
 
 
@@ -67,7 +68,7 @@ SIGNATURES = {
     "l4p_gemm": (_I, [_VP, _I, C.POINTER(GemmDesc)]),
     "l4p_conv3d_k3": (_I, [_VP, _I, C.POINTER(GemmDesc)]),
     "l4p_layernorm": (_I, [_VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I]),
-    "l4p_attention": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _F]),
+    "l4p_attention": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F]),
     "l4p_patch_gather": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
     "l4p_cast": (_I, [_VP, _I, _VP, _VP, _LL]),
     "l4p_upsample_trilinear": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I]),

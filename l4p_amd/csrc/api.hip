@@ -42,9 +42,9 @@ int l4p_layernorm(l4p_stream stream, int dtype, const float* x, const float* gam
                   void* out_T, float* out_f32, int M, int C) {
     return launch_layernorm(dtype, x, gamma, beta, eps, out_T, out_f32, M, C, (hipStream_t)stream);
 }
-int l4p_attention(l4p_stream stream, int dtype, const void* qk, const void* vt, void* out, int B, int S, int H, int Dh,
-                  float scale) {
-    return launch_attention(dtype, qk, vt, out, B, S, H, Dh, scale, (hipStream_t)stream);
+int l4p_attention(l4p_stream stream, int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S,
+                  int H, int Dh, float scale) {
+    return launch_attention(dtype, q, kt, vt, out, B, S, H, Dh, scale, (hipStream_t)stream);
 }
 int l4p_patch_gather(l4p_stream stream, int dtype, const float* rgb, void* out, int B, int Cin, int T, int H, int W,
                      int pt, int ph, int pw, int Kp) {
@@ -282,8 +282,9 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
         p.N = 3 * H * Dp;
         p.K = C;
         p.bias = (const float*)qkvb;
-        p.out_T = w.qk;
-        p.ldc = 2 * H * Dp;
+        p.out_T = w.qk;  // q: [M][H*Dp]; k (tile order) follows in the same workspace slot
+        p.k_tiled = w.qk + (size_t)M * H * Dp * es;
+        p.ldc = H * Dp;
         p.epi = EPI_QKV;
         p.vt = w.vt;
         p.S = S;
@@ -291,7 +292,7 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
         p.Dp = Dp;
         rc = launch_gemm(dt, 0, p, stream);
         if (rc) return rc;
-        rc = launch_attention(dt, w.qk, w.vt, w.ao, B, S, H, Dh, scale, stream);
+        rc = launch_attention(dt, w.qk, w.qk + (size_t)M * H * Dp * es, w.vt, w.ao, B, S, H, Dh, scale, stream);
         if (rc) return rc;
         memset(&p, 0, sizeof(p));
         p.A = w.ao;

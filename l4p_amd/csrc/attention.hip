@@ -3,93 +3,117 @@
 // 2048 tokens per window).  Never materialises the S x S score matrix.
 //
 // Inputs come straight from the QKV GEMM epilogue (gemm.hpp, EPI_QKV):
-//   qk : [B][S][2][H][DP]  (q | k, head dim zero-padded 88 -> DP = 96)
-//   vt : [B][H][DP][S]     (V transposed, so a PV operand fragment is 8 consecutive keys)
-// Output: out[B*S][H*Dh] (token-major, head-major columns = transpose(1,2).reshape of the reference).
+//   q  : [B*S][H*DP]            head dim zero-padded 88 -> DP = 96
+//   kt : K in LDS tile order    8-element groups [b][h][S/KVB][DP/16][KVB][half ^ ((key>>3)&1)]
+//   vt : [B][H][DP][S]          V transposed, so a PV operand fragment is 8 consecutive keys
+// Output: out[B*S][H*DH] (token-major, head-major columns = transpose(1,2).reshape of the reference).
 //
 // CDNA4 mapping (32x32 MFMA, one wave = 32 query rows, 4 waves per workgroup):
-//  * S^T = K Q^T ("swapped" operands): each lane owns ONE query column, so row max / row sum /
-//    rescale are lane-local plus a single lane<->lane+32 exchange.
+//  * K / V^T tiles are staged by LDS-DMA (global_load_lds, 16 B per lane): no VGPR round trip, no
+//    ds_write.  The K tile is a linear 12 KB copy (its swizzle was applied by the producer); the V^T
+//    tile gets the XOR swizzle through the per-lane SOURCE address.  Both fragment reads are
+//    conflict-free ds_read_b128.  LDS double-buffered, one barrier per KV block.
+//  * S^T = K Q^T ("swapped" operands): each lane owns ONE query column, so row max and rescale are
+//    lane-local plus a single lane<->lane+32 exchange.
 //  * K rows are read with bits 2/3 of the row index swapped, which makes the 8 scores a lane holds
-//    for a k-step 8 CONSECUTIVE keys: P goes from the S accumulator straight into the PV operand
-//    (no LDS round trip, no cross-lane shuffle), and the V^T fragment is one ds_read_b128.
+//    for a k-step 8 CONSECUTIVE keys: P goes from the S accumulator straight into the PV operand.
 //  * O^T = V^T P^T keeps the output accumulator column = query, so the online-softmax rescale is a
-//    plain per-lane multiply.
-//  * K / V^T tiles are staged global -> registers -> LDS (loads issued before the MFMAs of the
-//    current tile, written after them), LDS double-buffered, rows padded by 16 B (odd slot stride)
-//    so both ds_read_b128 patterns are conflict-free.
+//    plain per-lane multiply — and it is skipped (wave-uniformly) whenever no row maximum moved.
+//  * the softmax denominator comes out of the MFMA: padding row d = DH of the V^T tile is sourced
+//    from a constant "ones" chunk, so O^T[DH][q] = sum_k P[q][k] with exactly the weights used for O.
+//  * exp via v_exp_f32 (exp2 of non-positive arguments), scale*log2(e) folded into one fma.
 #include "common.hpp"
 
-template <typename T, int DP, int KVB>
-__global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qk, const T* __restrict__ vt,
-                                                   T* __restrict__ out, int S, int H, int Dh, float c_scale) {
+__device__ __attribute__((aligned(16))) static const unsigned short g_ones_bf16[8] = {0x3F80, 0x3F80, 0x3F80, 0x3F80,
+                                                                                         0x3F80, 0x3F80, 0x3F80, 0x3F80};
+__device__ __attribute__((aligned(16))) static const float g_ones_f32[4] = {1.f, 1.f, 1.f, 1.f};
+
+// SPLIT = 2: the workgroup has 8 waves; waves 0-3 walk the even KV blocks and waves 4-7 the odd ones for the
+// SAME 128 query rows, and the two partial (m, O, denominator) states are merged through LDS at the end.
+// Used when the launch has too few workgroups to put two of them on a CU (batch 1: 256 workgroups), so
+// every SIMD still holds two waves whose MFMA / VALU / wait phases overlap.
+template <typename T, int DP, int KVB, int DH, int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__ q, const T* __restrict__ kt,
+                                                           const T* __restrict__ vt, T* __restrict__ out, int S, int H,
+                                                           float c_scale) {
     typedef typename Frag<T>::type frag_t;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;
-    constexpr int CPF = 8 * ES / 16;
-    constexpr int KSTR = DP * ES + 16;   // bytes per K row in LDS
-    constexpr int VSTR = KVB * ES + 16;  // bytes per V^T row in LDS
-    constexpr int NKS = DP / 16;         // k-steps of the QK^T contraction
-    constexpr int NST = KVB / 32;        // 32-key score tiles per KV block
-    constexpr int NDT = DP / 32;         // 32-wide output d tiles
-    constexpr int KCH = KVB * (DP * ES / 16);  // 16-byte chunks in a K tile
-    constexpr int VCH = DP * (KVB * ES / 16);
-    constexpr int K_IT = KCH / 256, V_IT = VCH / 256;
-    static_assert(KCH % 256 == 0 && VCH % 256 == 0, "tile chunking");
-    constexpr int KBYTES = KVB * KSTR, VBYTES = DP * VSTR;
+    constexpr int CPF = 8 * ES / 16;       // 16-byte chunks per 8-element fragment
+    constexpr int NKS = DP / 16;           // k-steps of the QK^T contraction
+    constexpr int NST = KVB / 32;          // 32-key score tiles per KV block
+    constexpr int NDT = DP / 32;           // 32-wide output d tiles
+    constexpr int KBYTES = NKS * KVB * 2 * 8 * ES;  // 12 KB
+    constexpr int VBYTES = DP * 128;                // KVB * ES == 128: 12 KB
+    static_assert(KVB * ES == 128, "V^T tile rows are 128 bytes");
+    static_assert(KBYTES % 4096 == 0 && VBYTES % 4096 == 0, "tile = whole LDS-DMA passes of 256 lanes");
+    static_assert(DH < DP && DH % 4 == 0, "one padding row carries the denominator");
+    constexpr int K_IT = KBYTES / 4096, V_IT = VBYTES / 4096;
+    constexpr int DT_L = DH / 32, I_L = DH % 32;                       // where the denominator row lands in O^T
+    constexpr int HI_L = (I_L >> 2) & 1, R_L = (I_L & 3) + 4 * (I_L >> 3);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;               // [2][KBYTES]
-    char* Vs = smem + 2 * KBYTES;  // [2][VBYTES]
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // KV-split group of this wave
+    char* Ks = smem + grp * 2 * (KBYTES + VBYTES);  // [2][KBYTES]   (per group)
+    char* Vs = Ks + 2 * KBYTES;                      // [2][VBYTES]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63;  // thread / wave index inside the group
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, hi = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // XCD-aware work mapping: workgroup L runs on XCD L % 8 (observed dispatch order; speed only, not
+    // correctness).  All S/128 query blocks of one (batch, head) are given to the SAME XCD so that head's
+    // K / V^T (786 KB) is fetched into one L2 instead of eight.
+    const int nqb = S / 128, units = gridDim.x / nqb;  // units = B * H
+    int unit, qb;
+    if ((units & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        unit = xcd + 8 * (j / nqb);
+        qb = j % nqb;
+    } else {
+        unit = blockIdx.x / nqb;
+        qb = blockIdx.x % nqb;
+    }
+    const int b = unit / H, h = unit % H;
     const int q_row = qb * 128 + wave * 32 + lq;
-    const long long tok_stride = 2LL * H * DP;  // elements between consecutive tokens in qk
 
     // Q fragments (B operand: column = query, 8 consecutive d per k-step half)
     frag_t qf[NKS];
     {
-        const T* qp = qk + ((long long)b * S + q_row) * tok_stride + (long long)h * DP;
+        const T* qp = q + ((long long)b * S + q_row) * ((long long)H * DP) + (long long)h * DP;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             u32x4* d = (u32x4*)&qf[ks];
 #pragma unroll
-            for (int q = 0; q < CPF; ++q) d[q] = *(const u32x4*)(qp + ks * 16 + hi * 8 + q * EPC);
+            for (int c = 0; c < CPF; ++c) d[c] = *(const u32x4*)(qp + ks * 16 + hi * 8 + c * EPC);
         }
     }
 
-    const T* kbase = qk + (long long)b * S * tok_stride + (long long)(H + h) * DP;  // + key*tok_stride
-    const T* vbase = vt + ((long long)b * H + h) * DP * S;                           // + d*S + key
-
-    u32x4 rk[K_IT], rv[V_IT];
-    auto load_kv = [&](int kb) {
+    // ---- LDS-DMA sources -----------------------------------------------------------------------------
+    const int nkb = S / KVB;
+    const char* kbase = (const char*)kt + ((long long)(b * H + h) * nkb) * KBYTES + tid * 16;  // + kb*KBYTES + i*4096
+    // V^T: LDS position (row d, slot) <- chunk slot ^ ((d >> 1) & 7) of that row
+    const int vrow0 = tid >> 3, vslot = tid & 7;
+    const int vchunk = vslot ^ ((vrow0 >> 1) & 7);  // (d >> 1) & 7 is the same for d = vrow0 + 32*i
+    const char* vsrc[V_IT];
+    bool vones[V_IT];
 #pragma unroll
-        for (int i = 0; i < K_IT; ++i) {
-            const int id = tid + i * 256;
-            const int row = id / (DP * ES / 16), c = id % (DP * ES / 16);
-            rk[i] = *(const u32x4*)(kbase + (long long)(kb * KVB + row) * tok_stride + c * EPC);
-        }
+    for (int i = 0; i < V_IT; ++i) {
+        const int d = vrow0 + 32 * i;
+        vones[i] = d == DH;
+        vsrc[i] = (const char*)(vt + (((long long)b * H + h) * DP + d) * S) + vchunk * 16;  // + kb*128
+    }
+    const char* ones = ES == 2 ? (const char*)g_ones_bf16 : (const char*)g_ones_f32;
+    auto issue_kv = [&](int kb, int buf) {
 #pragma unroll
-        for (int i = 0; i < V_IT; ++i) {
-            const int id = tid + i * 256;
-            const int row = id / (KVB * ES / 16), c = id % (KVB * ES / 16);
-            rv[i] = *(const u32x4*)(vbase + (long long)row * S + kb * KVB + c * EPC);
-        }
-    };
-    auto store_kv = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < K_IT; ++i) {
-            const int id = tid + i * 256;
-            const int row = id / (DP * ES / 16), c = id % (DP * ES / 16);
-            *(u32x4*)(Ks + buf * KBYTES + row * KSTR + c * 16) = rk[i];
-        }
+        for (int i = 0; i < K_IT; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (long long)kb * KBYTES + i * 4096),
+                                             (lptr_t)(Ks + buf * KBYTES + (wave * 64 + i * 256) * 16), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < V_IT; ++i) {
-            const int id = tid + i * 256;
-            const int row = id / (KVB * ES / 16), c = id % (KVB * ES / 16);
-            *(u32x4*)(Vs + buf * VBYTES + row * VSTR + c * 16) = rv[i];
+            const char* src = vones[i] ? ones : vsrc[i] + (long long)kb * 128;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vs + buf * VBYTES + (wave * 64 + i * 256) * 16), 16, 0, 0);
         }
     };
 
@@ -98,22 +122,38 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qk, con
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY;
 
-    // K row read by this lane for score-tile row i = lq: swap bits 2 and 3
+    // K tile row read by this lane for score-tile row i = lq: swap bits 2 and 3
     const int krow = (lq & ~12) | ((lq & 4) << 1) | ((lq & 8) >> 1);
+    // byte offsets of this lane's fragments inside the tiles
+    int koff[NST];
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+        const int key = t * 32 + krow;
+        koff[t] = (key * 2 + (hi ^ ((key >> 3) & 1))) * 8 * ES;  // + ks * KVB * 2 * 8 * ES
+    }
+    int voff[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) voff[dt] = (dt * 32 + lq) * 128;
+    const int vsw = (lq >> 1) & 7;  // ((dt*32 + lq) >> 1) & 7
 
-    const int nkb = S / KVB;
-    load_kv(0);
-    store_kv(0);
+    issue_kv(grp, 0);
     __syncthreads();
 
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = kb & 1;
-        if (kb + 1 < nkb) load_kv(kb + 1);
+    const int nit = nkb / SPLIT;  // this group's KV blocks: grp, grp + SPLIT, ...
+    for (int it = 0; it < nit; ++it) {
+        const int cur = it & 1;
+#ifndef ATTN_DBG_NOLOAD  // (tools/probes/attn_variants.hip: compute-only timing)
+        if (it + 1 < nit) issue_kv((it + 1) * SPLIT + grp, cur ^ 1);
+#endif
         const char* Kb = Ks + cur * KBYTES;
         const char* Vb = Vs + cur * VBYTES;
 
+#ifdef ATTN_DBG_NOCOMPUTE  // (probe: staging-only timing)
+        __syncthreads();
+        continue;
+#endif
         // ---- S^T tiles: rows = keys (permuted), cols = queries --------------------------------
         f32x16 s[NST];
 #pragma unroll
@@ -125,36 +165,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qk, con
                 frag_t kf;
                 u32x4* d = (u32x4*)&kf;
 #pragma unroll
-                for (int q = 0; q < CPF; ++q)
-                    d[q] = *(const u32x4*)(Kb + (t * 32 + krow) * KSTR + (ks * 16 + hi * 8) * ES + q * 16);
+                for (int c = 0; c < CPF; ++c) d[c] = *(const u32x4*)(Kb + ks * (KVB * 2 * 8 * ES) + koff[t] + c * 16);
                 s[t] = mma32(kf, qf[ks], s[t]);
             }
         }
 
         // ---- online softmax (all per-query state is lane-local) -------------------------------
-        float mx = -INFINITY;
+        float mx = s[0][0];
 #pragma unroll
         for (int t = 0; t < NST; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+            for (int r = (t == 0 ? 1 : 0); r < 16; ++r) mx = fmaxf(mx, s[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx * c_scale);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
+        if (__any(m_new > m_run)) {  // wave-uniform: some row maximum moved -> rescale O (and the denominator row)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            m_run = m_new;
+        }
 #pragma unroll
         for (int t = 0; t < NST; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[t][r] * c_scale - m_new);
-                s[t][r] = pv;
-                psum += pv;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c_scale, -m_run));
 
         // ---- O^T += V^T P^T ---------------------------------------------------------------------
 #pragma unroll
@@ -164,35 +199,59 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qk, con
                 frag_t pf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[e] = from_f32<T>(s[t][8 * j + e]);
+                const int c0 = ((t * 32 + j * 16 + hi * 8) * ES) >> 4;  // first 16-byte chunk of the 8 keys
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     frag_t vf;
                     u32x4* d = (u32x4*)&vf;
 #pragma unroll
-                    for (int q = 0; q < CPF; ++q)
-                        d[q] = *(const u32x4*)(Vb + (dt * 32 + lq) * VSTR + (t * 32 + j * 16 + hi * 8) * ES + q * 16);
+                    for (int c = 0; c < CPF; ++c) d[c] = *(const u32x4*)(Vb + voff[dt] + (((c0 + c) ^ vsw) << 4));
                     o[dt] = mma32(vf, pf, o[dt]);
                 }
             }
+        __syncthreads();  // (drains the LDS-DMA of the next tile: vmcnt(0) + barrier)
+    }
 
-        if (kb + 1 < nkb) store_kv(cur ^ 1);
+    // ---- SPLIT: merge the partial states of the KV groups through LDS (tile buffers are free now) -----
+    if (SPLIT > 1) {
+        float* xch = (float*)smem;  // [4 waves][NDT*16 + 1][64 lanes]
+        constexpr int NX = NDT * 16 + 1;
+        if (grp == 1) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(wave * NX + dt * 16 + r) * 64 + lane] = o[dt][r];
+            xch[(wave * NX + NDT * 16) * 64 + lane] = m_run;
+        }
         __syncthreads();
+        if (grp == 1) return;
+        const float m1 = xch[(wave * NX + NDT * 16) * 64 + lane];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = o[dt][r] * a0 + xch[(wave * NX + dt * 16 + r) * 64 + lane] * a1;
     }
 
     // ---- normalise and store: lane owns query q_row, d = 32*dt + (r&3) + 8*(r>>2) + 4*hi -------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot = o[DT_L][R_L];
+    {
+        const float other = __shfl_xor(l_tot, 32);
+        if (hi != HI_L) l_tot = other;
+    }
     const float inv = 1.0f / l_tot;
-    T* op = out + ((long long)b * S + q_row) * ((long long)H * Dh) + (long long)h * Dh;
+    T* op = out + ((long long)b * S + q_row) * ((long long)H * DH) + (long long)h * DH;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d0 = dt * 32 + 8 * g + 4 * hi;
-            if (d0 < Dh) {  // Dh % 4 == 0
+            if (d0 < DH) {
                 if (ES == 2) {
                     bf16x4 v;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (bf16_t)(o[dt][4 * g + q] * inv);
+                    for (int k = 0; k < 4; ++k) v[k] = (bf16_t)(o[dt][4 * g + k] * inv);
                     *(bf16x4*)(op + d0) = v;
                 } else {
                     *(f32x4*)(op + d0) = (f32x4){o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
@@ -202,13 +261,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qk, con
         }
 }
 
-template <typename T, int KVB>
-static int launch_attn_t(const void* qk, const void* vt, void* out, int B, int S, int H, int Dh, float scale,
+template <typename T, int KVB, int DH, int SPLIT>
+static int launch_attn_t(const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, float scale,
                          hipStream_t stream) {
     constexpr int DP = 96;
-    constexpr int ES = sizeof(T);
-    const size_t lds = 2 * (KVB * (DP * ES + 16) + DP * (KVB * ES + 16));
-    auto kern = attn_kernel<T, DP, KVB>;
+    const size_t lds = SPLIT * 2 * (size_t)(DP / 16 * KVB * 2 * 8 * sizeof(T) + DP * 128);
+    auto kern = attn_kernel<T, DP, KVB, DH, SPLIT>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -216,19 +274,28 @@ static int launch_attn_t(const void* qk, const void* vt, void* out, int B, int S
     }
     const float c_scale = scale * 1.4426950408889634f;
     ProfScope prof(PROF_ATTENTION, stream);
-    hipLaunchKernelGGL(kern, dim3(S / 128, H, B), dim3(256), lds, stream, (const T*)qk, (const T*)vt, (T*)out, S, H,
-                       Dh, c_scale);
+    hipLaunchKernelGGL(kern, dim3((S / 128) * H * B), dim3(256 * SPLIT), lds, stream, (const T*)q, (const T*)kt, (const T*)vt, (T*)out,
+                       S, H, c_scale);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-// qk: [B][S][2][H][96], vt: [B][H][96][S], out: [B*S][H*Dh]; scale = Dh^-0.5 (reference :150)
-int launch_attention(int dtype, const void* qk, const void* vt, void* out, int B, int S, int H, int Dh, float scale,
-                     hipStream_t stream) {
-    if (S % 128 || Dh > 96 || Dh % 4) {
-        l4p_set_error("attention: need S %% 128 == 0 and head_dim <= 96, multiple of 4 (S=%d Dh=%d)", S, Dh);
+// scale = Dh^-0.5 (reference :150)
+int launch_attention(int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, int Dh,
+                     float scale, hipStream_t stream) {
+    if (S % 128 || (Dh != 88 && Dh != 64)) {
+        l4p_set_error("attention: need S %% 128 == 0 and head_dim in {88, 64} (S=%d Dh=%d)", S, Dh);
         return L4P_E_INVALID;
     }
-    if (dtype == L4P_BF16) return launch_attn_t<bf16_t, 64>(qk, vt, out, B, S, H, Dh, scale, stream);
-    return launch_attn_t<float, 32>(qk, vt, out, B, S, H, Dh, scale, stream);
+    // too few workgroups for two per CU (256 CUs): split the KV range over two wave groups inside each workgroup
+    const bool split = (long long)(S / 128) * H * B < 512 && (S / 64) % 2 == 0;
+    if (dtype == L4P_BF16) {
+        if (Dh == 88)
+            return split ? launch_attn_t<bf16_t, 64, 88, 2>(q, kt, vt, out, B, S, H, scale, stream)
+                         : launch_attn_t<bf16_t, 64, 88, 1>(q, kt, vt, out, B, S, H, scale, stream);
+        return split ? launch_attn_t<bf16_t, 64, 64, 2>(q, kt, vt, out, B, S, H, scale, stream)
+                     : launch_attn_t<bf16_t, 64, 64, 1>(q, kt, vt, out, B, S, H, scale, stream);
+    }
+    if (Dh == 88) return launch_attn_t<float, 32, 88, 1>(q, kt, vt, out, B, S, H, scale, stream);
+    return launch_attn_t<float, 32, 64, 1>(q, kt, vt, out, B, S, H, scale, stream);
 }

@@ -29,7 +29,7 @@ int launch_layernorm(int dtype, const float* x, const float* gamma, const float*
 int launch_cast(int dtype, const float* x, void* y, long long n, hipStream_t stream);
 int launch_patch_gather(int dtype, const float* rgb, void* out, int B, int Cin, int T, int H, int W, int pt, int ph,
                         int pw, int Kp, hipStream_t stream);
-int launch_attention(int dtype, const void* qk, const void* vt, void* out, int B, int S, int H, int Dh, float scale,
+int launch_attention(int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, int Dh, float scale,
                      hipStream_t stream);
 int launch_upsample(int dtype, const void* x, void* y, int B, int Ti, int Hi, int Wi, int To, int Ho, int Wo, int C,
                     int align, hipStream_t stream);

@@ -337,6 +337,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
                     }
                 }
             }
+            if (p.epi == EPI_QKV && n >= p.H * p.Dp && n < 2 * p.H * p.Dp) {
+                // K, stored in the attention kernel's LDS tile order (attention.hip): 8-element groups
+                // [b][h][kv block][k-step][key][half ^ ((key >> 3) & 1)], KVB keys per block
+                constexpr int KVB = 128 / ES;
+                const int nk = n - p.H * p.Dp;
+                const int h = nk / p.Dp, d0 = nk - h * p.Dp;
+                const int ks = d0 >> 4, half = (d0 >> 3) & 1;
+                const int b = m / p.S, s = m - b * p.S;
+                const int kb = s / KVB, key = s - kb * KVB;
+                const long long g8 =
+                    ((((long long)(b * p.H + h) * (p.S / KVB) + kb) * (p.Dp / 16) + ks) * KVB + key) * 2 + (half ^ ((key >> 3) & 1));
+                T* kp = (T*)p.k_tiled + g8 * 8;
+                if (ES == 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
+                    *(bf16x8*)kp = o;
+                } else {
+                    *(f32x4*)kp = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+                    *(f32x4*)((float*)kp + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+                }
+                continue;
+            }
             if (p.epi == EPI_QKV && n >= 2 * p.H * p.Dp) {
                 // V, stored transposed: vt[((b*H + h)*Dp + d)*S + s]
                 const int nv = n - 2 * p.H * p.Dp;

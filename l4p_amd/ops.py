@@ -97,32 +97,51 @@ def gemm(a: torch.Tensor, w: torch.Tensor, n: int, *, bias: Optional[torch.Tenso
     return oT, of
 
 
-def qkv_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, S: int, H: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Fused qkv projection writing the attention layouts: qk [B,S,2,H,96], vt [B,H,96,S]."""
+def kv_block(dtype: torch.dtype) -> int:
+    """Keys per attention KV block (a 128-byte V^T tile row): 64 for bf16, 32 for f32."""
+    return 128 // torch.empty((), dtype=dtype).element_size()
+
+
+def k_tile_order(k: torch.Tensor) -> torch.Tensor:
+    """Host-side statement of the K tile order the kernels use (tests / documentation):
+    k [B,S,H,96] -> 8-element groups [B][H][S/KVB][6][KVB][half ^ ((key>>3)&1)]."""
+    B, S, H, dp = k.shape
+    kvb = kv_block(k.dtype)
+    g = k.view(B, S // kvb, kvb, H, dp // 16, 2, 8).permute(0, 3, 1, 4, 2, 5, 6).contiguous()  # B H kb ks key half 8
+    key = torch.arange(kvb, device=k.device)
+    flip = ((key >> 3) & 1).bool()
+    g[:, :, :, :, flip] = g[:, :, :, :, flip].flip(-2)
+    return g.reshape(-1)
+
+
+def qkv_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, S: int, H: int):
+    """Fused qkv projection writing the attention layouts: q [B*S, H*96], kt (tile order, flat), vt [B,H,96,S]."""
     dtype = code_of(a.dtype)
     M, K = a.shape
-    assert M == B * S and w.shape[0] >= 3 * H * DP
-    qk = torch.empty((B, S, 2, H, DP), dtype=a.dtype, device=a.device)
+    assert M == B * S and w.shape[0] >= 3 * H * DP and S % kv_block(a.dtype) == 0
+    q = torch.empty((M, H * DP), dtype=a.dtype, device=a.device)
+    kt = torch.empty((M * H * DP,), dtype=a.dtype, device=a.device)
     vt = torch.empty((B, H, DP, S), dtype=a.dtype, device=a.device)
     d = GemmDesc()
     d.A, d.lda, d.W, d.ldw = _p(a), K, _p(w), K
     d.M, d.N, d.K = M, 3 * H * DP, K
     d.bias = _p(bias)
-    d.out_T, d.ldc = _p(qk), 2 * H * DP
+    d.out_T, d.ldc = _p(q), H * DP
     d.epi = EPI_QKV
+    d.k_tiled = _p(kt)
     d.vt, d.S, d.H, d.Dp = _p(vt), S, H, DP
     lib = _lib.load()
     _lib.check(lib.l4p_gemm(_stream(), dtype, C.byref(d)), "l4p_gemm(qkv)")
-    return qk, vt
+    return q, kt, vt
 
 
-def attention(qk: torch.Tensor, vt: torch.Tensor, head_dim: int, scale: Optional[float] = None) -> torch.Tensor:
-    B, S, two, H, dp = qk.shape
-    assert two == 2 and dp == DP and tuple(vt.shape) == (B, H, DP, S)
-    out = torch.empty((B * S, H * head_dim), dtype=qk.dtype, device=qk.device)
+def attention(q: torch.Tensor, kt: torch.Tensor, vt: torch.Tensor, head_dim: int, scale: Optional[float] = None) -> torch.Tensor:
+    B, H, dp, S = vt.shape
+    assert dp == DP and tuple(q.shape) == (B * S, H * DP) and kt.numel() == q.numel()
+    out = torch.empty((B * S, H * head_dim), dtype=q.dtype, device=q.device)
     scale = head_dim ** -0.5 if scale is None else scale
     lib = _lib.load()
-    _lib.check(lib.l4p_attention(_stream(), code_of(qk.dtype), _p(qk), _p(vt), _p(out), B, S, H, head_dim, scale),
+    _lib.check(lib.l4p_attention(_stream(), code_of(q.dtype), _p(q), _p(kt), _p(vt), _p(out), B, S, H, head_dim, scale),
                "l4p_attention")
     return out
 

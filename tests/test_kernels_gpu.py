@@ -104,7 +104,8 @@ def test_gemm_broadcast_residual(dev, mode):
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,S,H,Dh", [(1, 2048, 16, 88), (2, 256, 2, 88), (1, 128, 3, 64)])
 def test_qkv_attention(dev, mode, B, S, H, Dh):
-    """qkv GEMM epilogue layouts + fused attention vs softmax(q k^T / sqrt(d)) v."""
+    """qkv GEMM epilogue layouts (q dense, k in tile order, v transposed) + fused attention vs
+    softmax(q k^T / sqrt(d)) v."""
     C = H * Dh
     x, x_ref = as_mode(rnd((B * S, C), 40), mode)
     wqkv = rnd((3 * C, C), 41, C ** -0.5)
@@ -116,40 +117,51 @@ def test_qkv_attention(dev, mode, B, S, H, Dh):
     bp[0, :, :Dh] = qb.view(H, Dh)
     bp[2, :, :Dh] = vb.view(H, Dh)
     w, w_ref = as_mode(wp.view(3 * H * ops.DP, C), mode)
-    qk, vt = ops.qkv_gemm(x, ops.pad_rows(w), bp.view(-1).cuda(), B, S, H)
+    q, kt, vt = ops.qkv_gemm(x, ops.pad_rows(w), bp.view(-1).cuda(), B, S, H)
     full = (x_ref @ w_ref.t() + bp.view(-1)).view(B, S, 3, H, ops.DP)
-    check(qk, full[:, :, :2], mode, True)
+    check(q.view(B, S, H, ops.DP), full[:, :, 0], mode, True)
     check(vt, full[:, :, 2].permute(0, 2, 3, 1), mode, True)
+    k_expect = ops.k_tile_order(full[:, :, 1].contiguous().to(ops.torch_dtype(mode))).float()
+    check(kt, k_expect, mode, True)
     # attention on the values the kernel actually produced (rounded to T)
-    qk_ref, vt_ref = qk.float().cpu(), vt.float().cpu()
-    q = qk_ref[:, :, 0].permute(0, 2, 1, 3)  # B H S 96
-    k = qk_ref[:, :, 1].permute(0, 2, 1, 3)
-    v = vt_ref.permute(0, 1, 3, 2)  # B H S 96
-    attn = torch.softmax((q * Dh ** -0.5) @ k.transpose(-2, -1), dim=-1)
-    ref = (attn @ v)[..., :Dh].transpose(1, 2).reshape(B * S, C)
-    out = ops.attention(qk, vt, Dh)
+    q_ref = q.float().cpu().view(B, S, H, ops.DP).permute(0, 2, 1, 3)  # B H S 96
+    k_ref = full[:, :, 1].to(ops.torch_dtype(mode)).float().permute(0, 2, 1, 3)
+    v_ref = vt.float().cpu().permute(0, 1, 3, 2)  # B H S 96
+    attn = torch.softmax((q_ref * Dh ** -0.5) @ k_ref.transpose(-2, -1), dim=-1)
+    ref = (attn @ v_ref)[..., :Dh].transpose(1, 2).reshape(B * S, C)
+    out = ops.attention(q, kt, vt, Dh)
     check(out, ref, mode, True)
+
+
+def _attn_inputs(q4, k4, v4, mode):
+    """q4,k4,v4: [B,S,H,96] float -> device tensors in the kernel layouts + fp32 views of the rounded values."""
+    td = ops.torch_dtype(mode)
+    B, S, H, dp = q4.shape
+    qT, kT, vT = q4.to(td), k4.to(td), v4.to(td)
+    q = qT.reshape(B * S, H * dp).cuda()
+    kt = ops.k_tile_order(kT.cuda())
+    vt = vT.permute(0, 2, 3, 1).contiguous().cuda()
+    return q, kt, vt, qT.float(), kT.float(), vT.float()
 
 
 @pytest.mark.parametrize("mode", MODES)
 def test_attention_peaked_softmax(dev, mode):
-    """Force large running-max jumps across KV tiles (online-softmax rescale path)."""
+    """Force large running-max jumps across KV tiles (online-softmax rescale path and its wave-uniform skip)."""
     B, S, H, Dh = 1, 512, 2, 88
     g = torch.Generator().manual_seed(5)
-    qk = torch.randn(B, S, 2, H, ops.DP, generator=g)
-    qk[..., Dh:] = 0
-    # spike: a few keys late in the sequence dominate some queries
-    qk[0, 300:310, 1] *= 6.0
-    qk[0, 17, 0] *= 8.0
-    vt = torch.randn(B, H, ops.DP, S, generator=g)
-    qkT, qk_ref = as_mode(qk, mode)
-    vtT, vt_ref = as_mode(vt, mode)
-    q = qk_ref[:, :, 0].permute(0, 2, 1, 3)
-    k = qk_ref[:, :, 1].permute(0, 2, 1, 3)
-    v = vt_ref.permute(0, 1, 3, 2)
-    attn = torch.softmax((q.double() * Dh ** -0.5) @ k.double().transpose(-2, -1), dim=-1)
-    ref = (attn @ v.double())[..., :Dh].transpose(1, 2).reshape(B * S, H * Dh).float()
-    out = ops.attention(qkT, vtT, Dh)
+    q4 = torch.randn(B, S, H, ops.DP, generator=g)
+    k4 = torch.randn(B, S, H, ops.DP, generator=g)
+    v4 = torch.randn(B, S, H, ops.DP, generator=g)
+    for t in (q4, k4, v4):
+        t[..., Dh:] = 0
+    k4[0, 300:310] *= 6.0  # a few keys late in the sequence dominate
+    q4[0, 17] *= 8.0
+    k4[0, :64] *= 0.01     # first block nearly flat: later blocks all raise the max
+    q, kt, vt, qf, kf, vf = _attn_inputs(q4, k4, v4, mode)
+    qh, kh, vh = (t.permute(0, 2, 1, 3).double() for t in (qf, kf, vf))
+    attn = torch.softmax((qh * Dh ** -0.5) @ kh.transpose(-2, -1), dim=-1)
+    ref = (attn @ vh)[..., :Dh].transpose(1, 2).reshape(B * S, H * Dh).float()
+    out = ops.attention(q, kt, vt, Dh)
     check(out, ref, mode, True)
 
 

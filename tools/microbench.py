@@ -34,10 +34,12 @@ def main():
             t = timeit(lambda: ops.gemm(a, w, N, bias=bias, out=out))
             print(f"  gemm {name:5s} M={M} N={N} K={K}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s")
         H, Dh, S = 16, 88, 2048
-        qk = torch.randn(B, S, 2, H, 96, device="cuda").to(td)
-        qk[..., Dh:] = 0
+        q = torch.randn(B * S, H, 96, device="cuda")
+        q[..., Dh:] = 0
+        q = q.reshape(B * S, H * 96).to(td)
+        kt = torch.randn(B * S * H * 96, device="cuda").to(td)
         vt = torch.randn(B, H, 96, S, device="cuda").to(td)
-        t = timeit(lambda: ops.attention(qk, vt, Dh))
+        t = timeit(lambda: ops.attention(q, kt, vt, Dh))
         fl = 4 * S * S * Dh * H * B
         print(f"  attention B={B} S={S} H={H} d={Dh}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s useful ({fl*96/88/t/1e12:.1f} raw)")
         # conv3d shapes of the DPT head
