@@ -159,6 +159,30 @@ int l4p_rays_to_pose(l4p_stream stream, const float* rays, const float* K, float
                      int H, int W);
 
 /* ------------------------------------------------------------------------------------------------
+ * Joint depth + camera seam alignment (KabaschUmeyama3DAligner, aligner.py:121-265;
+ * generate_point_map, geometry_utils.py:13-53).  The reference runs numpy + skimage.measure.ransac on
+ * the CPU (randomised, unpinned): these are deterministic GPU restatements of the same estimator,
+ * validated against synthetic ground truth ("parity unpinned").
+ * ---------------------------------------------------------------------------------------------- */
+
+/* approximate q-quantile of n non-negative floats (4096-bin histogram over [min,max]); ws >= 4098 uints */
+int l4p_quantile(l4p_stream stream, const float* x, long long n, float q, unsigned* ws, float* out);
+
+/* world-space points of a hashed 1/ratio pixel subset of F frames: depth [F][H*W], K and P (world_T_cam)
+ * [F][16] row-major 4x4  ->  out [F*(H*W/ratio)][3] */
+int l4p_point_map_samples(l4p_stream stream, const float* depth, const float* K, const float* P, float* out, int F,
+                          int H, int W, int ratio, unsigned seed);
+
+/* RANSAC similarity dst ~ s R src + t over n correspondences (min_samples per trial, inlier threshold
+ * q98[0]*thr_rel, best model re-estimated on its inliers as skimage does).  ws: float[15*trials].
+ * out: float[18] = row-major 4x4 [sR|t;0 0 0 1], s, inlier count. */
+int l4p_similarity_ransac(l4p_stream stream, const float* src, const float* dst, int n, const float* q98,
+                          float thr_rel, int trials, int min_samples, unsigned seed, float* ws, float* out);
+
+/* aligner.apply (aligner.py:239-265): pose [16][T] <- T pose with the 3x3 block / s ; depth[n] *= s */
+int l4p_similarity_apply(l4p_stream stream, const float* sim, float* pose, int T, float* depth, long long n);
+
+/* ------------------------------------------------------------------------------------------------
  * SAM-style point tracker (sparse_heads.py, sam/{prompt_encoder,transformer,mask_decoder}.py).
  * The projections of the two-way transformer run through l4p_gemm; these are the remaining pieces.
  * ---------------------------------------------------------------------------------------------- */

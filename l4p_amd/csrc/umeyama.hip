@@ -1,0 +1,396 @@
+// Joint depth + camera seam alignment on the GPU (reference aligner.py:121-265, geometry_utils.py:13-53):
+// overlap depth/pose pairs -> sampled world-space point maps -> RANSAC similarity (Umeyama) -> apply.
+// The reference does this on the CPU with numpy + skimage.measure.ransac (randomised, unpinned version);
+// this is a deterministic counter-based-RNG re-statement of the same estimator, validated against synthetic
+// ground truth (tests/test_umeyama_gpu.py), not against the reference ("parity unpinned").
+#include "common.hpp"
+
+__device__ __forceinline__ unsigned hash_u32(unsigned x) {  // PCG-style integer hash (counter-based RNG)
+    x = x * 747796405u + 2891336453u;
+    const unsigned w = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+
+// -------------------------------------------------------------------------------------------------
+// q-quantile of a positive float array via a 4096-bin histogram over [min, max] (threshold scale only).
+// ws: uint[2] (min/max as ordered uints) + uint[4096] bins.  out[0] = approx quantile.
+// -------------------------------------------------------------------------------------------------
+__global__ void minmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ ws) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        mn = fminf(mn, x[i]);
+        mx = fmaxf(mx, x[i]);
+    }
+    mn = -wave_max(-mn);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) {  // values are >= 0 (depth = exp(.)): the uint order equals the float order
+        atomicMin(&ws[0], __float_as_uint(fmaxf(mn, 0.f)));
+        atomicMax(&ws[1], __float_as_uint(fmaxf(mx, 0.f)));
+    }
+}
+__global__ void hist_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ ws) {
+    const float mn = __uint_as_float(ws[0]), mx = __uint_as_float(ws[1]);
+    const float sc = mx > mn ? 4096.f / (mx - mn) : 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int b = (int)((x[i] - mn) * sc);
+        b = b < 0 ? 0 : (b > 4095 ? 4095 : b);
+        atomicAdd(&ws[2 + b], 1u);
+    }
+}
+__global__ void quantile_pick_kernel(const unsigned* __restrict__ ws, long long n, float q, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const float mn = __uint_as_float(ws[0]), mx = __uint_as_float(ws[1]);
+    const double target = q * (double)(n - 1);
+    double acc = 0;
+    int b = 0;
+    for (; b < 4096; ++b) {
+        if (acc + ws[2 + b] > target) break;
+        acc += ws[2 + b];
+    }
+    if (b > 4095) b = 4095;
+    const double frac = ws[2 + b] ? (target - acc) / (double)ws[2 + b] : 0.0;
+    out[0] = mn + (float)((b + frac) * (double)(mx - mn) / 4096.0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Sampled point maps (generate_point_map geometry_utils.py:13-53 on the frames ::step of the overlap):
+// X = world_T_cam * [depth * K^-1 [x, y, 1]; 1].  One sample per thread; pixel chosen by a hash inside
+// each stride-`ratio` cell (the reference takes a random 10 % permutation subset, aligner.py:214-220).
+// depth: [F][H*W]; K, P: [F][16] row-major 4x4 (pixel intrinsics / world_T_cam); out: [F*spf][3].
+// -------------------------------------------------------------------------------------------------
+__global__ void pointmap_kernel(const float* __restrict__ depth, const float* __restrict__ K, const float* __restrict__ P,
+                                float* __restrict__ out, int F, int H, int W, int ratio, unsigned seed, int spf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * spf) return;
+    const int f = i / spf, j = i % spf;
+    int pix = j * ratio + (int)(hash_u32(seed ^ (unsigned)j * 2654435761u) % (unsigned)ratio);
+    if (pix >= H * W) pix = H * W - 1;
+    const float x = (float)(pix % W), y = (float)(pix / W);
+    const float* k = K + f * 16;
+    // inverse of the upper-left 3x3 (general, as torch.inverse does)
+    const float a = k[0], b = k[1], c = k[2], d = k[4], e = k[5], g = k[6], h = k[8], l = k[9], m = k[10];
+    const float det = a * (e * m - g * l) - b * (d * m - g * h) + c * (d * l - e * h);
+    const float id = 1.f / det;
+    const float i00 = (e * m - g * l) * id, i01 = (c * l - b * m) * id, i02 = (b * g - c * e) * id;
+    const float i10 = (g * h - d * m) * id, i11 = (a * m - c * h) * id, i12 = (c * d - a * g) * id;
+    const float i20 = (d * l - e * h) * id, i21 = (b * h - a * l) * id, i22 = (a * e - b * d) * id;
+    const float z = depth[(long long)f * H * W + pix];
+    const float cx = (i00 * x + i01 * y + i02) * z, cy = (i10 * x + i11 * y + i12) * z, cz = (i20 * x + i21 * y + i22) * z;
+    const float* p = P + f * 16;
+    out[i * 3 + 0] = p[0] * cx + p[1] * cy + p[2] * cz + p[3];
+    out[i * 3 + 1] = p[4] * cx + p[5] * cy + p[6] * cz + p[7];
+    out[i * 3 + 2] = p[8] * cx + p[9] * cy + p[10] * cz + p[11];
+}
+
+// -------------------------------------------------------------------------------------------------
+// Umeyama similarity from accumulated moments (skimage.transform._geometric._umeyama):
+// dst ~ s R src + t.  sums: n, mean_s[3], mean_d[3], cov[3][3] = E[(d-md)(s-ms)^T], var_s.
+// -------------------------------------------------------------------------------------------------
+__device__ void jacobi3(double A[3][3], double V[3][3]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        if (fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]) < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double x = A[k][p], y = A[k][q];
+                    A[k][p] = c * x - s * y;
+                    A[k][q] = s * x + c * y;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double x = A[p][k], y = A[q][k];
+                    A[p][k] = c * x - s * y;
+                    A[q][k] = s * x + c * y;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double x = V[k][p], y = V[k][q];
+                    V[k][p] = c * x - s * y;
+                    V[k][q] = s * x + c * y;
+                }
+            }
+    }
+}
+
+// model: [0..8] = s*R row-major, [9..11] = t, [12] = s
+__device__ void umeyama_from_moments(const double ms[3], const double md[3], const double cov[3][3], double var_s,
+                                     float* model) {
+    double AtA[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) AtA[i][j] = cov[0][i] * cov[0][j] + cov[1][i] * cov[1][j] + cov[2][i] * cov[2][j];
+    jacobi3(AtA, V);
+    int o[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (AtA[o[b]][o[b]] > AtA[o[a]][o[a]]) {
+                const int t = o[a];
+                o[a] = o[b];
+                o[b] = t;
+            }
+    double v1[3], v2[3], v3[3], u1[3], u2[3], u3[3];
+    for (int i = 0; i < 3; ++i) {
+        v1[i] = V[i][o[0]];
+        v2[i] = V[i][o[1]];
+    }
+    v3[0] = v1[1] * v2[2] - v1[2] * v2[1];
+    v3[1] = v1[2] * v2[0] - v1[0] * v2[2];
+    v3[2] = v1[0] * v2[1] - v1[1] * v2[0];
+    for (int i = 0; i < 3; ++i) {
+        u1[i] = cov[i][0] * v1[0] + cov[i][1] * v1[1] + cov[i][2] * v1[2];
+        u2[i] = cov[i][0] * v2[0] + cov[i][1] * v2[1] + cov[i][2] * v2[2];
+    }
+    const double s1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    for (int i = 0; i < 3; ++i) u1[i] /= fmax(s1, 1e-300);
+    const double dp = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+    for (int i = 0; i < 3; ++i) u2[i] -= dp * u1[i];
+    const double s2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    for (int i = 0; i < 3; ++i) u2[i] /= fmax(s2, 1e-300);
+    u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
+    u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
+    u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+    // sigma3 with the reflection sign folded in: u3^T cov v3 (negative when det(cov) < 0)
+    double s3 = 0;
+    for (int i = 0; i < 3; ++i) s3 += u3[i] * (cov[i][0] * v3[0] + cov[i][1] * v3[1] + cov[i][2] * v3[2]);
+    const double scale = var_s > 0 ? (s1 + s2 + s3) / var_s : 1.0;
+    double R[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[i][j] = u1[i] * v1[j] + u2[i] * v2[j] + u3[i] * v3[j];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) model[i * 3 + j] = (float)(scale * R[i][j]);
+        model[9 + i] = (float)(md[i] - scale * (R[i][0] * ms[0] + R[i][1] * ms[1] + R[i][2] * ms[2]));
+    }
+    model[12] = (float)scale;
+}
+
+__device__ __forceinline__ float residual(const float* m, const float* s, const float* d) {
+    const float rx = m[0] * s[0] + m[1] * s[1] + m[2] * s[2] + m[9] - d[0];
+    const float ry = m[3] * s[0] + m[4] * s[1] + m[5] * s[2] + m[10] - d[1];
+    const float rz = m[6] * s[0] + m[7] * s[1] + m[8] * s[2] + m[11] - d[2];
+    return sqrtf(rx * rx + ry * ry + rz * rz);
+}
+
+// One workgroup per RANSAC trial: minimal-sample model, then inlier count + residual sum over all points.
+// scores: [trials][2] (inliers as float, residual sum), models: [trials][13]
+__global__ __launch_bounds__(256) void ransac_trials_kernel(const float* __restrict__ src, const float* __restrict__ dst,
+                                                            int n, const float* __restrict__ q98, float thr_rel,
+                                                            int min_samples, unsigned seed, float* __restrict__ scores,
+                                                            float* __restrict__ models) {
+    __shared__ float model[13];
+    __shared__ float red[4][2];
+    const int trial = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double ms[3] = {0, 0, 0}, md[3] = {0, 0, 0}, cov[3][3] = {{0}}, var = 0;
+        int idx[32];
+        for (int j = 0; j < min_samples; ++j) idx[j] = (int)(hash_u32(seed + 7919u * trial + 104729u * j) % (unsigned)n);
+        for (int j = 0; j < min_samples; ++j)
+            for (int k = 0; k < 3; ++k) {
+                ms[k] += src[idx[j] * 3 + k];
+                md[k] += dst[idx[j] * 3 + k];
+            }
+        for (int k = 0; k < 3; ++k) {
+            ms[k] /= min_samples;
+            md[k] /= min_samples;
+        }
+        for (int j = 0; j < min_samples; ++j) {
+            double ds[3], dd[3];
+            for (int k = 0; k < 3; ++k) {
+                ds[k] = src[idx[j] * 3 + k] - ms[k];
+                dd[k] = dst[idx[j] * 3 + k] - md[k];
+                var += ds[k] * ds[k];
+            }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) cov[a][b] += dd[a] * ds[b];
+        }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) cov[a][b] /= min_samples;
+        var /= min_samples;
+        umeyama_from_moments(ms, md, cov, var, model);
+    }
+    __syncthreads();
+    const float thr = q98[0] * thr_rel;
+    float cnt = 0.f, rs = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float r = residual(model, src + i * 3, dst + i * 3);
+        if (r < thr) {
+            cnt += 1.f;
+            rs += r;
+        }
+    }
+    cnt = wave_sum(cnt);
+    rs = wave_sum(rs);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6][0] = cnt;
+        red[threadIdx.x >> 6][1] = rs;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scores[trial * 2 + 0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        scores[trial * 2 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        for (int k = 0; k < 13; ++k) models[trial * 13 + k] = model[k];
+    }
+}
+
+// Best trial (most inliers, ties -> smaller residual sum, as skimage), then re-estimate on its inliers.
+// out: [16] row-major 4x4 similarity T = [sR | t; 0 0 0 1], out[16] = s, out[17] = inlier count
+__global__ __launch_bounds__(256) void ransac_final_kernel(const float* __restrict__ src, const float* __restrict__ dst, int n,
+                                                           const float* __restrict__ q98, float thr_rel, int trials,
+                                                           const float* __restrict__ scores, const float* __restrict__ models,
+                                                           float* __restrict__ out) {
+    __shared__ float model[13];
+    __shared__ double red[4][16];
+    __shared__ double mom[16];
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int t = 1; t < trials; ++t)
+            if (scores[t * 2] > scores[best * 2] || (scores[t * 2] == scores[best * 2] && scores[t * 2 + 1] < scores[best * 2 + 1]))
+                best = t;
+        for (int k = 0; k < 13; ++k) model[k] = models[best * 13 + k];
+    }
+    __syncthreads();
+    const float thr = q98[0] * thr_rel;
+    // pass 1: count + means over the inliers
+    double v[16];
+    for (int k = 0; k < 16; ++k) v[k] = 0;
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (residual(model, src + i * 3, dst + i * 3) < thr) {
+            v[0] += 1;
+            for (int k = 0; k < 3; ++k) {
+                v[1 + k] += src[i * 3 + k];
+                v[4 + k] += dst[i * 3 + k];
+            }
+        }
+    for (int k = 0; k < 7; ++k)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 7; ++k) mom[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    __syncthreads();
+    const double cntd = mom[0] > 0 ? mom[0] : 1.0;
+    const double ms[3] = {mom[1] / cntd, mom[2] / cntd, mom[3] / cntd}, md[3] = {mom[4] / cntd, mom[5] / cntd, mom[6] / cntd};
+    // pass 2: covariance + source variance
+    for (int k = 0; k < 16; ++k) v[k] = 0;
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (residual(model, src + i * 3, dst + i * 3) < thr) {
+            double ds[3], dd[3];
+            for (int k = 0; k < 3; ++k) {
+                ds[k] = src[i * 3 + k] - ms[k];
+                dd[k] = dst[i * 3 + k] - md[k];
+                v[9] += ds[k] * ds[k];
+            }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) v[a * 3 + b] += dd[a] * ds[b];
+        }
+    for (int k = 0; k < 10; ++k)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 10; ++k) red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double cov[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) cov[a][b] = (red[0][a * 3 + b] + red[1][a * 3 + b] + red[2][a * 3 + b] + red[3][a * 3 + b]) / cntd;
+        const double var = (red[0][9] + red[1][9] + red[2][9] + red[3][9]) / cntd;
+        float fin[13];
+        if (mom[0] >= 3)
+            umeyama_from_moments(ms, md, cov, var, fin);
+        else
+            for (int k = 0; k < 13; ++k) fin[k] = model[k];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) out[i * 4 + j] = fin[i * 3 + j];
+            out[i * 4 + 3] = fin[9 + i];
+        }
+        out[12] = out[13] = out[14] = 0.f;
+        out[15] = 1.f;
+        out[16] = fin[12];
+        out[17] = (float)mom[0];
+    }
+}
+
+// apply (aligner.py:239-265): pose <- T pose, rotation block / s ; pose: [16][T] row-major 4x4 per frame
+__global__ void similarity_apply_pose_kernel(const float* __restrict__ sim, float* __restrict__ pose, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float P[16], R[16];
+    for (int k = 0; k < 16; ++k) P[k] = pose[(long long)k * T + t];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+            for (int k = 0; k < 4; ++k) a += sim[i * 4 + k] * P[k * 4 + j];
+            R[i * 4 + j] = a;
+        }
+    const float is = 1.f / sim[16];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[i * 4 + j] *= is;
+    for (int k = 0; k < 16; ++k) pose[(long long)k * T + t] = R[k];
+}
+
+__global__ void scale_by_device_scalar_kernel(float* __restrict__ x, long long n, const float* __restrict__ s) {
+    const float v = s[0];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= v;
+}
+
+extern "C" {
+
+/* approx. q-quantile of n non-negative floats (4096-bin histogram). ws: >= 4098 uints. */
+int l4p_quantile(l4p_stream s_, const float* x, long long n, float q, unsigned* ws, float* out) {
+    hipStream_t s = (hipStream_t)s_;
+    ProfScope prof(PROF_ELEMENTWISE, s);
+    HIP_TRY(hipMemsetAsync(ws, 0xFF, 4, s));
+    HIP_TRY(hipMemsetAsync(ws + 1, 0, 4097 * 4, s));
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL(hist_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL(quantile_pick_kernel, dim3(1), dim3(64), 0, s, ws, n, q, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int l4p_point_map_samples(l4p_stream s_, const float* depth, const float* K, const float* P, float* out, int F, int H, int W,
+                          int ratio, unsigned seed) {
+    hipStream_t s = (hipStream_t)s_;
+    const int spf = (H * W) / ratio;
+    ProfScope prof(PROF_ELEMENTWISE, s);
+    hipLaunchKernelGGL(pointmap_kernel, dim3((F * spf + 255) / 256), dim3(256), 0, s, depth, K, P, out, F, H, W, ratio, seed, spf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* RANSAC similarity dst ~ s R src + t over n correspondences.  thr = q98[0] * thr_rel.
+ * ws: float[trials * 15].  out: float[18] = 4x4 T (row-major), s, inlier count. */
+int l4p_similarity_ransac(l4p_stream s_, const float* src, const float* dst, int n, const float* q98, float thr_rel,
+                          int trials, int min_samples, unsigned seed, float* ws, float* out) {
+    hipStream_t s = (hipStream_t)s_;
+    if (n < min_samples || min_samples < 3 || min_samples > 32 || trials < 1) {
+        l4p_set_error("similarity_ransac: bad arguments n=%d min_samples=%d trials=%d", n, min_samples, trials);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_ELEMENTWISE, s);
+    float* scores = ws;
+    float* models = ws + 2 * trials;
+    hipLaunchKernelGGL(ransac_trials_kernel, dim3(trials), dim3(256), 0, s, src, dst, n, q98, thr_rel, min_samples, seed, scores,
+                       models);
+    hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(256), 0, s, src, dst, n, q98, thr_rel, trials, scores, models, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* apply: pose [16][T] <- T pose with the rotation block divided by s; depth (n floats) *= s */
+int l4p_similarity_apply(l4p_stream s_, const float* sim, float* pose, int T, float* depth, long long n) {
+    hipStream_t s = (hipStream_t)s_;
+    ProfScope prof(PROF_ELEMENTWISE, s);
+    hipLaunchKernelGGL(similarity_apply_pose_kernel, dim3((T + 63) / 64), dim3(64), 0, s, sim, pose, T);
+    if (depth && n > 0) {
+        const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(grid), dim3(256), 0, s, depth, n, sim + 16);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+}
