@@ -158,6 +158,15 @@ int l4p_affine_align_apply(l4p_stream stream, const float* x, float* y, long lon
 int l4p_rays_to_pose(l4p_stream stream, const float* rays, const float* K, float* out, int B, int T, int h, int w,
                      int H, int W);
 
+/* Intrinsics from the ray map of frame t0 (compute_optimal_rotation_intrinsics, geometry_utils.py:409-456, as
+ * used by rays_to_cameras_and_fixed_per_frame_intrinsics :493-579): homography pixel -> direction by
+ * normalised DLT re-estimated on its consensus set (reprojection error < reproj_thr), H^-1 = K R, RQ.
+ * Deterministic replacement of cv2.findHomography(RANSAC)+cv2.RQDecomp3x3 ("parity unpinned").
+ * rays float [B][6][T][h][w], out_K float [B][4][4][T] (pixel units of the H x W image, same K for all
+ * frames), diag optional float [B][2] = (consensus size, iterations). */
+int l4p_rays_to_intrinsics(l4p_stream stream, const float* rays, float* out_K, float* diag, int B, int T, int h, int w,
+                           int H, int W, int t0, float reproj_thr);
+
 /* ------------------------------------------------------------------------------------------------
  * Joint depth + camera seam alignment (KabaschUmeyama3DAligner, aligner.py:121-265;
  * generate_point_map, geometry_utils.py:13-53).  The reference runs numpy + skimage.measure.ransac on

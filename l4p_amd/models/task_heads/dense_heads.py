@@ -211,20 +211,33 @@ class VideoMAETraj3DDPTHead(VideoMAEFlowDPTHead):
 
     def forward(self, enc_features_bpc_list, img_info=(16, 224, 224), intrinsics_b44t: Optional[torch.Tensor] = None,
                 **kwargs) -> Dict[str, torch.Tensor]:
-        from ...utils.geometry_utils import poses_from_rays
+        from ...utils.geometry_utils import intrinsics_from_rays, poses_from_rays
 
         T, H, W = img_info
         rays = self._decode(enc_features_bpc_list, img_info)  # float [B,6,16,16,16]
-        if not self.use_intrinsics:
-            raise NotImplementedError(
-                "use_intrinsics=False needs intrinsics estimation from the ray map; the reference does it with "
-                "cv2.findHomography(RANSAC)+RQDecomp3x3 (geometry_utils.py:409-456) whose results are unpinned. "
-                "Set model.l4p_model.task_heads['camray'].use_intrinsics = True (as demo.py:215 does)."
-            )
-        if intrinsics_b44t is None:
-            raise ValueError("intrinsics_b44t is required when use_intrinsics=True")
-        pose_b16t = poses_from_rays(rays, intrinsics_b44t.to(rays.device, torch.float32), H, W)
-        return {f"{self.task_name}_est_{self.task_suffix}": pose_b16t}
+        key = f"{self.task_name}_est_{self.task_suffix}"
+        if self.use_intrinsics:
+            if intrinsics_b44t is None:
+                raise ValueError("intrinsics_b44t is required when use_intrinsics=True")
+            return {key: poses_from_rays(rays, intrinsics_b44t.to(rays.device, torch.float32), H, W)}
+        if not self.fixed_intrinsics:
+            raise NotImplementedError("per-frame variable intrinsics (fixed_intrinsics=False) are not used by configs/model.yaml")
+        # fixed intrinsics, estimated once on the first window (dense_heads.py:303-334)
+        assert "win_id" in kwargs, "win_id is required when setting fixed intrinsics as True"
+        if kwargs["win_id"] == 0:
+            self.first_window_intrinsics_b44t = None
+        if self.first_window_intrinsics_b44t is None:
+            K_est = intrinsics_from_rays(rays, H, W, reproj_threshold=0.2)  # [B,4,4,T], first frame, pixel units
+            pose = poses_from_rays(rays, K_est, H, W)
+            self.first_window_intrinsics_b44t = K_est.clone()
+        else:
+            # as the reference: later windows rotate with the INPUT intrinsics (dense_heads.py:327-333) and report the
+            # first window's estimate
+            if intrinsics_b44t is None:
+                raise ValueError("intrinsics_b44t is required for windows after the first one")
+            pose = poses_from_rays(rays, intrinsics_b44t.to(rays.device, torch.float32), H, W)
+            K_est = self.first_window_intrinsics_b44t.clone()
+        return {key: pose, f"{self.task_name}_intrinsics_est_{self.task_suffix}": K_est.reshape(K_est.shape[0], 16, T)}
 
 
 def joint_windowed_estimation(task_names: List[str], task_heads: torch.nn.ModuleDict, enc_features_bpc_2dlist,

@@ -27,3 +27,15 @@ def poses_from_rays(rays_b6thw: torch.Tensor, intrinsics_b44t: torch.Tensor, H: 
     out = torch.empty(B, 16, T, dtype=torch.float32, device=rays.device)
     _lib.check(_lib.load().l4p_rays_to_pose(_stream(), _p(rays), _p(K), _p(out), B, T, h, w, H, W), "l4p_rays_to_pose")
     return out
+
+
+def intrinsics_from_rays(rays_b6thw: torch.Tensor, H: int, W: int, reproj_threshold: float = 0.2, frame: int = 0) -> torch.Tensor:
+    """Fixed intrinsics from the first frame's ray map (rays_to_cameras_and_fixed_per_frame_intrinsics,
+    geometry_utils.py:493-579, K part): float [B,6,T,h,w] -> float [B,4,4,T] in pixel units of the H x W image."""
+    assert rays_b6thw.is_cuda and rays_b6thw.dtype == torch.float32
+    B, six, T, h, w = rays_b6thw.shape
+    rays = rays_b6thw.contiguous()
+    K = torch.empty(B, 4, 4, T, dtype=torch.float32, device=rays.device)
+    _lib.check(_lib.load().l4p_rays_to_intrinsics(_stream(), _p(rays), _p(K), None, B, T, h, w, H, W, frame, reproj_threshold),
+               "l4p_rays_to_intrinsics")
+    return K

@@ -1,0 +1,73 @@
+"""GPU: intrinsics + pose from a Pluecker ray map with UNKNOWN intrinsics (row a10, use_intrinsics=False).
+The reference step is cv2.findHomography(RANSAC)+RQDecomp3x3 (randomised, unpinned) => validated against
+SYNTHETIC GROUND TRUTH: ray maps rendered from known (K, R, c) with 10 % corrupted rays must give back K
+(1e-3 relative) and the camera poses."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from l4p_amd.utils.geometry_utils import intrinsics_from_rays, poses_from_rays
+from tests.test_umeyama_gpu import _rot
+
+
+def render_rays(K_pix, c2w_b44t, H, W, h=16, w=16):
+    """get_rays_plucker semantics (geometry_utils.py:165-241): direction = R_c2w * normalize(Kgrid^-1 [i,j,1]),
+    moment = origin x direction, on the h x w grid (intrinsics rescaled from the H x W image)."""
+    T = c2w_b44t.shape[-1]
+    Kg = K_pix.clone().double()
+    Kg[0, 2] += 0.5
+    Kg[1, 2] += 0.5
+    Kg[0] = Kg[0] / W * w
+    Kg[1] = Kg[1] / H * h
+    Kg[0, 2] -= 0.5
+    Kg[1, 2] -= 0.5
+    j, i = torch.meshgrid(torch.arange(h, dtype=torch.float64), torch.arange(w, dtype=torch.float64), indexing="ij")
+    pix = torch.stack([i, j, torch.ones_like(i)], -1).reshape(-1, 3)
+    d_cam = (torch.linalg.inv(Kg[:3, :3]) @ pix.T).T
+    d_cam = d_cam / d_cam.norm(dim=-1, keepdim=True)
+    rays = torch.zeros(1, 6, T, h, w, dtype=torch.float64)
+    for t in range(T):
+        R, o = c2w_b44t[:3, :3, t].double(), c2w_b44t[:3, 3, t].double()
+        d = (R @ d_cam.T).T
+        m = torch.cross(o.expand_as(d), d, dim=-1)
+        rays[0, :3, t] = d.T.reshape(3, h, w)
+        rays[0, 3:, t] = m.T.reshape(3, h, w)
+    return rays.float()
+
+
+def test_intrinsics_and_pose_recovered(dev):
+    H = W = 224
+    T = 16
+    K = torch.eye(4)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = 301.0, 287.0, 118.0, 97.0
+    c2w = torch.eye(4)[:, :, None].repeat(1, 1, T).clone()
+    for t in range(1, T):  # frame 0 is the reference camera (identity), as make_first_cam_ref does
+        c2w[:3, :3, t] = _rot(0.03 * t, -0.02 * t, 0.015 * t)
+        c2w[:3, 3, t] = torch.tensor([0.05 * t, 0.02 * t, -0.03 * t])
+    rays = render_rays(K, c2w, H, W)
+    truth = [((0, 0), 301.0), ((1, 1), 287.0), ((0, 2), 118.0), ((1, 2), 97.0)]
+
+    def check_K(K_est, tol):
+        k = K_est[0, :, :, 0].cpu()
+        for (a, b) in truth:
+            assert abs(float(k[a]) - b) <= tol * 301.0, (a, float(k[a]))
+        assert abs(float(k[0, 1])) <= 300 * tol and float(k[2, 2]) == 1.0 and float(k[3, 3]) == 1.0
+        assert torch.equal(K_est[0, :, :, 0], K_est[0, :, :, T - 1])  # fixed over the window
+
+    # (1) clean ray map, reference threshold 0.2: exact recovery
+    check_K(intrinsics_from_rays(rays.cuda(), H, W, reproj_threshold=0.2), 1e-3)
+    # (2) 10 % grossly corrupted rays: the consensus estimator recovers K when the inlier threshold separates them
+    g = torch.Generator().manual_seed(1)
+    bad = torch.rand(1, 1, T, 16, 16, generator=g) < 0.1
+    noisy = torch.where(bad.expand_as(rays), rays + 4.0 * torch.randn(rays.shape, generator=g), rays)
+    check_K(intrinsics_from_rays(noisy.cuda(), H, W, reproj_threshold=0.01), 1e-3)
+    # (3) same data at the reference's threshold (0.2 is half the normalised image: random rays that land inside it
+    #     are counted as inliers, by cv2 as well) — bounded bias only
+    check_K(intrinsics_from_rays(noisy.cuda(), H, W, reproj_threshold=0.2), 2e-2)
+    # poses from clean rays + the estimated K
+    K_est = intrinsics_from_rays(rays.cuda(), H, W)
+    pose = poses_from_rays(rays.cuda(), K_est, H, W).cpu().view(1, 4, 4, T)
+    assert (pose[0] - c2w).abs().max() <= 2e-3
