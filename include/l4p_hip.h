@@ -107,6 +107,11 @@ typedef struct l4p_gemm_desc {
     void* out_relu_T;
     /* L4P_EPI_QKV: K destination in the attention kernel's tile order (see l4p_attention) */
     void* k_tiled;
+    /* split-K (L4P_EPI_DENSE only; for problems with too few output tiles to fill 256 CUs, e.g. the low-resolution
+     * DPT convs with K = 27*1024): splitk > 1 slices contract disjoint k ranges into partial[splitk][M][N] (float,
+     * caller-provided), a second kernel sums them and applies the epilogue. */
+    int splitk;
+    float* partial;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);

@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         ("c_gr", C.c_int), ("c_gs", C.c_int), ("c_go", C.c_int),
         ("out_relu_T", C.c_void_p),
         ("k_tiled", C.c_void_p),
+        ("splitk", C.c_int), ("partial", C.c_void_p),
     ]
 
 

@@ -9,5 +9,12 @@ int launch_gemm(int dtype, int mode, const GemmParams& p, hipStream_t stream) {
     if ((p.K * es) % 16 || (p.ldw * es) % 16) { l4p_set_error("gemm: K/ldw not 16-byte aligned"); return L4P_E_INVALID; }
     if (mode == 0 && (p.lda * es) % 16) { l4p_set_error("gemm: lda not 16-byte aligned"); return L4P_E_INVALID; }
     if (mode == 1 && (p.Cin % (128 / es) || p.K != 27 * p.Cin)) { l4p_set_error("conv3d: Cin=%d must be a multiple of %d and K=27*Cin", p.Cin, 128 / es); return L4P_E_INVALID; }
+    if (p.splitk > 1) {
+        const int bk = 128 / es, nk = (p.K + bk - 1) / bk;
+        if (p.epi != L4P_EPI_DENSE || !p.partial || p.splitk > nk || p.c_gr > 0) {
+            l4p_set_error("gemm: split-K needs the dense epilogue, a partial buffer and splitk <= %d k-tiles", nk);
+            return L4P_E_INVALID;
+        }
+    }
     return dtype == L4P_BF16 ? launch_gemm_bf16(mode, p, stream) : launch_gemm_f32(mode, p, stream);
 }

@@ -52,7 +52,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = (p.N + BN - 1) / BN;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
+    const int ntiles = ntn * ((p.M + BM - 1) / BM);
+    const int ksplit = blockIdx.x / ntiles, tile = blockIdx.x - ksplit * ntiles;  // split-K slice of this workgroup
+    const int mt = tile / ntn, nt = tile % ntn;
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int crow = tid >> 3, cc = tid & 7;  // this thread's (row, LDS slot) inside a staging pass
@@ -209,17 +211,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) wrow[j] = wn * (TN * 16) + 4 * TN * (li >> 2) + 4 * j + (li & 3);
 
+    // split-K: this workgroup contracts k-tiles [kt0, kt1) only and leaves a float partial (see below)
+    const int nsplit = p.splitk > 1 ? p.splitk : 1;
+    const int kt0 = (int)((long long)nk * ksplit / nsplit), kt1 = (int)((long long)nk * (ksplit + 1) / nsplit);
     if (GLDS) {
-        issue_tile(0, 0);
+        issue_tile(kt0, 0);
     } else {
-        load_tile(0);
+        load_tile(kt0);
         store_tile(0);
     }
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) {
             if (GLDS)
                 issue_tile(kt + 1, cur ^ 1);
             else
@@ -252,8 +257,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma16(wf[j], xf[i], acc[i][j]);
         }
-        if (!GLDS && kt + 1 < nk) store_tile(cur ^ 1);
+        if (!GLDS && kt + 1 < kt1) store_tile(cur ^ 1);
         __syncthreads();
+    }
+
+    if (p.splitk > 1) {
+        // raw float partial [ksplit][M][N]; bias / activation / residuals / conversion happen in splitk_finish_kernel
+        const int nb2 = n0 + wn * (TN * 16) + 4 * TN * kg;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (TM * 16) + i * 16 + li;
+            if (m >= p.M) continue;
+            float* pp = p.partial + ((long long)ksplit * p.M + m) * p.N + nb2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (nb2 + 4 * j < p.N) *(f32x4*)(pp + 4 * j) = acc[i][j];
+        }
+        return;
     }
 
     // ---- epilogue: lane owns row m, columns [nb, nb + 4*TN) -------------------------------------

@@ -97,6 +97,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, n: int, *, bias: Optional[torch.Tenso
     return oT, of
 
 
+def splitk_for(M: int, N: int, K: int, es: int) -> int:
+    """Split-K factor for problems whose output has too few 128x64 tiles to occupy 256 CUs while K is long
+    (the low-resolution DPT convs: M = 256..2048 voxels, K = 27*256..27*1024)."""
+    tiles = ((M + 127) // 128) * ((N + 63) // 64)
+    nk = (K + 128 // es - 1) // (128 // es)
+    if tiles >= 192 or nk < 32:
+        return 1
+    return max(1, min(16, 512 // tiles, nk // 8))
+
+
 def kv_block(dtype: torch.dtype) -> int:
     """Keys per attention KV block (a 128-byte V^T tile row): 64 for bf16, 32 for f32."""
     return 128 // torch.empty((), dtype=dtype).element_size()
@@ -178,6 +188,10 @@ def conv3d_k3(x: torch.Tensor, w: torch.Tensor, cout: int, *, stride: Tuple[int,
     d.out_T, d.ldc = _p(out), cout
     out_relu = torch.empty_like(out) if relu_copy else None
     d.out_relu_T = _p(out_relu)
+    sk = splitk_for(d.M, cout, 27 * Cin, x.element_size())
+    if sk > 1:
+        partial = torch.empty((sk, d.M, cout), dtype=torch.float32, device=x.device)
+        d.splitk, d.partial = sk, _p(partial)
     lib = _lib.load()
     _lib.check(lib.l4p_conv3d_k3(_stream(), dtype, C.byref(d)), "l4p_conv3d_k3")
     return (out, out_relu) if relu_copy else out
