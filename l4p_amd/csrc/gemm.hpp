@@ -32,8 +32,13 @@ __device__ __attribute__((aligned(16))) static const unsigned g_zero_chunk[4] = 
 // GLDS = true: tiles are staged with global_load_lds (LDS-DMA, no VGPR round trip, no ds_write); the LDS image is
 // lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk and again on the fragment reads.
 // GLDS = false: global -> register -> ds_write staging (needed for the fused input ReLU of the conv loader).
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS>
+// STAGES = 3 (LDS-DMA only): two k-tiles stay in flight; the per-iteration wait is a COUNTED s_waitcnt vmcnt(loads of one
+// tile) followed by a raw s_barrier, so the next tile's DMA is not drained at the barrier (a __syncthreads() would emit
+// vmcnt(0)).  Order per iteration: wait(own loads of tile kt) -> barrier (everyone's tile kt landed, everyone finished
+// reading tile kt-1) -> issue tile kt+2 into the buffer tile kt-1 used -> MFMAs on tile kt.
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS, int STAGES = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+    static_assert(STAGES == 2 || (STAGES == 3 && GLDS), "3-stage pipeline needs LDS-DMA staging");
     constexpr int NT = WM * WN * 64;
     constexpr int ES = sizeof(T);
     constexpr int BK = 128 / ES;   // 64 bf16 / 32 f32 per LDS row
@@ -45,8 +50,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     typedef typename Frag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                  // [2][BM*128]
-    char* Ws = smem + 2 * BM * 128;   // [2][BN*128]
+    char* As = smem;                       // [STAGES][BM*128]
+    char* Ws = smem + STAGES * BM * 128;   // [STAGES][BN*128]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -60,12 +65,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int crow = tid >> 3, cc = tid & 7;  // this thread's (row, LDS slot) inside a staging pass
     // chunk of the 128-byte source row this thread fetches: with LDS-DMA the swizzle moves to the source side
     const int cs = GLDS ? (cc ^ ((crow >> 1) & 7)) : cc;
+    // The W tile is read with the permuted row map (rows 16g + 4j + r of a wave's range, see wrow[] below), so it gets
+    // its own XOR phase: distinct over (g, r >> 1) where the A tile's phase is distinct over 8 consecutive row pairs.
+    auto sww = [](int row) { return ((((row % (16 * TN)) / (4 * TN)) & 3) << 1) | ((row >> 1) & 1); };
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- per-thread source addressing -------------------------------------------------------
     const T* a_base[A_IT];
     unsigned a_mask[A_IT];
     const T* w_base[W_IT];
+    int cs_w[W_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         int m = m0 + crow + i * (NT / 8);
@@ -98,7 +107,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
         int n = n0 + crow + i * (NT / 8);
-        w_base[i] = (const T*)p.W + (long long)n * p.ldw + cs * EPC;
+        cs_w[i] = GLDS ? (cc ^ sww(crow + i * (NT / 8))) : cc;
+        w_base[i] = (const T*)p.W + (long long)n * p.ldw + cs_w[i] * EPC;
     }
 
     const int nk = (p.K + BK - 1) / BK;
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < W_IT; ++i) {
                 u32x4 z = {0, 0, 0, 0};
-                rw[i] = kin ? *(const u32x4*)(w_base[i] + kt * BK) : z;
+                rw[i] = (kt * BK + cs_w[i] * EPC) < p.K ? *(const u32x4*)(w_base[i] + kt * BK) : z;
             }
         } else {
             const int tap = kt / kpc;
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) {
             const int row = crow + i * (NT / 8);
-            *(u32x4*)(Ws + buf * BN * 128 + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4)) = rw[i];
+            *(u32x4*)(Ws + buf * BN * 128 + row * 128 + ((cc ^ sww(row)) << 4)) = rw[i];
         }
     };
 
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
             }
 #pragma unroll
             for (int i = 0; i < W_IT; ++i) {
-                const char* src = kin ? (const char*)(w_base[i] + kt * BK) : zero;
+                const char* src = (kt * BK + cs_w[i] * EPC) < p.K ? (const char*)(w_base[i] + kt * BK) : zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ws + buf * BN * 128 + (wave_u * 64 + i * NT) * 16), 16, 0, 0);
             }
         } else {
@@ -214,21 +224,34 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     // split-K: this workgroup contracts k-tiles [kt0, kt1) only and leaves a float partial (see below)
     const int nsplit = p.splitk > 1 ? p.splitk : 1;
     const int kt0 = (int)((long long)nk * ksplit / nsplit), kt1 = (int)((long long)nk * (ksplit + 1) / nsplit);
-    if (GLDS) {
+    if (STAGES == 3) {
         issue_tile(kt0, 0);
+        if (kt0 + 1 < kt1) issue_tile(kt0 + 1, 1);
+    } else if (GLDS) {
+        issue_tile(kt0, 0);
+        __syncthreads();
     } else {
         load_tile(kt0);
         store_tile(0);
+        __syncthreads();
     }
-    __syncthreads();
 
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        if (kt + 1 < kt1) {
+        const int cur = STAGES == 3 ? (kt - kt0) % 3 : (kt - kt0) & 1;
+        if (STAGES == 3) {
+            if (kt + 1 < kt1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + W_IT) : "memory");  // tile kt landed, tile kt+1 may fly
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < kt1) issue_tile(kt + 2, (kt + 2 - kt0) % 3);
+        } else if (kt + 1 < kt1) {
+#ifndef GEMM_DBG_NOLOAD  // (tools/probes/gemm_variants.hip: ablation timing)
             if (GLDS)
                 issue_tile(kt + 1, cur ^ 1);
             else
                 load_tile(kt + 1);
+#endif
         }
         const char* Ab = As + cur * BM * 128;
         const char* Wb = Ws + cur * BN * 128;
@@ -247,7 +270,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wrow[j];
-                const int sw = (row >> 1) & 7;
+                const int sw = sww(row);
                 u32x4* d = (u32x4*)&wf[j];
 #pragma unroll
                 for (int q = 0; q < CPF; ++q) d[q] = *(const u32x4*)(Wb + row * 128 + (((c0 + q) ^ sw) << 4));
@@ -255,10 +278,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mma16(wf[j], xf[i], acc[i][j]);
+                for (int j = 0; j < TN; ++j) {
+#ifdef GEMM_DBG_NOMMA  // keep the fragment reads alive, skip the matrix pipe
+                    asm volatile("" ::"v"(wf[j]), "v"(xf[i]));
+#else
+                    acc[i][j] = mma16(wf[j], xf[i], acc[i][j]);
+#endif
+                }
         }
         if (!GLDS && kt + 1 < kt1) store_tile(cur ^ 1);
-        __syncthreads();
+        if (STAGES == 2) __syncthreads();
     }
 
     if (p.splitk > 1) {
