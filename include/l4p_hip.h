@@ -278,6 +278,25 @@ size_t l4p_encoder_workspace_bytes(const l4p_engine* e, int B);
 int l4p_encoder_forward(l4p_engine* e, l4p_stream stream, const float* rgb, int B, void* workspace, size_t ws_bytes,
                         int n_taps, const int* tap_layer, float* const* tap_f32, void* const* tap_T);
 
+/* DPTOutputAdapter_fix.forward (dpt_head.py:41-86) of one dense head as a single call: act_postprocess (1x1x1 conv +
+ * ConvTranspose / strided conv), layer_rn, four FeatureFusion blocks, head1, trilinear resize, head2, output
+ * projection (+exp).  hooks[i]: T [B][nt*nh*nw][dim] features of the head's hook layers; out: float
+ * [B][out_ch][out_t][out_h][out_w].  Weights "dpt.<task>.*" must have been bound with l4p_bind_weight.
+ * actpost / fusion are the reference's scale-factor tuples (dense_heads.py:30-31, :269-271). */
+typedef struct l4p_dpt_cfg {
+    int dim, nt, nh, nw;
+    int layer_dims[4];
+    int feature_dim, last_dim, out_ch;
+    int actpost[4][3];
+    int fusion[4][3];
+    int out_t, out_h, out_w;
+    int post_exp;
+} l4p_dpt_cfg;
+
+size_t l4p_dpt_workspace_bytes(const l4p_engine* e, const l4p_dpt_cfg* cfg, int B);
+int l4p_dpt_forward(l4p_engine* e, l4p_stream stream, const char* task, const l4p_dpt_cfg* cfg, const void* const* hooks,
+                    int B, void* workspace, size_t ws_bytes, float* out);
+
 #ifdef __cplusplus
 }
 #endif

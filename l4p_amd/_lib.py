@@ -56,6 +56,19 @@ class EncoderCfg(C.Structure):
     ]
 
 
+class DptCfg(C.Structure):
+    """Mirror of ``l4p_dpt_cfg``."""
+
+    _fields_ = [
+        ("dim", C.c_int), ("nt", C.c_int), ("nh", C.c_int), ("nw", C.c_int),
+        ("layer_dims", C.c_int * 4),
+        ("feature_dim", C.c_int), ("last_dim", C.c_int), ("out_ch", C.c_int),
+        ("actpost", (C.c_int * 3) * 4), ("fusion", (C.c_int * 3) * 4),
+        ("out_t", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int),
+        ("post_exp", C.c_int),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/l4p_hip.h declares must appear here
 _VP, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -97,6 +110,8 @@ SIGNATURES = {
     "l4p_encoder_configure": (_I, [_VP, C.POINTER(EncoderCfg)]),
     "l4p_encoder_workspace_bytes": (_SZ, [_VP, _I]),
     "l4p_encoder_forward": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _I, C.POINTER(_I), C.POINTER(_VP), C.POINTER(_VP)]),
+    "l4p_dpt_workspace_bytes": (_SZ, [_VP, C.POINTER(DptCfg), _I]),
+    "l4p_dpt_forward": (_I, [_VP, _VP, C.c_char_p, C.POINTER(DptCfg), C.POINTER(_VP), _I, _VP, _SZ, _VP]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -27,8 +27,9 @@ class Engine:
         _lib.check(self.lib.l4p_create(device.index or 0, dtype, C.byref(h)), "l4p_create")
         self.handle = h
         for name, t in weights.t.items():
-            if name.startswith("enc."):
+            if name.startswith("enc.") or name.startswith("dpt."):
                 _lib.check(self.lib.l4p_bind_weight(self.handle, name.encode(), t.data_ptr(), t.numel()), "l4p_bind_weight")
+        self._dpt_ws: Dict[Tuple[str, int], torch.Tensor] = {}
         ec = EncoderCfg(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, head_dim=cfg.head_dim, mlp_hidden=cfg.mlp_hidden,
                         in_chans=cfg.in_chans, frames=cfg.frames, img_h=cfg.img, img_w=cfg.img, pt=cfg.patch[0],
                         ph=cfg.patch[1], pw=cfg.patch[2], patch_kp=int(weights.meta["patch_kp"]), ln_eps=cfg.ln_eps)
@@ -48,6 +49,36 @@ class Engine:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def dpt_forward(self, task: str, hooks: Sequence[torch.Tensor], out_ch: int, actpost, fusion,
+                    out_size: Tuple[int, int, int], post_exp: bool) -> torch.Tensor:
+        """DPTOutputAdapter_fix.forward (dpt_head.py:41-86) of head ``task`` as one native call.
+        hooks: 4 x [B, P, C] engine dtype; returns float [B, out_ch, T, H, W]."""
+        c = self.cfg
+        B = hooks[0].shape[0]
+        dc = _lib.DptCfg()
+        dc.dim = c.dim
+        dc.nt, dc.nh, dc.nw = c.grid
+        for i in range(4):
+            dc.layer_dims[i] = c.layer_dims[i]
+            for j in range(3):
+                dc.actpost[i][j] = actpost[i][j]
+                dc.fusion[i][j] = fusion[i][j]
+        dc.feature_dim, dc.last_dim, dc.out_ch = c.feature_dim, c.last_dim, out_ch
+        dc.out_t, dc.out_h, dc.out_w = out_size
+        dc.post_exp = 1 if post_exp else 0
+        key = (task, B)
+        ws = self._dpt_ws.get(key)
+        if ws is None:
+            need = int(self.lib.l4p_dpt_workspace_bytes(self.handle, C.byref(dc), B))
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._dpt_ws[key] = ws
+        hs = [h.contiguous() for h in hooks]
+        hp = (C.c_void_p * 4)(*[h.data_ptr() for h in hs])
+        out = torch.empty((B, out_ch) + tuple(out_size), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.l4p_dpt_forward(self.handle, torch.cuda.current_stream().cuda_stream, task.encode(), C.byref(dc),
+                                            hp, B, ws.data_ptr(), ws.numel(), out.data_ptr()), "l4p_dpt_forward")
+        return out
 
     def encoder_forward(self, rgb: torch.Tensor, taps_f32: Iterable[int] = (), taps_T: Iterable[int] = ()) -> Tuple[Dict[int, torch.Tensor], Dict[int, torch.Tensor]]:
         """VideoMAEEncoder.forward (l4p_videomae.py:80-122) for the requested feature indices only.

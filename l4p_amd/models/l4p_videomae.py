@@ -123,6 +123,7 @@ class L4P_VideoMAE(torch.nn.Module):
         self.weights = weights
         self.engine = Engine(self.cfg, weights, self.engine_dtype, self.device)
         rt = _Runtime(self.cfg, weights, self.engine_dtype)
+        rt.engine = self.engine
         for head in self.task_heads.values():
             head._rt = rt
 

@@ -11,6 +11,7 @@ while the conv runs on 2-8x fewer voxels.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -123,8 +124,15 @@ class VideoMAEFlowDPTHead(torch.nn.Module):
         if self._rt is None:
             raise RuntimeError(f"head '{self.task_name}' has no weights: call load_state_dict on the model first")
         hooks = [enc_features_bpc_list.T(h) for h in self.hooks_idx]
-        return dpt_decode(self._rt.weights, self._rt.cfg, self._engine_task, hooks, self.out_nchan, self.output_size,
-                          tuple(img_info), self._post_exp)
+        eng = getattr(self._rt, "engine", None)
+        if eng is None or os.environ.get("L4P_DPT_PYTHON"):
+            # kernel-by-kernel composition from Python (the readable statement of the graph; same kernels)
+            return dpt_decode(self._rt.weights, self._rt.cfg, self._engine_task, hooks, self.out_nchan, self.output_size,
+                              tuple(img_info), self._post_exp)
+        out_ch = self._rt.weights[f"dpt.{self._engine_task}.out.w"].shape[0]
+        osz = tuple(img_info) if self.output_size is None else tuple(self.output_size)
+        return eng.dpt_forward(self._engine_task, hooks, out_ch, actpost_of(self._engine_task), fusion_of(self._engine_task),
+                               osz, self._post_exp)
 
     # -- reference API ---------------------------------------------------------------------------
     def forward(self, enc_features_bpc_list, img_info: Tuple[int, int, int] = (16, 224, 224), **kwargs) -> Dict[str, torch.Tensor]:

@@ -80,3 +80,20 @@ def test_mini_encoder_and_dense_heads_vs_oracle_and_golden(dev, mini, precision,
             g = torch.from_numpy(gold[key]).reshape(-1)
             s = y.reshape(-1)[sample_indices(y.numel())] if y.numel() > 4096 else y.reshape(-1)
             assert (s - g).abs().max() <= tol_max * g.abs().max(), key
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_native_dpt_call_equals_python_composition(dev, mini, precision, monkeypatch):
+    """l4p_dpt_forward (one C++ call) issues the same kernels in the same order as dense_heads.dpt_decode
+    (kernel-by-kernel from Python): outputs must be bit-identical, for a full-resolution head and the camray head."""
+    cfg, sd = mini
+    model = build(cfg, sd, precision)
+    batch = make_batch(16, 2)
+    tasks = ["depth", "camray"]
+    with torch.no_grad():
+        a = model.forward({k: v.clone() for k, v in batch.items()}, tasks)
+        monkeypatch.setenv("L4P_DPT_PYTHON", "1")
+        b = model.forward({k: v.clone() for k, v in batch.items()}, tasks)
+    torch.cuda.synchronize()
+    for k in ("depth_est_b1thw", "traj3d_est_b16t"):
+        assert torch.equal(a[k], b[k]), k
