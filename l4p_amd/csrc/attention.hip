@@ -22,6 +22,8 @@
 //  * the softmax denominator comes out of the MFMA: padding row d = DH of the V^T tile is sourced
 //    from a constant "ones" chunk, so O^T[DH][q] = sum_k P[q][k] with exactly the weights used for O.
 //  * exp via v_exp_f32 (exp2 of non-positive arguments), scale*log2(e) folded into one fma.
+#include <type_traits>
+
 #include "common.hpp"
 
 __device__ __attribute__((aligned(16))) static const unsigned short g_ones_bf16[8] = {0x3F80, 0x3F80, 0x3F80, 0x3F80,
@@ -105,11 +107,13 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         vsrc[i] = (const char*)(vt + (((long long)b * H + h) * DP + d) * S) + vchunk * 16;  // + kb*128
     }
     const char* ones = ES == 2 ? (const char*)g_ones_bf16 : (const char*)g_ones_f32;
-    auto issue_kv = [&](int kb, int buf) {
+    auto issue_k = [&](int kb, int buf) {
 #pragma unroll
         for (int i = 0; i < K_IT; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (long long)kb * KBYTES + i * 4096),
                                              (lptr_t)(Ks + buf * KBYTES + (wave * 64 + i * 256) * 16), 16, 0, 0);
+    };
+    auto issue_v = [&](int kb, int buf) {
 #pragma unroll
         for (int i = 0; i < V_IT; ++i) {
             const char* src = vones[i] ? ones : vsrc[i] + (long long)kb * 128;
@@ -138,24 +142,8 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     for (int dt = 0; dt < NDT; ++dt) voff[dt] = (dt * 32 + lq) * 128;
     const int vsw = (lq >> 1) & 7;  // ((dt*32 + lq) >> 1) & 7
 
-    issue_kv(grp, 0);
-    __syncthreads();
-
-    const int nit = nkb / SPLIT;  // this group's KV blocks: grp, grp + SPLIT, ...
-    for (int it = 0; it < nit; ++it) {
-        const int cur = it & 1;
-#ifndef ATTN_DBG_NOLOAD  // (tools/probes/attn_variants.hip: compute-only timing)
-        if (it + 1 < nit) issue_kv((it + 1) * SPLIT + grp, cur ^ 1);
-#endif
-        const char* Kb = Ks + cur * KBYTES;
-        const char* Vb = Vs + cur * VBYTES;
-
-#ifdef ATTN_DBG_NOCOMPUTE  // (probe: staging-only timing)
-        __syncthreads();
-        continue;
-#endif
-        // ---- S^T tiles: rows = keys (permuted), cols = queries --------------------------------
-        f32x16 s[NST];
+    // S^T = K Q^T for one KV block: rows = keys (permuted), cols = queries
+    auto qk_tile = [&](const char* Kb, f32x16* s) {
 #pragma unroll
         for (int t = 0; t < NST; ++t) {
 #pragma unroll
@@ -169,16 +157,45 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
                 s[t] = mma32(kf, qf[ks], s[t]);
             }
         }
-
-        // ---- online softmax (all per-query state is lane-local) -------------------------------
+    };
+    auto row_max = [&](const f32x16* s) {
         float mx = s[0][0];
 #pragma unroll
         for (int t = 0; t < NST; ++t)
 #pragma unroll
             for (int r = (t == 0 ? 1 : 0); r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        return fmaxf(mx, __shfl_xor(mx, 32));
+    };
+
+    // Software pipeline over this group's KV blocks (block j of the group = global block j*SPLIT + grp):
+    //   iteration j:  [ S_{j+1} = K_{j+1} Q^T  (MFMA)  ||  P_j = exp2(S_j*c - m)  (VALU) ]
+    //                 [ O^T += V_j^T P_j^T     (MFMA)  ||  row max of S_{j+1}     (VALU) ]
+    // so each MFMA batch has independent VALU work to issue under it.  K runs one block ahead of V in the LDS rings.
+    const int nit = nkb / SPLIT;
+    issue_k(grp, 0);
+    issue_v(grp, 0);
+    if (nit > 1) issue_k(SPLIT + grp, 1);
+    __syncthreads();
+    f32x16 s_cur[NST], s_nxt[NST];
+    qk_tile(Ks, s_cur);
+    float mx = row_max(s_cur);
+
+    // one pipeline step; HAS_NEXT is a compile-time flag so that the steady-state body is ONE basic block in which the
+    // scheduler is free to interleave the two MFMA batches with the VALU work (the last block is peeled)
+    auto step = [&](int it, auto has_next) {
+        constexpr bool HAS_NEXT = decltype(has_next)::value;
+        const int cur = it & 1;
+#ifndef ATTN_DBG_NOLOAD  // (tools/probes/attn_variants.hip: compute-only timing)
+        if (it + 2 < nit) issue_k((it + 2) * SPLIT + grp, cur);      // K_{it} (ring slot cur) was consumed last iteration
+        if (HAS_NEXT) issue_v((it + 1) * SPLIT + grp, cur ^ 1);      // V_{it-1} (slot cur^1) was consumed last iteration
+#endif
+#ifdef ATTN_DBG_NOCOMPUTE  // (probe: staging-only timing)
+        __syncthreads();
+        return;
+#endif
+        // ---- running max / rescale (lane-local; skipped wave-uniformly when no row maximum moved) -----
         const float m_new = fmaxf(m_run, mx * c_scale);
-        if (__any(m_new > m_run)) {  // wave-uniform: some row maximum moved -> rescale O (and the denominator row)
+        if (__any(m_new > m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt)
@@ -186,19 +203,22 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             m_run = m_new;
         }
+        // ---- next block's scores (MFMA) alongside this block's exponentials (VALU) ----------------
+        if (HAS_NEXT) qk_tile(Ks + (cur ^ 1) * KBYTES, s_nxt);
+        frag_t pf[NST][2];
 #pragma unroll
         for (int t = 0; t < NST; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c_scale, -m_run));
-
-        // ---- O^T += V^T P^T ---------------------------------------------------------------------
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    pf[t][j][e] = from_f32<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[t][8 * j + e], c_scale, -m_run)));
+        // ---- O^T += V^T P^T (MFMA) alongside the row max of the next scores (VALU) ------------------
+        const char* Vb = Vs + cur * VBYTES;
 #pragma unroll
         for (int t = 0; t < NST; ++t)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                frag_t pf;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = from_f32<T>(s[t][8 * j + e]);
                 const int c0 = ((t * 32 + j * 16 + hi * 8) * ES) >> 4;  // first 16-byte chunk of the 8 keys
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
@@ -206,11 +226,18 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
                     u32x4* d = (u32x4*)&vf;
 #pragma unroll
                     for (int c = 0; c < CPF; ++c) d[c] = *(const u32x4*)(Vb + voff[dt] + (((c0 + c) ^ vsw) << 4));
-                    o[dt] = mma32(vf, pf, o[dt]);
+                    o[dt] = mma32(vf, pf[t][j], o[dt]);
                 }
             }
-        __syncthreads();  // (drains the LDS-DMA of the next tile: vmcnt(0) + barrier)
-    }
+        if (HAS_NEXT) {
+            mx = row_max(s_nxt);
+#pragma unroll
+            for (int t = 0; t < NST; ++t) s_cur[t] = s_nxt[t];
+            __syncthreads();  // (drains the LDS-DMA issued at the top: vmcnt(0) + barrier)
+        }
+    };
+    for (int it = 0; it + 1 < nit; ++it) step(it, std::true_type{});
+    step(nit - 1, std::false_type{});
 
     // ---- SPLIT: merge the partial states of the KV groups through LDS (tile buffers are free now) -----
     if (SPLIT > 1) {
