@@ -126,6 +126,36 @@ def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 4):
                        f"+ heads in full {t_heads:.2f}s -> {dt:.1f}s per clip")}
 
 
+def build_workload(tasks, B, nq, device, rank=0):
+    """Model (name-seeded random weights, packed on rank 0 and broadcast once) + one synthetic batch of B clips."""
+    cfg = ModelCfg.full()
+    model = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision="bf16")
+    net = model.l4p_model
+    net.task_heads = torch.nn.ModuleDict({t: net.task_heads[t] for t in tasks})
+    if "camray" in tasks:
+        net.task_heads["camray"].use_intrinsics = True
+    sd, pw = None, None
+    if rank == 0:
+        sd = seeded_state_dict(cfg, tasks=tasks)
+        pw = pack_state_dict(sd, cfg, torch.bfloat16, device, tasks=tasks)
+    pw = broadcast_weights(pw, device)  # RCCL over xGMI, once
+    net.set_weights(pw)
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    rgb = torch.randn([B, 3, 16, 224, 224], generator=g, dtype=torch.float32)
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 224.0
+    K[0, 2] = K[1, 2] = 112.0
+    batch = {"rgb_b3thw": rgb.to(device), "intrinsics_b44t": K[None, :, :, None].repeat(B, 1, 1, 16).to(device)}
+    if "track_2d" in tasks:
+        q = torch.zeros(1, nq, 3)
+        for i in range(nq):
+            q[0, i] = torch.tensor([0.5, 14.0 + 28.0 * (i % 8) + 0.5, 14.0 + 28.0 * ((i // 8) % 8) + 0.5])
+        batch["track_2d_pointquerries_bn3"] = q.repeat(B, 1, 1).to(device)  # every clip tracks its own nq queries
+        batch["track_2d_pointlabels_bn"] = torch.ones(B, nq, device=device)
+    return model, batch, sd
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,31 +179,7 @@ def main():
     tasks = ["depth"] if args.workload == "c2" else list(ALL_TASKS)
     B = args.batch or (1 if args.workload == "c2" else 4)
 
-    model = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision="bf16")
-    net = model.l4p_model
-    net.task_heads = torch.nn.ModuleDict({t: net.task_heads[t] for t in tasks})
-    if "camray" in tasks:
-        net.task_heads["camray"].use_intrinsics = True
-    sd, pw = None, None
-    if rank == 0:
-        sd = seeded_state_dict(cfg, tasks=tasks)
-        pw = pack_state_dict(sd, cfg, torch.bfloat16, device, tasks=tasks)
-    pw = broadcast_weights(pw, device)  # RCCL over xGMI, once
-    net.set_weights(pw)
-
-    g = torch.Generator().manual_seed(1234 + rank)
-    rgb = torch.randn([B, 3, 16, 224, 224], generator=g, dtype=torch.float32)
-    K = torch.eye(4)
-    K[0, 0] = K[1, 1] = 224.0
-    K[0, 2] = K[1, 2] = 112.0
-    batch = {"rgb_b3thw": rgb.to(device), "intrinsics_b44t": K[None, :, :, None].repeat(B, 1, 1, 16).to(device)}
-    if "track_2d" in tasks:
-        nq = args.queries
-        q = torch.zeros(1, nq, 3)
-        for i in range(nq):
-            q[0, i] = torch.tensor([0.5, 14.0 + 28.0 * (i % 8) + 0.5, 14.0 + 28.0 * ((i // 8) % 8) + 0.5])
-        batch["track_2d_pointquerries_bn3"] = q.repeat(B, 1, 1).to(device)  # every clip tracks its own nq queries
-        batch["track_2d_pointlabels_bn"] = torch.ones(B, nq, device=device)
+    model, batch, sd = build_workload(tasks, B, args.queries, device, rank)
 
     def step():
         with torch.no_grad():

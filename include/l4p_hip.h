@@ -52,6 +52,10 @@ int l4p_prof_reset(void);
 int l4p_prof_num_classes(void);
 const char* l4p_prof_class_name(int cls);
 int l4p_prof_read(int cls, double* total_ms, long long* count);
+/* Per-(class, tag) breakdown (tag = GEMM shape, LayerNorm shape, kernel name ...) of the same event pairs as text
+ * lines "class\ttag\tcount\ttotal_ms\n", largest first.  Returns the bytes needed incl. the terminator; writes at
+ * most cap bytes to buf (buf may be NULL to query the size).  Tuning aid behind tools/prof_detail.py. */
+long long l4p_prof_detail(char* buf, long long cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level entry points (also the unit-parity surface of tests/).

@@ -79,6 +79,7 @@ SIGNATURES = {
     "l4p_prof_num_classes": (_I, []),
     "l4p_prof_class_name": (C.c_char_p, [_I]),
     "l4p_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "l4p_prof_detail": (_LL, [C.c_char_p, _LL]),
     "l4p_gemm": (_I, [_VP, _I, C.POINTER(GemmDesc)]),
     "l4p_conv3d_k3": (_I, [_VP, _I, C.POINTER(GemmDesc)]),
     "l4p_layernorm": (_I, [_VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I]),

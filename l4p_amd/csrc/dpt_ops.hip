@@ -92,7 +92,7 @@ int launch_upsample(int dtype, const void* x, void* y, int B, int Ti, int Hi, in
     }
     const long long total = (long long)B * To * Ho * Wo * (C / 8);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    ProfScope prof(PROF_ELEMENTWISE, stream);
+    ProfScope prof(PROF_ELEMENTWISE, stream, "upsample");
     if (dtype == L4P_BF16)
         hipLaunchKernelGGL(upsample_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, B, Ti,
                            Hi, Wi, To, Ho, Wo, C, align);
@@ -164,7 +164,7 @@ int launch_head_out(int dtype, const void* x, const float* w, const float* bias,
     }
     const long long total = vox_per_b * B;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    ProfScope prof(PROF_ELEMENTWISE, stream);
+    ProfScope prof(PROF_ELEMENTWISE, stream, "head_out");
     if (dtype == L4P_BF16)
         hipLaunchKernelGGL((head_out_kernel<bf16_t, 128>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, w, bias, y,
                            vox_per_b, B, Cout, post_exp);

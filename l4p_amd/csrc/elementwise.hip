@@ -94,7 +94,7 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
         return L4P_E_INVALID;
     }
     const dim3 grid((M + 3) / 4), block(256);
-    ProfScope prof(PROF_LAYERNORM, stream);
+    ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d add%d T2%d act%d f32%d", M, C, add != nullptr, out_T2 != nullptr, act, out_f32 != nullptr);
     if (dtype == L4P_BF16)
         hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
                            out_f32, M, C, add, add_mod, (bf16_t*)out_T2, act);
@@ -135,7 +135,7 @@ int launch_cast(int dtype, const float* x, void* y, long long n, hipStream_t str
     }
     const long long n4 = n / 4;
     const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    ProfScope prof(PROF_ELEMENTWISE, stream);
+    ProfScope prof(PROF_ELEMENTWISE, stream, "cast");
     if (dtype == L4P_BF16)
         hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, x, (bf16_t*)y, n4);
     else
@@ -189,7 +189,7 @@ int launch_patch_gather(int dtype, const float* rgb, void* out, int B, int Cin, 
     }
     const long long total = (long long)B * (T / pt) * (H / ph) * (W / pw) * Kp;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    ProfScope prof(PROF_ELEMENTWISE, stream);
+    ProfScope prof(PROF_ELEMENTWISE, stream, "patch_gather");
     if (dtype == L4P_BF16)
         hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, rgb, (bf16_t*)out, B, Cin, T,
                            H, W, pt, ph, pw, Kp);

@@ -13,8 +13,9 @@
 //    vector accesses and every output row is written in 64..256-byte runs.
 //  * LDS tiles have 128-byte rows, XOR-swizzled at 16-byte granularity (chunk ^= (row>>1)&7) so the
 //    non-contiguous 16-lane groups of ds_read_b128 hit 16 distinct slots.
-//  * global->register->LDS staging, next tile's loads issued before the current tile's MFMAs
-//    (register prefetch, double-buffered LDS, one barrier per k-tile).
+//  * tiles are staged by LDS-DMA (global_load_lds, 16 B per lane, swizzle applied to the per-lane SOURCE chunk);
+//    the register-staged loader remains for the conv path with a fused input ReLU.  Next tile's loads are issued
+//    before the current tile's MFMAs (double-buffered LDS, one barrier per k-tile).
 //  * T = bf16 uses v_mfma_f32_16x16x32_bf16, T = float uses 8x v_mfma_f32_16x16x4_f32 on the same
 //    fragment registers (exact-f32 parity mode).
 #pragma once
@@ -28,6 +29,216 @@ typedef l4p_gemm_desc GemmParams;
 
 // 16 zero bytes in global memory: the source of LDS-DMA chunks that must read as zero (conv padding, k tail)
 __device__ __attribute__((aligned(16))) static const unsigned g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+// ---- epilogue shared by every GEMM kernel: the lane (li, kg) owns rows m_wave0 + 16*i + li and the 4*TN consecutive
+//      columns n_wave0 + 4*TN*kg + [0, 4*TN) of its wave's tile (acc[i][j][r] = column 4*TN*kg + 4*j + r) -------------
+// One row (16*i + li) of the lane's tile: bias, activation, residuals, scatter / store.
+template <typename T, int NV>
+__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v)[NV], const float (&bv)[NV], int m, int nb);
+
+// ROLLED = false: the row loop is fully unrolled (registers die row by row: 120 VGPRs for the 128x128 kernel, which
+// keeps 2-3 workgroups per CU).  ROLLED = true (gemm8p.hpp, alone on its CU with registers to spare): the row body -
+// ~1k instructions with every epilogue flavour and the integer divisions of the scatter paths - exists ONCE; TM
+// unrolled copies overflow the instruction cache (measured: 15 us per 256x256 tile) and nothing hides those misses.
+template <typename T, int TM, int TN, bool ROLLED = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0, int li,
+                                              int kg) {
+    constexpr int ES = sizeof(T);
+    constexpr int NV = 4 * TN;
+    const int nb = n_wave0 + NV * kg;
+    // the lane's bias values are row independent: fetch them once, ahead of the row loop (a load inside the loop
+    // costs one exposed L2 round trip per row when the workgroup is alone on its CU)
+    float bv[NV];
+#pragma unroll
+    for (int g8 = 0; g8 < NV; g8 += 8) {
+        const bool ok = p.bias && nb + g8 < p.N;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 b0 = ok ? *(const f32x4*)(p.bias + nb + g8) : z, b1 = ok ? *(const f32x4*)(p.bias + nb + g8 + 4) : z;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bv[g8 + q] = b0[q];
+            bv[g8 + 4 + q] = b1[q];
+        }
+    }
+    if (ROLLED) {
+#pragma nounroll
+        for (int i = 0; i < TM; ++i) {
+            float v[NV];
+#define L4P_ACC_ROW(I)                                                                                   \
+    case I:                                                                                              \
+        if (I < TM) {                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[I < TM ? I : 0][j][r]; \
+        }                                                                                                \
+        break;
+            switch (i) {  // wave-uniform: keeps the accumulators statically indexed
+                L4P_ACC_ROW(0) L4P_ACC_ROW(1) L4P_ACC_ROW(2) L4P_ACC_ROW(3) L4P_ACC_ROW(4) L4P_ACC_ROW(5) L4P_ACC_ROW(6) L4P_ACC_ROW(7)
+            }
+#undef L4P_ACC_ROW
+            static_assert(TM <= 8, "extend the accumulator row switch");
+            const int m = m_wave0 + i * 16 + li;
+            if (m < p.M) gemm_epilogue_row<T, NV>(p, v, bv, m, nb);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v[NV];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
+            const int m = m_wave0 + i * 16 + li;
+            if (m < p.M) gemm_epilogue_row<T, NV>(p, v, bv, m, nb);
+        }
+    }
+}
+
+template <typename T, int NV>
+__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v)[NV], const float (&bv)[NV], int m, int nb) {
+    constexpr int ES = sizeof(T);
+    {
+        // float residuals of the whole row segment, loaded before any of its outputs is stored (in-place updates alias)
+        float rv[NV], rv2[NV];
+        const bool res32 = p.res1 && p.res_f32;
+        if (res32) {
+            const long long rrow = (long long)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr;
+#pragma unroll
+            for (int g8 = 0; g8 < NV; g8 += 8) {
+                const int n = nb + g8;
+                f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, s0 = r0, s1 = r0;
+                if (n < p.N) {
+                    r0 = *(const f32x4*)((const float*)p.res1 + rrow + n);
+                    r1 = *(const f32x4*)((const float*)p.res1 + rrow + n + 4);
+                    if (p.res2) {
+                        s0 = *(const f32x4*)((const float*)p.res2 + rrow + n);
+                        s1 = *(const f32x4*)((const float*)p.res2 + rrow + n + 4);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    rv[g8 + q] = r0[q];
+                    rv[g8 + 4 + q] = r1[q];
+                    rv2[g8 + q] = s0[q];
+                    rv2[g8 + 4 + q] = s1[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int g8 = 0; g8 < NV; g8 += 8) {
+            const int n = nb + g8;
+            if (n >= p.N) continue;  // N % 8 == 0 is required
+            float* vv = v + g8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vv[q] += bv[g8 + q];
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] = gelu_erf(vv[q]);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] = fmaxf(vv[q], 0.0f);
+            }
+            // output / residual addressing
+            long long off;  // element offset for dense-style addressing
+            if (p.epi == EPI_CONVT) {
+                const int tap = n / p.Cout, co = n - tap * p.Cout;
+                const int dw = tap % p.kw, dh = (tap / p.kw) % p.kh, dt = tap / (p.kw * p.kh);
+                int wi = m % p.Wi;
+                int r = m / p.Wi;
+                int hi = r % p.Hi;
+                r /= p.Hi;
+                int ti = r % p.Ti;
+                int b = r / p.Ti;
+                const long long vox =
+                    (((long long)b * p.Ti * p.kt + (ti * p.kt + dt)) * (p.Hi * p.kh) + (hi * p.kh + dh)) * (p.Wi * p.kw) +
+                    (wi * p.kw + dw);
+                off = vox * p.Cout + co;
+            } else {
+                const long long pm = p.c_gr > 0 ? (long long)(m / p.c_gr) * p.c_gs + p.c_go + (m % p.c_gr) : m;
+                off = pm * p.ldc + n;
+            }
+            if (res32) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] += rv[g8 + q];
+                if (p.res2) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) vv[q] += rv2[g8 + q];
+                }
+            } else if (p.res1) {
+                const long long roff = (long long)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr + n;
+                const T* rp = (const T*)p.res1 + roff;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] += to_f32<T>(rp[q]);
+                if (p.res2) {
+                    const T* sp = (const T*)p.res2 + roff;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) vv[q] += to_f32<T>(sp[q]);
+                }
+            }
+            if (p.epi == EPI_QKV && n >= p.H * p.Dp && n < 2 * p.H * p.Dp) {
+                // K, stored in the attention kernel's LDS tile order (attention.hip): 8-element groups
+                // [b][h][kv block][k-step][key][half ^ ((key >> 3) & 1)], KVB keys per block
+                constexpr int KVB = 128 / ES;
+                const int nk = n - p.H * p.Dp;
+                const int h = nk / p.Dp, d0 = nk - h * p.Dp;
+                const int ks = d0 >> 4, half = (d0 >> 3) & 1;
+                const int b = m / p.S, s = m - b * p.S;
+                const int kb = s / KVB, key = s - kb * KVB;
+                const long long g8 =
+                    ((((long long)(b * p.H + h) * (p.S / KVB) + kb) * (p.Dp / 16) + ks) * KVB + key) * 2 + (half ^ ((key >> 3) & 1));
+                T* kp = (T*)p.k_tiled + g8 * 8;
+                if (ES == 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
+                    *(bf16x8*)kp = o;
+                } else {
+                    *(f32x4*)kp = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+                    *(f32x4*)((float*)kp + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+                }
+                continue;
+            }
+            if (p.epi == EPI_QKV && n >= 2 * p.H * p.Dp) {
+                // V, stored transposed: vt[((b*H + h)*Dp + d)*S + s]
+                const int nv = n - 2 * p.H * p.Dp;
+                const int h = nv / p.Dp, d = nv - h * p.Dp;
+                const int b = m / p.S, s = m - b * p.S;
+                T* vp = (T*)p.vt + ((long long)(b * p.H + h) * p.Dp + d) * p.S + s;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vp[(long long)q * p.S] = from_f32<T>(vv[q]);
+                continue;
+            }
+            if (p.out_f32) {
+                float* op = p.out_f32 + off;
+                *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+                *(f32x4*)(op + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+            }
+            if (p.out_relu_T) {  // second output: relu(v) as T (pre-activated input of the next ResidualConvUnit conv)
+                T* op = (T*)p.out_relu_T + off;
+                if (ES == 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)fmaxf(vv[q], 0.f);
+                    *(bf16x8*)op = o;
+                } else {
+                    *(f32x4*)op = (f32x4){fmaxf(vv[0], 0.f), fmaxf(vv[1], 0.f), fmaxf(vv[2], 0.f), fmaxf(vv[3], 0.f)};
+                    *(f32x4*)((float*)op + 4) = (f32x4){fmaxf(vv[4], 0.f), fmaxf(vv[5], 0.f), fmaxf(vv[6], 0.f), fmaxf(vv[7], 0.f)};
+                }
+            }
+            if (p.out_T) {
+                T* op = (T*)p.out_T + off;
+                if (ES == 2) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
+                    *(bf16x8*)op = o;
+                } else {
+                    *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+                    *(f32x4*)((float*)op + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+                }
+            }
+        }
+    }
+}
 
 // GLDS = true: tiles are staged with global_load_lds (LDS-DMA, no VGPR round trip, no ds_write); the LDS image is
 // lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk and again on the fragment reads.
@@ -305,151 +516,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         return;
     }
 
-    // ---- epilogue: lane owns row m, columns [nb, nb + 4*TN) -------------------------------------
-    constexpr int NV = 4 * TN;
-    const int nb = n0 + wn * (TN * 16) + NV * kg;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (TM * 16) + i * 16 + li;
-        if (m >= p.M) continue;
-        float v[NV];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
-#pragma unroll
-        for (int g8 = 0; g8 < NV; g8 += 8) {
-            const int n = nb + g8;
-            if (n >= p.N) continue;  // N % 8 == 0 is required
-            float* vv = v + g8;
-            if (p.bias) {
-                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    vv[q] += b0[q];
-                    vv[4 + q] += b1[q];
-                }
-            }
-            if (p.act == ACT_GELU) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) vv[q] = gelu_erf(vv[q]);
-            } else if (p.act == ACT_RELU) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) vv[q] = fmaxf(vv[q], 0.0f);
-            }
-            // output / residual addressing
-            long long off;  // element offset for dense-style addressing
-            if (p.epi == EPI_CONVT) {
-                const int tap = n / p.Cout, co = n - tap * p.Cout;
-                const int dw = tap % p.kw, dh = (tap / p.kw) % p.kh, dt = tap / (p.kw * p.kh);
-                int wi = m % p.Wi;
-                int r = m / p.Wi;
-                int hi = r % p.Hi;
-                r /= p.Hi;
-                int ti = r % p.Ti;
-                int b = r / p.Ti;
-                const long long vox =
-                    (((long long)b * p.Ti * p.kt + (ti * p.kt + dt)) * (p.Hi * p.kh) + (hi * p.kh + dh)) * (p.Wi * p.kw) +
-                    (wi * p.kw + dw);
-                off = vox * p.Cout + co;
-            } else {
-                const long long pm = p.c_gr > 0 ? (long long)(m / p.c_gr) * p.c_gs + p.c_go + (m % p.c_gr) : m;
-                off = pm * p.ldc + n;
-            }
-            if (p.res1) {
-                const long long roff = (long long)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr + n;
-                if (p.res_f32) {
-                    const f32x4 r0 = *(const f32x4*)((const float*)p.res1 + roff),
-                                r1 = *(const f32x4*)((const float*)p.res1 + roff + 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        vv[q] += r0[q];
-                        vv[4 + q] += r1[q];
-                    }
-                    if (p.res2) {
-                        const f32x4 s0 = *(const f32x4*)((const float*)p.res2 + roff),
-                                    s1 = *(const f32x4*)((const float*)p.res2 + roff + 4);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            vv[q] += s0[q];
-                            vv[4 + q] += s1[q];
-                        }
-                    }
-                } else {
-                    const T* rp = (const T*)p.res1 + roff;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) vv[q] += to_f32<T>(rp[q]);
-                    if (p.res2) {
-                        const T* sp = (const T*)p.res2 + roff;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) vv[q] += to_f32<T>(sp[q]);
-                    }
-                }
-            }
-            if (p.epi == EPI_QKV && n >= p.H * p.Dp && n < 2 * p.H * p.Dp) {
-                // K, stored in the attention kernel's LDS tile order (attention.hip): 8-element groups
-                // [b][h][kv block][k-step][key][half ^ ((key >> 3) & 1)], KVB keys per block
-                constexpr int KVB = 128 / ES;
-                const int nk = n - p.H * p.Dp;
-                const int h = nk / p.Dp, d0 = nk - h * p.Dp;
-                const int ks = d0 >> 4, half = (d0 >> 3) & 1;
-                const int b = m / p.S, s = m - b * p.S;
-                const int kb = s / KVB, key = s - kb * KVB;
-                const long long g8 =
-                    ((((long long)(b * p.H + h) * (p.S / KVB) + kb) * (p.Dp / 16) + ks) * KVB + key) * 2 + (half ^ ((key >> 3) & 1));
-                T* kp = (T*)p.k_tiled + g8 * 8;
-                if (ES == 2) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
-                    *(bf16x8*)kp = o;
-                } else {
-                    *(f32x4*)kp = (f32x4){vv[0], vv[1], vv[2], vv[3]};
-                    *(f32x4*)((float*)kp + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
-                }
-                continue;
-            }
-            if (p.epi == EPI_QKV && n >= 2 * p.H * p.Dp) {
-                // V, stored transposed: vt[((b*H + h)*Dp + d)*S + s]
-                const int nv = n - 2 * p.H * p.Dp;
-                const int h = nv / p.Dp, d = nv - h * p.Dp;
-                const int b = m / p.S, s = m - b * p.S;
-                T* vp = (T*)p.vt + ((long long)(b * p.H + h) * p.Dp + d) * p.S + s;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) vp[(long long)q * p.S] = from_f32<T>(vv[q]);
-                continue;
-            }
-            if (p.out_f32) {
-                float* op = p.out_f32 + off;
-                *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
-                *(f32x4*)(op + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
-            }
-            if (p.out_relu_T) {  // second output: relu(v) as T (pre-activated input of the next ResidualConvUnit conv)
-                T* op = (T*)p.out_relu_T + off;
-                if (ES == 2) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)fmaxf(vv[q], 0.f);
-                    *(bf16x8*)op = o;
-                } else {
-                    *(f32x4*)op = (f32x4){fmaxf(vv[0], 0.f), fmaxf(vv[1], 0.f), fmaxf(vv[2], 0.f), fmaxf(vv[3], 0.f)};
-                    *(f32x4*)((float*)op + 4) = (f32x4){fmaxf(vv[4], 0.f), fmaxf(vv[5], 0.f), fmaxf(vv[6], 0.f), fmaxf(vv[7], 0.f)};
-                }
-            }
-            if (p.out_T) {
-                T* op = (T*)p.out_T + off;
-                if (ES == 2) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
-                    *(bf16x8*)op = o;
-                } else {
-                    *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
-                    *(f32x4*)((float*)op + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
-                }
-            }
-        }
-    }
+    gemm_epilogue<T, TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), li, kg);
 }
 
 // host launcher (gemm.hip)

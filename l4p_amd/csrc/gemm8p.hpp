@@ -1,0 +1,248 @@
+// Deep-pipelined bf16 MFMA GEMM / implicit-GEMM conv3d for LARGE problems on gfx950 (same math, descriptor and
+// epilogue as gemm.hpp; reference call sites listed there).  Where gemm.hpp's 128x128 tile is bound by the per-CU
+// global->LDS path (64 FLOP/B) and drains its LDS-DMA at every barrier, this kernel follows the CDNA4 playbook's
+// "8-phase" structure:
+//
+//  * 512 threads = 8 waves, wave tile 128 x 64 (acc 8 x 4 MFMA tiles), workgroup tile (WR*128) x (WC*64):
+//    256 x 256 (WR=2, WC=4; 128 FLOP/B) or 512 x 128 (WR=4, WC=2; narrow-N convs).  One workgroup per CU.
+//  * a k-tile (64 deep) lives in LDS as four HALF-tiles: A0/A1 = the first/second 64 rows of every wave's 128 rows,
+//    W0/W1 = the first/second 32 columns (as 4 x 8-column groups, see the epilogue's column order) of every wave's 64.
+//    Two k-tile buffers.  128-byte rows, XOR-swizzled at 16 B exactly like gemm.hpp (conflict-free ds_read_b128),
+//    filled by LDS-DMA with the swizzle applied to the per-lane SOURCE chunk.
+//  * each k-tile is four PHASES, one C quadrant (64 x 32, 16 MFMAs over k = 64) each:
+//        P1: read W0 + A0 | stage W1(t+1) | Q00      P2: read W1 | stage A1(t+1) | Q01
+//        P3: read A1      | stage A0(t+2) | Q11      P4:    -    | stage W0(t+2) | Q10
+//    A phase = [ds_reads, one half-tile of LDS-DMA, counted vmcnt] s_barrier [16 MFMAs at raised priority] s_barrier.
+//  * the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART, so on every SIMD one
+//    wave's MFMA segment overlaps its partner's read/stage segment.
+//  * the LDS-DMA queue is never drained in the loop: after its own issue every phase waits vmcnt(INFLIGHT), i.e. for
+//    the half-tile issued four phases earlier.  Hazards (both groups, one barrier apart):
+//        RAW: data waited for in phase q is first read in phase q+1        (W1: q=P1',r=P2'; A1: P2'/P3'; A0: P3'/P1''; W0: P4'/P1'')
+//        WAR: a half-tile is re-staged >= 2 phases after its last ds_read  (W1: read P2, staged P1'; A1: P3/P2'; A0: P1/P3; W0: P1/P4)
+//    Past the last k-tile the phases stage zero chunks so the counted waits stay exact.
+#pragma once
+#include "gemm.hpp"
+
+template <int MODE, int WR, int WC>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
+    static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
+    typedef bf16_t T;
+    constexpr int BM = WR * 128, BN = WC * 64, BK = 64, TM = 8, TN = 4;
+    constexpr int A_HALF = WR * 64 * 128, W_HALF = WC * 32 * 128;  // bytes
+    constexpr int BUF = 2 * A_HALF + 2 * W_HALF;
+    constexpr int A_PASS = WR, W_PASS = WC / 2;          // 512-lane LDS-DMA passes (64 rows each) per half-tile
+    constexpr int INFLIGHT = 2 * A_PASS + 2 * W_PASS;    // loads of the four most recent half-tiles
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A0 | A1 | W0 | W1]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC, grp = wave >> 2;
+    const int li = lane & 15, kg = lane >> 4;
+
+    // ---- workgroup -> tile: XCD x gets a contiguous range of tiles (workgroup b runs on XCD b % 8), n fastest, so the
+    //      tiles that share an A row panel / the W panels stay inside one L2 ----
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, ntiles = ntn * ntm;
+    int tile;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = ntiles >> 3, r = ntiles & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+    // ---- staging sources (one 16-byte chunk per lane per pass) ----
+    const int srow = tid >> 3, slot = tid & 7;
+    const int cs_a = slot ^ ((srow >> 1) & 7);
+    const int cs_w = slot ^ ((((srow >> 3) & 3) << 1) | ((srow >> 1) & 1));
+    const char* a_src[A_PASS][2];
+    unsigned a_mask[A_PASS][2];
+    const char* w_src[W_PASS][2];
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int m = m0 + i * 128 + h * 64 + srow;
+            if (m >= p.M) m = p.M - 1;
+            if (MODE == 0) {
+                const long long pm = p.a_gr > 0 ? (long long)(m / p.a_gr) * p.a_gs + p.a_go + (m % p.a_gr) : m;
+                a_src[i][h] = (const char*)((const T*)p.A + pm * p.lda + cs_a * 8);
+                a_mask[i][h] = 0;
+            } else {
+                int wo = m % p.Wo;
+                int r = m / p.Wo;
+                int ho = r % p.Ho;
+                r /= p.Ho;
+                int to = r % p.To;
+                int b = r / p.To;
+                const int ti = to * p.st, hi = ho * p.sh, wi = wo * p.sw;
+                unsigned mask = 0;
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap) {
+                    const int dt = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+                    const bool ok = (unsigned)(ti + dt) < (unsigned)p.Ti && (unsigned)(hi + dh) < (unsigned)p.Hi &&
+                                    (unsigned)(wi + dw) < (unsigned)p.Wi;
+                    mask |= (ok ? 1u : 0u) << tap;
+                }
+                a_mask[i][h] = mask;
+                const long long vox = (((long long)b * p.Ti + ti) * p.Hi + hi) * p.Wi + wi;
+                a_src[i][h] = (const char*)((const T*)p.A + vox * p.Cin + cs_a * 8);
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < W_PASS; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int lr = srow + 64 * i;
+            int n = n0 + (lr >> 5) * 64 + ((lr >> 3) & 3) * 16 + 8 * h + (lr & 7);
+            if (n >= p.N) n = p.N - 1;  // columns past N are computed on a clamped row and never stored
+            w_src[i][h] = (const char*)((const T*)p.W + (long long)n * p.ldw + cs_w * 8);
+        }
+
+    const int nk = (p.K + BK - 1) / BK;
+    const int kpc = (MODE == 1) ? (p.Cin / BK) : 1;
+    const char* zero = (const char*)g_zero_chunk;
+
+    auto stage_a = [&](int h, int kt, int buf) {
+        long long off;
+        int tap = 0;
+        if (MODE == 0) {
+            off = (long long)kt * (BK * 2);
+        } else {
+            tap = kt / kpc;
+            const int ci0 = (kt - tap * kpc) * BK;
+            const int dt = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+            off = ((((long long)dt * p.Hi + dh) * p.Wi + dw) * p.Cin + ci0) * 2;
+        }
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            bool ok;
+            if (MODE == 0)
+                ok = kt * BK + cs_a * 8 < p.K;
+            else
+                ok = kt < nk && ((a_mask[i][h] >> tap) & 1u);
+            const char* src = ok ? a_src[i][h] + off : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * BUF + h * A_HALF + (i * 512 + wave * 64) * 16), 16,
+                                             0, 0);
+        }
+    };
+    auto stage_w = [&](int h, int kt, int buf) {
+        const bool ok = kt * BK + cs_w * 8 < p.K;
+#pragma unroll
+        for (int i = 0; i < W_PASS; ++i) {
+            const char* src = ok ? w_src[i][h] + (long long)kt * (BK * 2) : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src,
+                                             (lptr_t)(smem + buf * BUF + 2 * A_HALF + h * W_HALF + (i * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a half-tile); the k-step's chunk is XORed with the row phase ----
+    const int sw_a = (li >> 1) & 7, sw_w = (((li >> 2) & 3) << 1) | ((li >> 1) & 1);
+    int a_off[2], w_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        a_off[kk] = (wr * 64 + li) * 128 + (((kk * 4 + kg) ^ sw_a) << 4);                        // + ii * 2048
+        w_off[kk] = (wc * 32 + 8 * (li >> 2) + (li & 3)) * 128 + (((kk * 4 + kg) ^ sw_w) << 4);  // + jj * 512
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 xa[4][2], wb[2][2][2];
+
+    auto read_a = [&](int h, int buf) {
+        const char* base = smem + buf * BUF + h * A_HALF;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) xa[ii][kk] = *(const bf16x8*)(base + a_off[kk] + ii * 2048);
+    };
+    auto read_w = [&](int h, int buf) {
+        const char* base = smem + buf * BUF + 2 * A_HALF + h * W_HALF;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) wb[h][jj][kk] = *(const bf16x8*)(base + w_off[kk] + jj * 512);
+    };
+    auto quadrant = [&](int qa, int qw) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[qa * 4 + ii][qw * 2 + jj] = mma16(wb[qw][jj][kk], xa[ii][kk], acc[qa * 4 + ii][qw * 2 + jj]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // end of a phase's read/stage segment: counted wait for the half-tile staged four phases ago, then the barrier
+    auto seg_end = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto phase_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: k-tile 0 complete, A0/W0 of k-tile 1 ----
+    stage_a(0, 0, 0);
+    stage_w(0, 0, 0);
+    stage_w(1, 0, 0);
+    stage_a(1, 0, 0);
+    stage_a(0, 1, 1);
+    stage_w(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");  // A0(0), W0(0) landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto ktile = [&](int t, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value, nxt = cur ^ 1;
+        // P1
+        read_w(0, cur);
+        read_a(0, cur);
+        stage_w(1, t + 1, nxt);
+        seg_end();
+        quadrant(0, 0);
+        phase_end();
+        // P2
+        read_w(1, cur);
+        stage_a(1, t + 1, nxt);
+        seg_end();
+        quadrant(0, 1);
+        phase_end();
+        // P3
+        read_a(1, cur);
+        stage_a(0, t + 2, cur);
+        seg_end();
+        quadrant(1, 1);
+        phase_end();
+        // P4
+        stage_w(0, t + 2, cur);
+        seg_end();
+        quadrant(1, 0);
+        phase_end();
+    };
+    for (int t = 0; t < nk; t += 2) {
+        ktile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nk) ktile(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with the trailing barrier of the delayed group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (only zero-chunk dummies are still in flight)
+
+#ifdef GEMM_DBG_NOEPI  // (tools/probes/gemm_variants.hip: main-loop-only timing)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
+    gemm_epilogue<T, TM, TN, true>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
+#endif
+}

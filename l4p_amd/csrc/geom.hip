@@ -58,7 +58,7 @@ __global__ void affine_apply_kernel(const float* __restrict__ x, float* __restri
 
 int launch_affine_solve(const float* pred, const float* tgt, long long n, int inverse, double* scratch, float* sol,
                         hipStream_t stream) {
-    ProfScope prof(PROF_ELEMENTWISE, stream);
+    ProfScope prof(PROF_ELEMENTWISE, stream, "affine_solve");
     HIP_TRY(hipMemsetAsync(scratch, 0, 6 * sizeof(double), stream));
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(affine_sums_kernel, dim3(grid), dim3(256), 0, stream, pred, tgt, n, inverse, scratch);
@@ -68,7 +68,7 @@ int launch_affine_solve(const float* pred, const float* tgt, long long n, int in
 }
 int launch_affine_apply(const float* x, float* y, long long n, int inverse, const float* sol, hipStream_t stream) {
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    ProfScope prof(PROF_ELEMENTWISE, stream);
+    ProfScope prof(PROF_ELEMENTWISE, stream, "affine_apply");
     hipLaunchKernelGGL(affine_apply_kernel, dim3(grid), dim3(256), 0, stream, x, y, n, inverse, sol);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -251,7 +251,7 @@ int launch_rays_to_pose(const float* rays, const float* K, float* out, int B, in
         l4p_set_error("rays_to_pose: ray map %dx%d larger than 256 rays per frame", h, w);
         return L4P_E_INVALID;
     }
-    ProfScope prof(PROF_ELEMENTWISE, stream);
+    ProfScope prof(PROF_ELEMENTWISE, stream, "rays_to_pose");
     hipLaunchKernelGGL(rays_to_pose_kernel, dim3(B * T), dim3(256), 0, stream, rays, K, out, B, T, h, w, H, W);
     HIP_TRY(hipGetLastError());
     return 0;

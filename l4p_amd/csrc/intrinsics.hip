@@ -347,7 +347,7 @@ int l4p_rays_to_intrinsics(l4p_stream s_, const float* rays, float* out_K, float
         l4p_set_error("rays_to_intrinsics: unsupported ray map %dx%d / frame %d", h, w, t0);
         return L4P_E_INVALID;
     }
-    ProfScope prof(PROF_ELEMENTWISE, s);
+    ProfScope prof(PROF_ELEMENTWISE, s, "l4p_rays_to_intrinsics");
     hipLaunchKernelGGL(rays_to_intrinsics_kernel, dim3(B), dim3(256), 0, s, rays, out_K, diag, T, h, w, H, W, t0, reproj_thr,
                        1e-4f);
     HIP_TRY(hipGetLastError());

@@ -1,6 +1,9 @@
 #include "prof.hpp"
 
+#include <algorithm>
+#include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -11,6 +14,7 @@ namespace {
 struct Pair {
     hipEvent_t a, b;
     int cls;
+    char tag[64];
 };
 std::mutex g_mu;
 std::vector<Pair> g_pairs;      // recorded this session
@@ -29,9 +33,10 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-void prof_begin(int cls, hipStream_t stream) {
+void prof_begin(int cls, hipStream_t stream, const char* tag) {
     std::lock_guard<std::mutex> lk(g_mu);
-    Pair p{get_event(), get_event(), cls};
+    Pair p{get_event(), get_event(), cls, {0}};
+    if (tag) snprintf(p.tag, sizeof p.tag, "%s", tag);
     (void)hipEventRecord(p.a, stream);
     g_pairs.push_back(p);
 }
@@ -80,5 +85,29 @@ int l4p_prof_read(int cls, double* total_ms, long long* count) {
     if (total_ms) *total_ms = t;
     if (count) *count = n;
     return 0;
+}
+// Per-(class, tag) table of the event pairs since the last reset, as text lines "class<TAB>tag<TAB>count<TAB>total_ms",
+// sorted by total time.  Returns the number of bytes needed (including the terminator); writes at most cap bytes.
+long long l4p_prof_detail(char* buf, long long cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::map<std::string, std::pair<long long, double>> agg;
+    for (auto& p : g_pairs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) continue;
+        auto& e = agg[std::string(kNames[p.cls]) + "\t" + p.tag];
+        e.first++;
+        e.second += ms;
+    }
+    std::vector<std::pair<double, std::string>> rows;
+    for (auto& kv : agg) {
+        char line[192];
+        snprintf(line, sizeof line, "%s\t%lld\t%.4f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        rows.emplace_back(-kv.second.second, line);
+    }
+    std::sort(rows.begin(), rows.end());
+    std::string out;
+    for (auto& r : rows) out += r.second;
+    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", out.c_str());
+    return (long long)out.size() + 1;
 }
 }

@@ -3,6 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdarg>
+#include <cstdio>
+
 enum ProfClass {
     PROF_GEMM = 0,      // gemm_kernel<..., MODE 0>: linears, 1x1x1 convs, ConvTranspose-as-GEMM
     PROF_CONV3D,        // gemm_kernel<..., MODE 1>: implicit-GEMM 3x3x3 conv
@@ -13,7 +16,7 @@ enum ProfClass {
     PROF_NUM
 };
 
-void prof_begin(int cls, hipStream_t stream);
+void prof_begin(int cls, hipStream_t stream, const char* tag = nullptr);
 void prof_end(int cls, hipStream_t stream);
 extern bool g_prof_on;
 
@@ -22,6 +25,16 @@ struct ProfScope {
     hipStream_t s;
     ProfScope(int c, hipStream_t st) : cls(c), s(st) {
         if (g_prof_on) prof_begin(cls, s);
+    }
+    // tagged form: the printf-style tag (e.g. the GEMM shape) keys the per-tag table of l4p_prof_detail()
+    ProfScope(int c, hipStream_t st, const char* fmt, ...) __attribute__((format(printf, 4, 5))) : cls(c), s(st) {
+        if (!g_prof_on) return;
+        char tag[64];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(tag, sizeof tag, fmt, ap);
+        va_end(ap);
+        prof_begin(cls, s, tag);
     }
     ~ProfScope() {
         if (g_prof_on) prof_end(cls, s);

@@ -533,7 +533,7 @@ int launch_track_tokens(const float* queries, const float* labels, const float* 
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
                         int W, hipStream_t stream) {
-    ProfScope prof(PROF_TRACK, stream);
+    ProfScope prof(PROF_TRACK, stream, "track_tokens");
     hipLaunchKernelGGL(track_tokens_kernel, dim3(N), dim3(256), 0, stream, queries, labels, pfeat, plabel, gauss,
                        mask_tokens, pe0, pe1, nap, fe0, fe1, tokens, N, C, (float)T, (float)H, (float)W);
     HIP_TRY(hipGetLastError());
@@ -547,7 +547,7 @@ int launch_track_keys_init(int dtype, const float* enc, const float* hist, const
         return L4P_E_INVALID;
     }
     const long long per_q8 = (long long)P * C / 8, total8 = per_q8 * N;
-    ProfScope prof(PROF_TRACK, stream);
+    ProfScope prof(PROF_TRACK, stream, "track_keys_init");
     if (dtype == L4P_BF16)
         hipLaunchKernelGGL(track_keys_init_kernel<bf16_t>, dim3(GRID1D(total8, 16384)), dim3(256), 0, stream, enc, hist,
                            pos, k32, (bf16_t*)kT, (bf16_t*)kP, per_q8, total8);
@@ -560,7 +560,7 @@ int launch_track_keys_init(int dtype, const float* enc, const float* hist, const
 
 int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
                      long long group_off, hipStream_t stream) {
-    ProfScope prof(PROF_TRACK, stream);
+    ProfScope prof(PROF_TRACK, stream, "fill_rows");
     hipLaunchKernelGGL(fill_rows_kernel, dim3(GRID1D(rows * (C / 4), 16384)), dim3(256), 0, stream, out, v, rows, C,
                        group_rows, group_stride, group_off);
     HIP_TRY(hipGetLastError());
@@ -575,7 +575,7 @@ int launch_small_attn(int dtype, int kind, const void* q, const void* k, const v
         l4p_set_error("small_attn: unsupported head geometry D=%d heads=%d", D, heads);
         return L4P_E_INVALID;
     }
-    ProfScope prof(PROF_TRACK, stream);
+    ProfScope prof(PROF_TRACK, stream, "small_attn kind%d N%d P%d D%d", kind, N, P, D);
     if (kind == 0) {  // 6 x 6 self attention
         if (dtype == L4P_BF16)
             hipLaunchKernelGGL(self_attn6_kernel<bf16_t>, dim3(N, heads), dim3(64), 0, stream, (const bf16_t*)q,
@@ -621,7 +621,7 @@ int launch_mask_product(int dtype, const void* up, const float* hyper, float* ma
     }
     const dim3 grid(GRID1D(vox, 1024), N);
     const size_t lds = (size_t)3 * Cc * 4;
-    ProfScope prof(PROF_TRACK, stream);
+    ProfScope prof(PROF_TRACK, stream, "mask_product");
     if (dtype == L4P_BF16)
         hipLaunchKernelGGL(mask_product_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)up, hyper, masks, vox, Cc);
     else
@@ -633,7 +633,7 @@ int launch_mask_product(int dtype, const void* up, const float* hyper, float* ma
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
                          int W, hipStream_t stream) {
     const size_t lds = (size_t)3 * h * w * 4;
-    ProfScope prof(PROF_TRACK, stream);
+    ProfScope prof(PROF_TRACK, stream, "track_readout");
     hipLaunchKernelGGL(track_readout_kernel, dim3(N * T), dim3(256), lds, stream, masks, traj, vis, depth, T, h, w, H, W);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -641,7 +641,7 @@ int launch_track_readout(const float* masks, float* traj, float* vis, float* dep
 
 int launch_track_prepare(const float* cur_q, const float* orig_q, int start, int ws, float* q_off, float* labels,
                          unsigned char* valid_t, unsigned char* valid_n, int N, hipStream_t stream) {
-    ProfScope prof(PROF_TRACK, stream);
+    ProfScope prof(PROF_TRACK, stream, "track_prepare");
     hipLaunchKernelGGL(track_prepare_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, cur_q, orig_q, start, ws, q_off,
                        labels, valid_t, valid_n, N);
     HIP_TRY(hipGetLastError());
@@ -652,7 +652,7 @@ int launch_track_commit(const float* w_traj, const float* w_vis, const float* w_
                         const unsigned char* valid_n, float* traj, float* vis, float* depth, int T, int start, int ws,
                         int next_start, int last_window, float* cur_q, float* plabel, const float* new_pfeat, float* pfeat,
                         int* best_out, int N, int C, hipStream_t stream) {
-    ProfScope prof(PROF_TRACK, stream);
+    ProfScope prof(PROF_TRACK, stream, "track_commit");
     hipLaunchKernelGGL(track_commit_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, w_traj, w_vis, w_depth, valid_t,
                        valid_n, traj, vis, depth, T, start, ws, next_start, last_window, cur_q, plabel, best_out, N);
     if (!last_window && new_pfeat && pfeat)

@@ -341,7 +341,7 @@ extern "C" {
 /* approx. q-quantile of n non-negative floats (4096-bin histogram). ws: >= 4098 uints. */
 int l4p_quantile(l4p_stream s_, const float* x, long long n, float q, unsigned* ws, float* out) {
     hipStream_t s = (hipStream_t)s_;
-    ProfScope prof(PROF_ELEMENTWISE, s);
+    ProfScope prof(PROF_ELEMENTWISE, s, "l4p_quantile");
     HIP_TRY(hipMemsetAsync(ws, 0xFF, 4, s));
     HIP_TRY(hipMemsetAsync(ws + 1, 0, 4097 * 4, s));
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
@@ -356,7 +356,7 @@ int l4p_point_map_samples(l4p_stream s_, const float* depth, const float* K, con
                           int ratio, unsigned seed) {
     hipStream_t s = (hipStream_t)s_;
     const int spf = (H * W) / ratio;
-    ProfScope prof(PROF_ELEMENTWISE, s);
+    ProfScope prof(PROF_ELEMENTWISE, s, "l4p_point_map_samples");
     hipLaunchKernelGGL(pointmap_kernel, dim3((F * spf + 255) / 256), dim3(256), 0, s, depth, K, P, out, F, H, W, ratio, seed, spf);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -371,7 +371,7 @@ int l4p_similarity_ransac(l4p_stream s_, const float* src, const float* dst, int
         l4p_set_error("similarity_ransac: bad arguments n=%d min_samples=%d trials=%d", n, min_samples, trials);
         return L4P_E_INVALID;
     }
-    ProfScope prof(PROF_ELEMENTWISE, s);
+    ProfScope prof(PROF_ELEMENTWISE, s, "l4p_similarity_ransac");
     float* scores = ws;
     float* models = ws + 2 * trials;
     hipLaunchKernelGGL(ransac_trials_kernel, dim3(trials), dim3(256), 0, s, src, dst, n, q98, thr_rel, min_samples, seed, scores,
@@ -384,7 +384,7 @@ int l4p_similarity_ransac(l4p_stream s_, const float* src, const float* dst, int
 /* apply: pose [16][T] <- T pose with the rotation block divided by s; depth (n floats) *= s */
 int l4p_similarity_apply(l4p_stream s_, const float* sim, float* pose, int T, float* depth, long long n) {
     hipStream_t s = (hipStream_t)s_;
-    ProfScope prof(PROF_ELEMENTWISE, s);
+    ProfScope prof(PROF_ELEMENTWISE, s, "l4p_similarity_apply");
     hipLaunchKernelGGL(similarity_apply_pose_kernel, dim3((T + 63) / 64), dim3(64), 0, s, sim, pose, T);
     if (depth && n > 0) {
         const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

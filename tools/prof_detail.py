@@ -1,0 +1,51 @@
+"""Per-shape kernel time table for one bench workload (event profiler, l4p_prof_detail).
+usage: python tools/prof_detail.py [c2|c3] [steps]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from l4p_amd import _lib
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    tasks = ["depth"] if wl == "c2" else list(bench.ALL_TASKS)
+    B = 1 if wl == "c2" else 4
+    model, data, _ = bench.build_workload(tasks, B, 64, dev)
+    lib = _lib.load()
+
+    def run():
+        with torch.no_grad():
+            return model.forward(data, tasks)
+
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    lib.l4p_prof_reset()
+    lib.l4p_prof_enable(1)
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    lib.l4p_prof_enable(0)
+    n = lib.l4p_prof_detail(None, 0)
+    buf = C.create_string_buffer(int(n))
+    lib.l4p_prof_detail(buf, n)
+    tot = 0.0
+    print(f"{'class':12s} {'tag':48s} {'n/step':>7s} {'ms/step':>9s} {'us/launch':>10s}")
+    for line in buf.value.decode().splitlines():
+        cls, tag, cnt, ms = line.split("\t")
+        cnt, ms = int(cnt) / steps, float(ms) / steps
+        tot += ms
+        print(f"{cls:12s} {tag:48s} {cnt:7.1f} {ms:9.3f} {ms / cnt * 1e3:10.1f}")
+    print(f"total {tot:.3f} ms/step")
+
+
+if __name__ == "__main__":
+    main()
