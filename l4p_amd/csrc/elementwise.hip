@@ -19,24 +19,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (row >= M) return;
     const int nv = C >> 2;
     const f32x4* xr = (const f32x4*)(x + (long long)row * C);
-    f32x4 v[MAXV];
-    float s = 0.f;
+    const f32x4* ar = out_T2 ? (const f32x4*)(add + (long long)(row % add_mod) * C) : nullptr;
+    // every load of the row is issued up front (x, gamma, beta, the optional addend): ONE exposed memory round trip per
+    // row instead of three dependent ones (x -> statistics -> gamma/beta/add) - the kernel is latency-, not bandwidth-bound
+    f32x4 v[MAXV], g[MAXV], bb[MAXV], av[MAXV];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + i * 64;
-        if (idx < nv) {
-            v[i] = xr[idx];
-            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        } else {
-            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        const bool in = idx < nv;
+        v[i] = in ? xr[idx] : z;
+        g[i] = in ? ((const f32x4*)gamma)[idx] : z;
+        bb[i] = in ? ((const f32x4*)beta)[idx] : z;
+        av[i] = (in && ar) ? ar[idx] : z;
     }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + i * 64;
-        if (idx < nv) {
+        if (lane + i * 64 < nv) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float d = v[i][k] - mean;
@@ -49,25 +53,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + i * 64;
         if (idx < nv) {
-            const f32x4 g = ((const f32x4*)gamma)[idx], bb = ((const f32x4*)beta)[idx];
             f32x4 y;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd * g[k] + bb[k];
+            for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd * g[i][k] + bb[i][k];
             if (act == L4P_ACT_GELU) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) y[k] = gelu_erf(y[k]);
             }
             if (out_T2) {  // T(y + add[row % add_mod]): the "+ positional / + prompt token" operand of the tracker
-                const f32x4 a = ((const f32x4*)(add + (long long)(row % add_mod) * C))[idx];
                 if (sizeof(T) == 2) {
                     bf16x4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (bf16_t)(y[k] + a[k]);
+                    for (int k = 0; k < 4; ++k) o[k] = (bf16_t)(y[k] + av[i][k]);
                     ((bf16x4*)((bf16_t*)out_T2 + (long long)row * C))[idx] = o;
                 } else {
                     f32x4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = y[k] + a[k];
+                    for (int k = 0; k < 4; ++k) o[k] = y[k] + av[i][k];
                     ((f32x4*)((float*)out_T2 + (long long)row * C))[idx] = o;
                 }
             }
@@ -86,6 +88,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+template <typename T, int MAXV>
+static void launch_ln_t(const float* x, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M,
+                        int C, const float* add, int add_mod, void* out_T2, int act, hipStream_t stream) {
+    hipLaunchKernelGGL((layernorm_kernel<T, MAXV>), dim3((M + 3) / 4), dim3(256), 0, stream, x, gamma, beta, eps, (T*)out_T, out_f32,
+                       M, C, add, add_mod, (T*)out_T2, act);
+}
+template <typename T>
+static void launch_ln(const float* x, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M, int C,
+                      const float* add, int add_mod, void* out_T2, int act, hipStream_t stream) {
+    // float4 slots per lane: 2 covers C <= 512 (DPT / tracker up-scaling), 6 the 1408-wide streams, 8 the 2048 limit
+    if (C <= 512)
+        launch_ln_t<T, 2>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
+    else if (C <= 1536)
+        launch_ln_t<T, 6>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
+    else
+        launch_ln_t<T, 8>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
+}
+
 int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const float* beta, float eps, void* out_T,
                         float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act,
                         hipStream_t stream) {
@@ -93,14 +113,11 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
         l4p_set_error("layernorm: C=%d must be a multiple of 4 and <= 2048 (and out_T2 needs add/add_mod)", C);
         return L4P_E_INVALID;
     }
-    const dim3 grid((M + 3) / 4), block(256);
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d add%d T2%d act%d f32%d", M, C, add != nullptr, out_T2 != nullptr, act, out_f32 != nullptr);
     if (dtype == L4P_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8>), grid, block, 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                           out_f32, M, C, add, add_mod, (bf16_t*)out_T2, act);
+        launch_ln<bf16_t>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
     else
-        hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, block, 0, stream, x, gamma, beta, eps, (float*)out_T,
-                           out_f32, M, C, add, add_mod, (float*)out_T2, act);
+        launch_ln<float>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
     HIP_TRY(hipGetLastError());
     return 0;
 }
