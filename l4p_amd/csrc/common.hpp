@@ -47,6 +47,22 @@ template <typename T> __device__ __forceinline__ float to_f32(T v) { return (flo
 
 // exact (erf) GELU, matches torch.nn.GELU() default
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// The same GELU for the bf16 engine, branch free and ~3x fewer VALU slots than erff (which runs both of its divergent
+// branches in every wave): erfc by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the bf16 rounding of the
+// operands and of the stored result), evaluated on the erfc side so the negative tail has no 1 - erf cancellation.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    const float pe = poly * t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);  // erfc(|x| / sqrt 2)
+    return 0.5f * x * (x >= 0.f ? 2.0f - pe : pe);
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float x);  // GELU at the precision of engine dtype T
+template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_for<bf16_t>(float x) { return gelu_erf_fast(x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd * g[i][k] + bb[i][k];
             if (act == L4P_ACT_GELU) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = gelu_erf(y[k]);
+                for (int k = 0; k < 4; ++k) y[k] = gelu_for<T>(y[k]);
             }
             if (out_T2) {  // T(y + add[row % add_mod]): the "+ positional / + prompt token" operand of the tracker
                 if (sizeof(T) == 2) {

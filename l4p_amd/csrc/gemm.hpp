@@ -132,7 +132,7 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
             for (int q = 0; q < 8; ++q) vv[q] += bv[g8 + q];
             if (p.act == ACT_GELU) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) vv[q] = gelu_erf(vv[q]);
+                for (int q = 0; q < 8; ++q) vv[q] = gelu_for<T>(vv[q]);
             } else if (p.act == ACT_RELU) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) vv[q] = fmaxf(vv[q], 0.0f);
