@@ -34,7 +34,8 @@ __device__ __attribute__((aligned(16))) static const unsigned g_zero_chunk[4] = 
 //      columns n_wave0 + 4*TN*kg + [0, 4*TN) of its wave's tile (acc[i][j][r] = column 4*TN*kg + 4*j + r) -------------
 // One row (16*i + li) of the lane's tile: bias, activation, residuals, scatter / store.
 template <typename T, int NV>
-__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v)[NV], const float (&bv)[NV], int m, int nb);
+__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v)[NV], const float (&bv)[NV],
+                                                  const long long (&coff)[NV / 8], int m, int nb);
 
 // ROLLED = false: the row loop is fully unrolled (registers die row by row: 120 VGPRs for the 128x128 kernel, which
 // keeps 2-3 workgroups per CU).  ROLLED = true (gemm8p.hpp, alone on its CU with registers to spare): the row body -
@@ -60,6 +61,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             bv[g8 + 4 + q] = b1[q];
         }
     }
+    // column part of the output offset (row independent: the ConvTranspose tap decomposition costs five integer
+    // divisions, which used to be repeated for every row)
+    long long coff[NV / 8];
+#pragma unroll
+    for (int g8 = 0; g8 < NV; g8 += 8) {
+        const int n = nb + g8;
+        if (p.epi == EPI_CONVT) {
+            const int tap = n / p.Cout, co = n - tap * p.Cout;
+            const int dw = tap % p.kw, dh = (tap / p.kw) % p.kh, dt = tap / (p.kw * p.kh);
+            coff[g8 / 8] = (((long long)dt * (p.Hi * p.kh) + dh) * (p.Wi * p.kw) + dw) * p.Cout + co;
+        } else {
+            coff[g8 / 8] = n;
+        }
+    }
     if (ROLLED) {
 #pragma nounroll
         for (int i = 0; i < TM; ++i) {
@@ -77,7 +92,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #undef L4P_ACC_ROW
             static_assert(TM <= 8, "extend the accumulator row switch");
             const int m = m_wave0 + i * 16 + li;
-            if (m < p.M) gemm_epilogue_row<T, NV>(p, v, bv, m, nb);
+            if (m < p.M) gemm_epilogue_row<T, NV>(p, v, bv, coff, m, nb);
         }
     } else {
 #pragma unroll
@@ -88,13 +103,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
             const int m = m_wave0 + i * 16 + li;
-            if (m < p.M) gemm_epilogue_row<T, NV>(p, v, bv, m, nb);
+            if (m < p.M) gemm_epilogue_row<T, NV>(p, v, bv, coff, m, nb);
         }
     }
 }
 
 template <typename T, int NV>
-__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v)[NV], const float (&bv)[NV], int m, int nb) {
+__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v)[NV], const float (&bv)[NV],
+                                                  const long long (&coff)[NV / 8], int m, int nb) {
     constexpr int ES = sizeof(T);
     {
         // float residuals of the whole row segment, loaded before any of its outputs is stored (in-place updates alias)
@@ -123,6 +139,19 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
                 }
             }
         }
+        // row part of the output offset
+        long long rowoff;
+        if (p.epi == EPI_CONVT) {
+            const int wi = m % p.Wi;
+            int r = m / p.Wi;
+            const int hi = r % p.Hi;
+            r /= p.Hi;
+            const int ti = r % p.Ti, b = r / p.Ti;
+            rowoff = ((((long long)b * p.Ti + ti) * p.kt * (p.Hi * p.kh) + hi * p.kh) * (p.Wi * p.kw) + wi * p.kw) * p.Cout;
+        } else {
+            const long long pm = p.c_gr > 0 ? (long long)(m / p.c_gr) * p.c_gs + p.c_go + (m % p.c_gr) : m;
+            rowoff = pm * p.ldc;
+        }
 #pragma unroll
         for (int g8 = 0; g8 < NV; g8 += 8) {
             const int n = nb + g8;
@@ -137,25 +166,7 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
 #pragma unroll
                 for (int q = 0; q < 8; ++q) vv[q] = fmaxf(vv[q], 0.0f);
             }
-            // output / residual addressing
-            long long off;  // element offset for dense-style addressing
-            if (p.epi == EPI_CONVT) {
-                const int tap = n / p.Cout, co = n - tap * p.Cout;
-                const int dw = tap % p.kw, dh = (tap / p.kw) % p.kh, dt = tap / (p.kw * p.kh);
-                int wi = m % p.Wi;
-                int r = m / p.Wi;
-                int hi = r % p.Hi;
-                r /= p.Hi;
-                int ti = r % p.Ti;
-                int b = r / p.Ti;
-                const long long vox =
-                    (((long long)b * p.Ti * p.kt + (ti * p.kt + dt)) * (p.Hi * p.kh) + (hi * p.kh + dh)) * (p.Wi * p.kw) +
-                    (wi * p.kw + dw);
-                off = vox * p.Cout + co;
-            } else {
-                const long long pm = p.c_gr > 0 ? (long long)(m / p.c_gr) * p.c_gs + p.c_go + (m % p.c_gr) : m;
-                off = pm * p.ldc + n;
-            }
+            const long long off = rowoff + coff[g8 / 8];  // element offset of the 8 outputs
             if (res32) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) vv[q] += rv[g8 + q];

@@ -5,7 +5,7 @@
 #include <cstdarg>
 #include <vector>
 bool g_prof_on = false;
-void prof_begin(int, hipStream_t) {}
+void prof_begin(int, hipStream_t, const char*) {}
 void prof_end(int, hipStream_t) {}
 void l4p_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); }
 #include "../../l4p_amd/csrc/attention.hip"
