@@ -156,6 +156,67 @@ __global__ __launch_bounds__(256) void head_out_kernel(const T* __restrict__ x, 
     }
 }
 
+// LDS-staged form used when C * sizeof(T) == 256 (the bf16 engine): the workgroup copies 256 voxel rows (64 KB, one
+// contiguous span) into LDS with coalesced 16-byte LDS-DMA, XOR-swizzled through the SOURCE chunk (LDS chunk q of row r
+// holds source chunk q ^ (r & 15)) so the row-per-thread reads that follow are conflict-free.  The direct form above
+// reads 16 bytes per lane at a 256-byte stride (64 lines per load instruction, 1.4 TB/s measured).  Same summation order.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void head_out_lds_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           long long vox_per_b, int B, int Cout, int post_exp) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int ROWB = C * (int)sizeof(T), CPR = ROWB / 16;  // bytes / 16-byte chunks per row
+    static_assert(CPR == 16, "swizzle below assumes 16 chunks per row");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ws = (float*)smem;             // [8][C] + 8 bias
+    char* tile = smem + (8 * C + 8) * 4;  // [256][ROWB]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < Cout * C; i += 256) ws[i] = w[i];
+    if (tid < Cout) ws[8 * C + tid] = bias[tid];
+    const long long total = vox_per_b * B;
+    const long long m0 = (long long)blockIdx.x * 256;
+    const int nrow = (int)(total - m0 < 256 ? total - m0 : 256);
+    // pass i stages rows i*16 .. i*16+15: thread -> (row = i*16 + tid/16, LDS chunk q = tid%16) <- source chunk q ^ (row & 15)
+    const int q = tid & 15, r16 = tid >> 4;
+    for (int i = 0; i < 16; ++i) {
+        const int row = i * 16 + r16;
+        if (row < nrow)
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)x + (m0 + row) * ROWB + ((q ^ (row & 15)) << 4)),
+                                             (lptr_t)(tile + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+    __syncthreads();
+    if (tid >= nrow) return;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    const char* xr = tile + tid * ROWB;
+#pragma unroll 4
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        const char* cp = xr + ((((c0 * (int)sizeof(T)) >> 4) ^ (tid & 15)) << 4);  // (bf16: one chunk = 8 channels)
+        float v[8];
+        const bf16x8 t = *(const bf16x8*)cp;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < Cout) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[o] += v[k] * ws[o * C + c0 + k];
+            }
+    }
+    const long long m = m0 + tid;
+    const long long b = m / vox_per_b, v = m - b * vox_per_b;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+        if (o < Cout) {
+            float r = acc[o] + ws[8 * C + o];
+            if (post_exp) r = expf(r);
+            y[(b * Cout + o) * vox_per_b + v] = r;
+        }
+}
+
 int launch_head_out(int dtype, const void* x, const float* w, const float* bias, float* y, long long vox_per_b, int B,
                     int C, int Cout, int post_exp, hipStream_t stream) {
     if (C != 128 || Cout < 1 || Cout > 8) {
@@ -165,10 +226,13 @@ int launch_head_out(int dtype, const void* x, const float* w, const float* bias,
     const long long total = vox_per_b * B;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     ProfScope prof(PROF_ELEMENTWISE, stream, "head_out");
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL((head_out_kernel<bf16_t, 128>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, w, bias, y,
-                           vox_per_b, B, Cout, post_exp);
-    else
+    if (dtype == L4P_BF16) {
+        auto kern = head_out_lds_kernel<bf16_t, 128>;
+        const size_t lds = (8 * 128 + 8) * 4 + 256 * 256;
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, stream, (const bf16_t*)x, w, bias, y, vox_per_b,
+                           B, Cout, post_exp);
+    } else
         hipLaunchKernelGGL((head_out_kernel<float, 128>), dim3(grid), dim3(256), 0, stream, (const float*)x, w, bias, y,
                            vox_per_b, B, Cout, post_exp);
     HIP_TRY(hipGetLastError());
