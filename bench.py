@@ -248,10 +248,20 @@ def main():
                 "conv3d": "gemm8p_kernel<1> / gemm_kernel<bf16,MODE1> (implicit-GEMM 3x3x3 conv)",
                 "attention": "attn_kernel<bf16,96,64>"}
 
+        # HBM bytes per launch of the class from the committed PMC passes (profiles/r01_c3_hbm_traffic.*: rocprofv3
+        # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate passes); PMC cannot be collected from inside this
+        # process, so the figure is the one measured on the same command and is only attached to the workload it was taken on
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_c3_hbm_traffic.json")
+        if args.workload == "c3" and B == 4 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = {k: v["hbm_total"] for k, v in json.load(f)["per_class_bytes_per_launch"].items()}
+
         def roof(k):
             a = classes[k]["tflops"]
             return {"kernel": kern[k], "bound": "mfma", "achieved": a, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
-                    "frac": round(a / (PEAK_BF16_MFMA / 1e12), 4), "traffic": None,
+                    "frac": round(a / (PEAK_BF16_MFMA / 1e12), 4), "traffic": traffic.get(k),
+                    "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c3_hbm_traffic.md)",
                     "method": "algorithmic FLOPs / HIP-event-bracketed kernel time, second pass of the same K steps",
                     "avg_launch_us": classes[k]["avg_launch_us"], "launches_per_step": classes[k]["launches_per_step"],
                     "algorithmic_flops_per_step": fl[k] * B}

@@ -251,6 +251,29 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
     }
 }
 
+// Tile walk of the implicit-GEMM conv.  Every input voxel feeds 27 taps; with workgroups handed out in plain row order
+// over eight XCDs the three t-planes a tile touches are 2 x (Ho*Wo*Cin) bytes apart and each XCD's 4 MB L2 re-fetched
+// them from HBM (PMC: 7.9 GB read per launch of the 16x224x224x128 conv against 0.8 GB of input).  Here an XCD owns a
+// contiguous range of tiles (the caller's XCD remap) and position n of the walk is the m-tile
+//   (b, band, t, i):  i fastest inside a band of BT tiles (a few image rows), then t, then the next band
+// so the rows of planes t-1 / t / t+1 that a band needs are still in L2 when the walk moves to t+1.
+__device__ __forceinline__ int conv_tile_walk(const GemmParams& p, int n, int BM, int es) {
+    const int P = p.Ho * p.Wo;  // output voxels per (b, t) plane
+    if (P % BM) return n;
+    const int TP = P / BM;
+    const long long tile_bytes = (long long)BM * p.sh * p.sw * p.Cin * es;
+    int bt = (int)((2ll << 20) / 3 / (tile_bytes > 0 ? tile_bytes : 1));
+    if (bt > TP) bt = TP;
+    if (bt < 1) bt = 1;
+    while (TP % bt) --bt;  // largest divisor of TP that keeps three planes of a band within ~2 MB
+    const int i = n % bt;
+    int r = n / bt;
+    const int t = r % p.To;
+    r /= p.To;
+    const int band = r % (TP / bt), b = r / (TP / bt);
+    return (b * p.To + t) * TP + band * bt + i;
+}
+
 // GLDS = true: tiles are staged with global_load_lds (LDS-DMA, no VGPR round trip, no ds_write); the LDS image is
 // lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk and again on the fragment reads.
 // GLDS = false: global -> register -> ds_write staging (needed for the fused input ReLU of the conv loader).
@@ -280,8 +303,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = (p.N + BN - 1) / BN;
     const int ntiles = ntn * ((p.M + BM - 1) / BM);
-    const int ksplit = blockIdx.x / ntiles, tile = blockIdx.x - ksplit * ntiles;  // split-K slice of this workgroup
-    const int mt = tile / ntn, nt = tile % ntn;
+    const int ksplit = blockIdx.x / ntiles;  // split-K slice of this workgroup
+    int tile = blockIdx.x - ksplit * ntiles;
+    if (MODE == 1 && p.splitk <= 1) {  // conv: XCD-contiguous tile ranges (workgroup b runs on XCD b % 8)
+        const int xcd = tile & 7, idx = tile >> 3, q = ntiles >> 3, r = ntiles & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int mt = tile / ntn;
+    const int nt = tile % ntn;
+    if (MODE == 1 && p.splitk <= 1) mt = conv_tile_walk(p, mt, BM, ES);
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int crow = tid >> 3, cc = tid & 7;  // this thread's (row, LDS slot) inside a staging pass

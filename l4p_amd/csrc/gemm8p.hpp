@@ -50,7 +50,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = ntiles >> 3, r = ntiles & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    int mt = tile / ntn;
+    if (MODE == 1) mt = conv_tile_walk(p, mt, BM, 2);
+    const int m0 = mt * BM, n0 = (tile % ntn) * BN;
 
     // ---- staging sources (one 16-byte chunk per lane per pass) ----
     const int srow = tid >> 3, slot = tid & 7;
