@@ -230,7 +230,9 @@ int l4p_fill_rows(l4p_stream stream, float* out, const float* v, long long rows,
 
 /* Attention of sam/transformer.py:223-245 after the projections. kind 0: 6 prompt tokens among themselves
  * (q,k,v,out [N][6][D]); kind 1: tokens -> image (q [N][6][D], k,v [N][P][D], out [N][6][D]);
- * kind 2: image -> tokens (q [N][P][D], k,v [N][6][D], out [N][P][D]). */
+ * kind 2: image -> tokens (q [N][P][D], k,v [N][6][D], out [N][P][D]);
+ * kind 3 / 4: kinds 1 / 2 when every track still has the SAME image-side operand (first window, first layer: the
+ * keys have not been touched by a query yet): k,v [P][D] resp. q [P][D] are shared, outputs stay per track. */
 int l4p_small_attn(l4p_stream stream, int dtype, int kind, const void* q, const void* k, const void* v, void* out,
                    int N, int P, int D, int heads);
 

@@ -182,15 +182,15 @@ __global__ __launch_bounds__(64) void self_attn6_kernel(const T* __restrict__ q,
 template <typename T>
 __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, T* __restrict__ out, int P, int D, int hd,
-                                                       float scale) {
+                                                       float scale, long long kv_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = (float*)smem;      // [6][P]
     float* qs = sc + 6 * P;        // [6][hd]
     float* red = qs + 6 * 96;      // [256] scratch, later [ngroups][6][hd]
     const int n = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
     const T* qp = q + (long long)n * 6 * D + (long long)h * hd;
-    const T* kp = k + (long long)n * P * D + (long long)h * hd;
-    const T* vp = v + (long long)n * P * D + (long long)h * hd;
+    const T* kp = k + (long long)n * kv_stride + (long long)h * hd;  // kv_stride = P*D, or 0 when every query shares K / V
+    const T* vp = v + (long long)n * kv_stride + (long long)h * hd;
     for (int i = tid; i < 6 * hd; i += 256) qs[(i / hd) * 96 + (i % hd)] = (float)qp[(long long)(i / hd) * D + (i % hd)];
     __syncthreads();
     // scores
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, 
 template <typename T>
 __global__ __launch_bounds__(256) void i2t_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, T* __restrict__ out, int P, int D, int hd,
-                                                       int heads, float scale) {
+                                                       int heads, float scale, long long q_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ks = (float*)smem;  // [6][D]
     float* vs = ks + 6 * D;    // [6][D]
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void i2t_attn_kernel(const T* __restrict__ q, 
     const int work = blockIdx.x * 256 + tid;  // (p, h)
     if (work >= P * heads) return;
     const int p = work / heads, h = work % heads;
-    const T* qp = q + ((long long)n * P + p) * D + (long long)h * hd;
+    const T* qp = q + (long long)n * q_stride + (long long)p * D + (long long)h * hd;  // q_stride = P*D, or 0 (shared queries)
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int d0 = 0; d0 < hd; d0 += 4) {
         float qv[4];
@@ -583,7 +583,8 @@ int launch_small_attn(int dtype, int kind, const void* q, const void* k, const v
         else
             hipLaunchKernelGGL(self_attn6_kernel<float>, dim3(N, heads), dim3(64), 0, stream, (const float*)q,
                                (const float*)k, (const float*)v, (float*)out, D, hd, scale);
-    } else if (kind == 1) {  // tokens -> image
+    } else if (kind == 1 || kind == 3) {  // tokens -> image (3: one K / V set shared by every query)
+        const long long kv_stride = kind == 1 ? (long long)P * D : 0;
         const int ncg = hd / 4, nkg = 256 / ncg;
         size_t lds = (size_t)(6 * P + 6 * 96 + 256) * 4;
         const size_t need2 = (size_t)nkg * 6 * hd * 4;
@@ -593,21 +594,22 @@ int launch_small_attn(int dtype, int kind, const void* q, const void* k, const v
         if (dtype == L4P_BF16) {
             HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kb, dim3(N, heads), dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, scale);
+                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, scale, kv_stride);
         } else {
             HIP_TRY(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kf, dim3(N, heads), dim3(256), lds, stream, (const float*)q, (const float*)k,
-                               (const float*)v, (float*)out, P, D, hd, scale);
+                               (const float*)v, (float*)out, P, D, hd, scale, kv_stride);
         }
-    } else {  // image -> tokens
+    } else if (kind == 2 || kind == 4) {  // image -> tokens (4: one query set shared by every track)
+        const long long q_stride = kind == 2 ? (long long)P * D : 0;
         const size_t lds = (size_t)12 * D * 4;
         const dim3 grid((P * heads + 255) / 256, N);
         if (dtype == L4P_BF16)
             hipLaunchKernelGGL(i2t_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, heads, scale);
+                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, heads, scale, q_stride);
         else
             hipLaunchKernelGGL(i2t_attn_kernel<float>, grid, dim3(256), lds, stream, (const float*)q, (const float*)k,
-                               (const float*)v, (float*)out, P, D, hd, heads, scale);
+                               (const float*)v, (float*)out, P, D, hd, heads, scale, q_stride);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -22,7 +22,7 @@ from ...ops import _p, _stream
 
 def _gemm(a: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, n: int, *, bias=None, act=ACT_NONE, res1=None,
           out_f32: Optional[torch.Tensor] = None, out_T: Optional[torch.Tensor] = None, ldc: Optional[int] = None,
-          a_map=None, c_map=None, a_off: int = 0, f32_off: int = 0) -> None:
+          a_map=None, c_map=None, a_off: int = 0, f32_off: int = 0, res_mod: int = 0) -> None:
     """Raw l4p_gemm call with explicit strides / row maps (see include/l4p_hip.h)."""
     d = GemmDesc()
     es = a.element_size()
@@ -30,7 +30,7 @@ def _gemm(a: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, n: int, *,
     d.M, d.N, d.K = M, n, K
     d.bias, d.act = _p(bias), act
     if res1 is not None:
-        d.res1, d.res_f32, d.ldr = _p(res1), 1, n
+        d.res1, d.res_f32, d.ldr, d.res_mod = _p(res1), 1, n, res_mod
     d.out_f32 = None if out_f32 is None else out_f32.data_ptr() + 4 * f32_off
     d.out_T = _p(out_T)
     d.ldc = n if ldc is None else ldc
@@ -114,10 +114,13 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def _window(self, enc_last: torch.Tensor, hist: torch.Tensor, q_off: torch.Tensor, labels: torch.Tensor,
-                pfeat: torch.Tensor, plabel: torch.Tensor, need_history: bool):
+                pfeat: torch.Tensor, plabel: torch.Tensor, need_history: bool, hist_uniform: bool = False):
         """forward / forward_single_batch (sparse_heads.py:497-667) for N queries of one clip.
         enc_last: float [P,C]; hist: float [N,P,C]; returns window traj [N,2,T], vis [N,T], depth [N,T],
-        new prompt features [N,C]; updates ``hist`` in place when ``need_history``."""
+        new prompt features [N,C]; updates ``hist`` in place when ``need_history``.
+        ``hist_uniform``: every track has the same history rows (first window: the learned mask token), so until the
+        first image->token update the keys are ONE [P,C] set: the first layer's t2i.k / t2i.v / i2t.q projections and
+        the key initialisation run once instead of N times (identical rows in, identical rows out)."""
         rt = self._rt
         cfg, dt = rt.cfg, rt.dtype
         lib = _lib.load()
@@ -138,10 +141,11 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         _lib.check(lib.l4p_cast(_stream(), dt, _p(tok32), _p(tokT), tok32.numel()), "l4p_cast")
 
         pos = self._w("dense_pe")
-        k32 = torch.empty((N * P, Cc), **f32)
-        kT = torch.empty((N * P, Cc), dtype=td, device=dev)
-        kP = torch.empty((N * P, Cc), dtype=td, device=dev)
-        _lib.check(lib.l4p_track_keys_init(_stream(), dt, _p(enc_last), _p(hist), _p(pos), _p(k32), _p(kT), _p(kP), N, P, Cc),
+        Nk = 1 if hist_uniform else N  # distinct key sets before the first image -> token update
+        k32 = torch.empty((Nk * P, Cc), **f32)
+        kT = torch.empty((Nk * P, Cc), dtype=td, device=dev)
+        kP = torch.empty((Nk * P, Cc), dtype=td, device=dev)
+        _lib.check(lib.l4p_track_keys_init(_stream(), dt, _p(enc_last), _p(hist), _p(pos), _p(k32), _p(kT), _p(kP), Nk, P, Cc),
                    "l4p_track_keys_init")
 
         q32: Optional[torch.Tensor] = None
@@ -149,6 +153,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         x32 = torch.empty((6 * N, Cc), **f32)
         for l in range(cfg.sam_depth):
             lo = f"l{l}."
+            shared = Nk == 1 and N > 1  # keys still common to all tracks (only in layer 0 of a first window)
             # --- self attention of the prompt tokens (transformer.py:159-166) ---
             sq = self._proj(qP, lo + "self.q", Cc)
             sk = self._proj(qP, lo + "self.k", Cc)
@@ -160,7 +165,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             tq = self._proj(qP, lo + "t2i.q", Dh)
             tk = self._proj(kP, lo + "t2i.k", Dh)
             tv = self._proj(kT, lo + "t2i.v", Dh)
-            ta = self._attn(1, tq, tk, tv, N, P, Dh)
+            ta = self._attn(3 if shared else 1, tq, tk, tv, N, P, Dh)
             del tk, tv
             _gemm(ta, 6 * N, Dh, Dh, self._w(lo + "t2i.out.w"), Cc, bias=self._w(lo + "t2i.out.b"), res1=q32, out_f32=x32)
             q32, qT, qP = self._ln(x32, lo + "norm2", tok32, 6 * N, out32=torch.empty_like(x32))
@@ -173,9 +178,21 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             iq = self._proj(kP, lo + "i2t.q", Dh)
             ik = self._proj(qP, lo + "i2t.k", Dh)
             iv = self._proj(qT, lo + "i2t.v", Dh)
-            ia = self._attn(2, iq, ik, iv, N, P, Dh)
+            ia = torch.empty((N * P, Dh), dtype=td, device=dev)
+            _lib.check(lib.l4p_small_attn(_stream(), dt, 4 if shared else 2, _p(iq), _p(ik), _p(iv), _p(ia), N, P, Dh,
+                                          cfg.sam_heads), "l4p_small_attn")
             del iq
-            _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), res1=k32, out_f32=k32)
+            if shared:  # from here on every track owns its keys: residual = the common key set, row m % P
+                k_common = k32
+                k32 = torch.empty((N * P, Cc), **f32)
+                kT = torch.empty((N * P, Cc), dtype=td, device=dev)
+                kP = torch.empty((N * P, Cc), dtype=td, device=dev)
+                _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), res1=k_common,
+                      out_f32=k32, res_mod=P)
+                Nk = N
+                del k_common
+            else:
+                _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), res1=k32, out_f32=k32)
             del ia
             _lib.check(lib.l4p_layernorm_ex(_stream(), dt, _p(k32), _p(self._w(lo + "norm4.g")), _p(self._w(lo + "norm4.b")),
                                             1e-5, _p(kT), _p(k32), N * P, Cc, _p(pos), P, _p(kP), ACT_NONE),
@@ -307,7 +324,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                     self.trace.append({"labels": labels.clone(), "queries": q_off.clone(), "prompt_labels": plabel.clone(),
                                        "valid_t": valid_t.clone()})
                 enc_last = enc_features_bpc_2dlist[wi].f32(-1)[b].contiguous()
-                w_traj, w_vis, w_dep, new_pfeat = self._window(enc_last, hist, q_off, labels, pfeat, plabel, not last)
+                # first window: the history of every track is the learned mask token (filled above) -> shared keys
+                w_traj, w_vis, w_dep, new_pfeat = self._window(enc_last, hist, q_off, labels, pfeat, plabel, not last,
+                                                               hist_uniform=(wi == 0))
                 _lib.check(lib.l4p_track_commit(_stream(), _p(w_traj), _p(w_vis), _p(w_dep), _p(valid_t), _p(valid_n),
                                                 traj_b.data_ptr(), vis_b.data_ptr(), dep_b.data_ptr(), T, start, ws, nxt,
                                                 1 if last else 0, _p(cur_q), _p(plabel), _p(new_pfeat), _p(pfeat), _p(best),
