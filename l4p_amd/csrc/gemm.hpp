@@ -142,11 +142,21 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
         // row part of the output offset
         long long rowoff;
         if (p.epi == EPI_CONVT) {
-            const int wi = m % p.Wi;
-            int r = m / p.Wi;
-            const int hi = r % p.Hi;
-            r /= p.Hi;
-            const int ti = r % p.Ti, b = r / p.Ti;
+            int wi, hi, ti, b;
+            if (((p.Wi & (p.Wi - 1)) | (p.Hi & (p.Hi - 1)) | (p.Ti & (p.Ti - 1))) == 0) {  // power-of-two grid: shifts
+                const int sw = __builtin_ctz(p.Wi), sh = __builtin_ctz(p.Hi), st = __builtin_ctz(p.Ti);
+                wi = m & (p.Wi - 1);
+                hi = (m >> sw) & (p.Hi - 1);
+                ti = (m >> (sw + sh)) & (p.Ti - 1);
+                b = m >> (sw + sh + st);
+            } else {
+                wi = m % p.Wi;
+                int r = m / p.Wi;
+                hi = r % p.Hi;
+                r /= p.Hi;
+                ti = r % p.Ti;
+                b = r / p.Ti;
+            }
             rowoff = ((((long long)b * p.Ti + ti) * p.kt * (p.Hi * p.kh) + hi * p.kh) * (p.Wi * p.kw) + wi * p.kw) * p.Cout;
         } else {
             const long long pm = p.c_gr > 0 ? (long long)(m / p.c_gr) * p.c_gs + p.c_go + (m % p.c_gr) : m;
