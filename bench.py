@@ -82,8 +82,11 @@ def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int):
         conv += 2.0 * vo * 27 * (F_ // 2) * cfg.last_dim
     # tracker: 73.81 GFLOP per query and window, all but ~1 % of it in projections / up-scaling
     # ConvTransposes that run through the GEMM kernel
+    # In a first window every track starts from the same keys, so the engine runs the first layer's three image-side
+    # projections (t2i.k, t2i.v, i2t.q: 2*S*D*(D/2) each) once per clip instead of once per track; they are counted once.
     if "track_2d" in tasks:
-        gemm += 73.81e9 * n_queries
+        shared = 3 * 2.0 * S * D * (D // 2)
+        gemm += (73.81e9 - shared) * n_queries + shared
     return {"gemm": gemm, "conv3d": conv, "attention": attn}
 
 
