@@ -305,8 +305,11 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             cur_q = orig_q.clone()
             pfeat = torch.zeros(N, Cc, **f32)
             plabel = torch.zeros(N, **f32)
-            hist = torch.empty(N * P, Cc, **f32)
-            _lib.check(lib.l4p_fill_rows(_stream(), _p(hist), _p(self._w("history_mask_token")), N * P, Cc, N * P, 0, 0),
+            # history tokens: the learned mask token everywhere before the first window; a single window only ever reads
+            # the first P rows (shared keys), so the per-track copy is not materialised for it
+            hrows = N * P if nwin > 1 else P
+            hist = torch.empty(hrows, Cc, **f32)
+            _lib.check(lib.l4p_fill_rows(_stream(), _p(hist), _p(self._w("history_mask_token")), hrows, Cc, hrows, 0, 0),
                        "l4p_fill_rows")
             q_off = torch.empty(N, 3, **f32)
             labels = torch.empty(N, **f32)
