@@ -85,6 +85,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         self.trace: Optional[list] = None  # set to [] to record per-window labels / queries (tests)
 
     # ------------------------------------------------------------------------------------------------
+    def _single_window_history_rows(self, N: int, P: int) -> int:
+        return P  # (a single window only reads the shared first P rows; tests override this to exercise the general path)
+
     def _w(self, k: str) -> torch.Tensor:
         return self._rt.weights["trk." + k]
 
@@ -307,7 +310,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             plabel = torch.zeros(N, **f32)
             # history tokens: the learned mask token everywhere before the first window; a single window only ever reads
             # the first P rows (shared keys), so the per-track copy is not materialised for it
-            hrows = N * P if nwin > 1 else P
+            hrows = N * P if nwin > 1 else self._single_window_history_rows(N, P)
             hist = torch.empty(hrows, Cc, **f32)
             _lib.check(lib.l4p_fill_rows(_stream(), _p(hist), _p(self._w("history_mask_token")), hrows, Cc, hrows, 0, 0),
                        "l4p_fill_rows")

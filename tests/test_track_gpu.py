@@ -67,3 +67,28 @@ def test_tracker_vs_oracle_and_golden(dev, mini, precision, case, T, nq):
             assert np.array_equal(tr["queries"][:, 0].cpu().numpy(), gold[f"trace{w}_queries"][:, 0]), w
             if "best_vis_id" in otrace[w]:
                 assert torch.equal(tr["best_vis_id"].cpu().long(), otrace[w]["best_vis_id"]), w
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_shared_first_window_keys_equal_per_track_path(dev, mini, precision, monkeypatch):
+    """First-window shortcut (one [P,C] key set until the first image->token update) against the general per-track
+    path on the same inputs: identical rows in, identical rows out — bit for bit."""
+    cfg, sd = mini
+    model = build(cfg, sd, precision)
+    head = model.l4p_model.task_heads["track_2d"]
+    batch = make_batch(16, 8)
+    with torch.no_grad():
+        fast = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+        orig = head._window
+
+        def general(*a, **kw):
+            kw["hist_uniform"] = False
+            return orig(*a, **kw)
+
+        monkeypatch.setattr(head, "_window", general)
+        # the general path reads a per-track history block: make the single-window run allocate it
+        monkeypatch.setattr(type(head), "_single_window_history_rows", lambda self, N, P: N * P, raising=False)
+        slow = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+    torch.cuda.synchronize()
+    for key in ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]:
+        assert torch.equal(fast[key], slow[key]), key
