@@ -130,7 +130,7 @@ def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 4):
                        f"+ heads in full {t_heads:.2f}s -> {dt:.1f}s per clip")}
 
 
-def build_workload(tasks, B, nq, device, rank=0):
+def build_workload(tasks, B, nq, device, rank=0, frames=16, same_data=False):
     """Model (name-seeded random weights, packed on rank 0 and broadcast once) + one synthetic batch of B clips."""
     cfg = ModelCfg.full()
     model = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision="bf16")
@@ -145,12 +145,12 @@ def build_workload(tasks, B, nq, device, rank=0):
     pw = broadcast_weights(pw, device)  # RCCL over xGMI, once
     net.set_weights(pw)
 
-    g = torch.Generator().manual_seed(1234 + rank)
-    rgb = torch.randn([B, 3, 16, 224, 224], generator=g, dtype=torch.float32)
+    g = torch.Generator().manual_seed(1234 + (0 if same_data else rank))
+    rgb = torch.randn([B, 3, frames, 224, 224], generator=g, dtype=torch.float32)
     K = torch.eye(4)
     K[0, 0] = K[1, 1] = 224.0
     K[0, 2] = K[1, 2] = 112.0
-    batch = {"rgb_b3thw": rgb.to(device), "intrinsics_b44t": K[None, :, :, None].repeat(B, 1, 1, 16).to(device)}
+    batch = {"rgb_b3thw": rgb.to(device), "intrinsics_b44t": K[None, :, :, None].repeat(B, 1, 1, frames).to(device)}
     if "track_2d" in tasks:
         q = torch.zeros(1, nq, 3)
         for i in range(nq):
@@ -165,7 +165,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--frames", type=int, default=256, help="c5: length of the long video")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default: 1 for c2, 4 for c3)")
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,12 +182,18 @@ def main():
 
     cfg = ModelCfg.full()
     tasks = ["depth"] if args.workload == "c2" else list(ALL_TASKS)
-    B = args.batch or (1 if args.workload == "c2" else 4)
+    B = args.batch or (4 if args.workload == "c3" else 1)
+    c5 = args.workload == "c5"  # configs[4]: ONE long video, its windows sharded over the ranks (strong scaling)
 
-    model, batch, sd = build_workload(tasks, B, args.queries, device, rank)
+    model, batch, sd = build_workload(tasks, B, args.queries, device, rank, frames=args.frames if c5 else 16, same_data=c5)
+    if c5:
+        model.l4p_model.always_use_windowed_version = True
 
     def step():
         with torch.no_grad():
+            if c5:
+                from l4p_amd.parallel import forward_windows_sharded
+                return forward_windows_sharded(model.l4p_model, batch, tasks, rank, world, group=4)
             return model.forward(batch, tasks)
 
     for _ in range(args.warmup):
@@ -221,20 +228,27 @@ def main():
 
     if rank != 0:
         return
-    frames = world * B * 16 * args.steps
+    frames = (B * args.frames if c5 else world * B * 16) * args.steps
     res = {
-        "metric": "frames/sec (all heads), 16x224x224 clip; encoder MFMA-roofline %" if args.workload == "c3" else
+        "metric": "frames/sec (all heads), 16x224x224 clip; encoder MFMA-roofline %" if args.workload in ("c3", "c5") else
                   "frames/sec (depth head only), 16x224x224 clip; encoder MFMA-roofline %",
         "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if c5 else "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (randn clips, name-seeded random weights of the VideoMAE-v2-giant + DPT geometry)",
         "config": {"workload": ("configs[1]: single MI355X, depth head only, bf16, batch=1 16-frame 224x224 clip" if args.workload == "c2"
+                                 else f"configs[4]: one {args.frames}-frame video -> {(args.frames - 16) // 8 + 1} overlapping 16-frame windows sharded over the ranks, all heads, on-GPU pose / window alignment, {args.queries} track queries" if c5
                                  else f"configs[2]: all heads (depth+flow+track2d/3d+motion-seg+pose), bf16, batch={B} clips, {args.queries} track queries"),
-                   "clips_per_gpu_per_step": B, "tasks": tasks, "parallelism": f"dp{world} (clips sharded, no collective in the step)"},
+                   "clips_per_gpu_per_step": B, "tasks": tasks, "parallelism": (f"windows sharded over {world} rank(s); one all-gather of the decoded windows, stitching replicated, track queries sharded" if c5
+                                   else f"dp{world} (clips sharded, no collective in the step)")},
     }
     if not args.no_prof:
         prof = read_prof(lib)
         fl = algorithmic_flops(cfg, tasks, args.queries if "track_2d" in tasks else 0)
+        nwin_rank0 = 1
+        if c5:  # rank 0's share: its chunk of windows (the tracker term is approximate: queries, not windows, are sharded)
+            from l4p_amd.parallel import window_chunks
+            s0, e0 = window_chunks((args.frames - 16) // 8 + 1, world)[0]
+            nwin_rank0 = e0 - s0
         classes = {}
         for name, (ms, n) in prof.items():
             if n == 0:
@@ -243,7 +257,7 @@ def main():
             ent = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n / args.steps,
                    "avg_launch_us": round(ms / n * 1e3, 3)}
             if name in fl and fl[name] > 0:
-                ent["tflops"] = round(fl[name] * B / (per_step_ms * 1e-3) / 1e12, 2)
+                ent["tflops"] = round(fl[name] * B * nwin_rank0 / (per_step_ms * 1e-3) / 1e12, 2)
             classes[name] = ent
         mfma = [k for k in ("gemm", "conv3d", "attention") if k in classes]
         dom = max(mfma, key=lambda k: classes[k]["ms_per_step"])
@@ -267,7 +281,7 @@ def main():
                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c3_hbm_traffic.md)",
                     "method": "algorithmic FLOPs / HIP-event-bracketed kernel time, second pass of the same K steps",
                     "avg_launch_us": classes[k]["avg_launch_us"], "launches_per_step": classes[k]["launches_per_step"],
-                    "algorithmic_flops_per_step": fl[k] * B}
+                    "algorithmic_flops_per_step": fl[k] * B * nwin_rank0}
 
         res["roofline"] = roof(dom)
         if "attention" in classes and dom != "attention":

@@ -165,10 +165,19 @@ class L4P_VideoMAE(torch.nn.Module):
         if (not self.always_use_windowed_version) and (T == self.window_size[0]):
             return self.forward_single_window(data, tasks)
         assert T % self.window_stride_T == 0, "Temporal window needs to be a multiple of window stride, for now!"
-        time_strides = torch.arange(0, T - self.window_size[0] + 1, self.window_stride_T)
+        time_strides = self.time_strides(T)
         tf, tT = self._taps(tasks)
         ws = self.window_size[0]
         feats2d = [self.video_encoder(data["rgb_b3thw"][:, :, int(s):int(s) + ws], tf, tT) for s in time_strides]
+        return self.stitch_windows(feats2d, data, tasks, time_strides)
+
+    def time_strides(self, T: int) -> torch.Tensor:
+        return torch.arange(0, T - self.window_size[0] + 1, self.window_stride_T)
+
+    def stitch_windows(self, feats2d: list, data: Dict[str, Any], tasks: List[str], time_strides: torch.Tensor) -> Dict[str, Any]:
+        """Everything after the per-window encoder (l4p_videomae.py:296-329): per-window heads + stitching / alignment /
+        track recursion.  ``feats2d`` holds one entry per window: EncoderFeatures, or parallel.DecodedWindow for windows
+        whose heavy work already ran (possibly on another GPU)."""
         out: Dict[str, Any] = {"enc_features_bpc_2dlist": feats2d}
         joint_possible = "depth" in tasks and "camray" in tasks
         if self.joint_alignment and joint_possible:

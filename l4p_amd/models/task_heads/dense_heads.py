@@ -121,6 +121,9 @@ class VideoMAEFlowDPTHead(torch.nn.Module):
         return list(self.hooks_idx)
 
     def _decode(self, enc_features_bpc_list, img_info) -> torch.Tensor:
+        pre = getattr(enc_features_bpc_list, "decoded", None)
+        if pre is not None and self._engine_task in pre:
+            return pre[self._engine_task]  # window decoded earlier / on another rank (parallel.DecodedWindow)
         if self._rt is None:
             raise RuntimeError(f"head '{self.task_name}' has no weights: call load_state_dict on the model first")
         hooks = [enc_features_bpc_list.T(h) for h in self.hooks_idx]

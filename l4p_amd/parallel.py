@@ -50,3 +50,160 @@ def broadcast_weights(weights: Optional[PackedWeights], device: torch.device, sr
 def shard(n_items: int, rank: int, world: int) -> List[int]:
     """Static round-robin assignment of independent clips / windows to ranks."""
     return list(range(rank, n_items, world))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Config 5 (SURVEY.md §8e): one long video -> overlapping 16-frame windows sharded over the ranks.
+# The expensive, window-local work (encoder + DPT decoders) runs on the rank that owns the window; ONE exchange step
+# (all-gather of the decoded windows and of the last-layer features) follows; the cheap sequential part (overlap alignment,
+# stitching, pose chaining) then runs replicated on every rank from identical inputs, and the tracker - a recursion over
+# windows that is independent per query - runs on a shard of the queries whose results are all-gathered.
+# The stitched outputs are therefore bit-identical to the single-GPU windowed forward.
+# ---------------------------------------------------------------------------------------------------------------------
+def window_chunks(n_windows: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous [start, end) window ranges per rank, sizes differing by at most one (31 windows, 8 ranks -> 4,4,4,4,4,4,4,3)."""
+    q, r = divmod(n_windows, world)
+    out, s = [], 0
+    for k in range(world):
+        e = s + q + (1 if k < r else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+class DecodedWindow:
+    """Stand-in for EncoderFeatures of a window whose heavy work is already done: ``decoded[task]`` is the DPT decoder
+    output of that task (dense_heads._decode returns it as is), ``last`` the float last-layer features the tracker reads."""
+
+    def __init__(self, depth: int, decoded: dict, last: Optional[torch.Tensor]):
+        self.depth, self.decoded, self.last = depth, decoded, last
+
+    def __len__(self) -> int:
+        return self.depth + 1
+
+    def f32(self, i: int) -> torch.Tensor:
+        if i not in (-1, self.depth) or self.last is None:
+            raise KeyError(f"decoded window keeps only the last-layer features (asked for {i})")
+        return self.last
+
+    def __getitem__(self, i: int) -> torch.Tensor:
+        return self.f32(i)
+
+
+def all_gather_windows(local: dict, n_windows: int, rank: int, world: int) -> List[dict]:
+    """local: {window id: {key: tensor}} for this rank's chunk -> list over ALL windows of {key: tensor}.
+    One all_gather per key on a [chunk_max, ...] block (chunks differ by at most one window; the pad slot is ignored)."""
+    chunks = window_chunks(n_windows, world)
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return [local[w] for w in range(n_windows)]
+    cmax = max(e - s for s, e in chunks)
+    s0, e0 = chunks[rank]
+    keys = sorted(local[s0].keys()) if e0 > s0 else None
+    meta = [None] * world
+    dist.all_gather_object(meta, None if keys is None else {k: (tuple(local[s0][k].shape), local[s0][k].dtype) for k in keys})
+    ref = next(m for m in meta if m is not None)
+    dev = next(iter(local[s0].values())).device if keys else None
+    if dev is None:  # a rank without windows (more ranks than windows) still has to take part in the collectives
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    out: List[dict] = [dict() for _ in range(n_windows)]
+    for k in sorted(ref.keys()):
+        shape, dtype = ref[k]
+        block = torch.zeros((cmax,) + shape, dtype=dtype, device=dev)
+        for j, w in enumerate(range(s0, e0)):
+            block[j].copy_(local[w][k])
+        parts = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(parts, block)
+        for r, (s, e) in enumerate(chunks):
+            for j, w in enumerate(range(s, e)):
+                out[w][k] = parts[r][j]
+    return out
+
+
+def shard_queries(n_queries: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [start, end) of the track queries owned by ``rank``."""
+    return window_chunks(n_queries, world)[rank]
+
+
+def all_gather_queries(x: torch.Tensor, n_queries: int, rank: int, world: int, dim: int = 1) -> torch.Tensor:
+    """Inverse of shard_queries along ``dim`` (shards differ by at most one query: padded to the largest)."""
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return x
+    chunks = window_chunks(n_queries, world)
+    cmax = max(e - s for s, e in chunks)
+    xm = x.movedim(dim, 0).contiguous()
+    block = torch.zeros((cmax,) + tuple(xm.shape[1:]), dtype=x.dtype, device=x.device)
+    block[: xm.shape[0]].copy_(xm)
+    parts = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(parts, block)
+    full = torch.cat([parts[r][: e - s] for r, (s, e) in enumerate(chunks)], dim=0)
+    return full.movedim(0, dim).contiguous()
+
+
+def decode_local_windows(net, data: dict, tasks: List[str], rank: int, world: int, group: int = 1) -> dict:
+    """Phase 1 (sharded, all the FLOPs): encoder + DPT decoders of this rank's windows -> {window id: {key: tensor}}."""
+    rgb = data["rgb_b3thw"]
+    ws = net.window_size[0]
+    strides = net.time_strides(rgb.shape[2])
+    s0, e0 = window_chunks(len(strides), world)[rank]
+    tf, tT = net._taps(tasks)
+    img_info = tuple(data.get("img_info", net.window_size))
+    dense = [t for t in tasks if t != "track_2d"]
+    local = {}
+    B = rgb.shape[0]
+    # group > 1: that many windows ride through the encoder / decoders as one batch (better filled GEMM tiles: +20 % at
+    # group 4).  The batch size selects kernels (split-K of the small convs, the KV split of attention), so the result then
+    # equals the window-by-window one only up to summation order (1e-5 relative in f32 mode); group = 1 is bit-identical.
+    for g0 in range(s0, e0, group):
+        ws_ids = list(range(g0, min(g0 + group, e0)))
+        clip = torch.cat([rgb[:, :, int(strides[w]):int(strides[w]) + ws] for w in ws_ids], dim=0)
+        feats = net.video_encoder(clip, tf, tT)
+        dec = {t: net.task_heads[t]._decode(feats, img_info) for t in dense}
+        last = feats.f32(-1) if "track_2d" in tasks else None
+        for j, w in enumerate(ws_ids):
+            item = {"dec." + t: dec[t][j * B:(j + 1) * B].contiguous() for t in dense}
+            if last is not None:
+                item["last"] = last[j * B:(j + 1) * B].contiguous()
+            local[w] = item
+    return local
+
+
+def stitch_gathered_windows(net, data: dict, tasks: List[str], gathered: List[dict], rank: int, world: int) -> dict:
+    """Phase 3: replicated stitching / alignment from the gathered windows; the tracker runs on this rank's query shard
+    (its outputs hold that shard only - all_gather_queries puts them back together)."""
+    strides = net.time_strides(data["rgb_b3thw"].shape[2])
+    windows = [DecodedWindow(net.cfg.depth, {k[4:]: v for k, v in g.items() if k.startswith("dec.")}, g.get("last"))
+               for g in gathered]
+    d = dict(data)
+    local_tasks = list(tasks)
+    if "track_2d" in tasks:
+        nq = data["track_2d_pointquerries_bn3"].shape[1]
+        q0, q1 = shard_queries(nq, rank, world)
+        d["track_2d_pointquerries_bn3"] = data["track_2d_pointquerries_bn3"][:, q0:q1].contiguous()
+        d["track_2d_pointlabels_bn"] = data["track_2d_pointlabels_bn"][:, q0:q1].contiguous()
+        if q1 == q0:
+            local_tasks.remove("track_2d")
+    return net.stitch_windows(windows, d, local_tasks, strides)
+
+
+def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[int] = None, world: Optional[int] = None,
+                            group: int = 1) -> dict:
+    """L4P_VideoMAE.forward for a long clip with its windows sharded over the ranks (see the block comment above).
+    ``net``: l4p_amd.models.l4p_videomae.L4P_VideoMAE with weights set on every rank (broadcast_weights)."""
+    if rank is None or world is None:
+        on = dist.is_available() and dist.is_initialized()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    data = {k: (v.to(net.device) if torch.is_tensor(v) else v) for k, v in data.items()}
+    T = data["rgb_b3thw"].shape[2]
+    assert T % net.window_stride_T == 0 and T >= net.window_size[0]
+    nwin = len(net.time_strides(T))
+    local = decode_local_windows(net, data, tasks, rank, world, group)
+    gathered = all_gather_windows(local, nwin, rank, world)  # the one exchange step of the dense path
+    out = stitch_gathered_windows(net, data, tasks, gathered, rank, world)
+    if "track_2d" in tasks and world > 1:
+        nq = data["track_2d_pointquerries_bn3"].shape[1]
+        name = net.task_heads["track_2d"].task_name
+        for key, shp in ((f"{name}_traj_est_bn2t", 2), (f"{name}_vis_est_bn1t", 1), (f"{name}_depth_est_bn1t", 1)):
+            if key not in out:  # rank without queries
+                out[key] = torch.zeros(data["rgb_b3thw"].shape[0], 0, shp, T, dtype=torch.float32, device=net.device)
+            out[key] = all_gather_queries(out[key], nq, rank, world, dim=1)
+    return out

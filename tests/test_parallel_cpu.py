@@ -43,3 +43,50 @@ def test_weight_broadcast_and_sharding_world2():
     (r0, d0, n0, kp0, s0), (r1, d1, n1, kp1, s1) = res
     assert d0 == d1 and n0 == n1 and kp0 == kp1 == 1216
     assert sorted(s0 + s1) == list(range(7)) and not set(s0) & set(s1)
+
+
+def _worker_windows(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from l4p_amd.parallel import all_gather_queries, all_gather_windows, init_distributed, shard_queries, window_chunks
+
+    init_distributed("gloo")
+    nwin, nq = 7, 5  # unequal chunks on both axes: windows 4 + 3, queries 3 + 2
+    s, e = window_chunks(nwin, world)[rank]
+    local = {w: {"dec.depth": torch.full((1, 1, 4, 3, 3), float(w)), "last": torch.arange(6.0).reshape(1, 2, 3) + 100 * w}
+             for w in range(s, e)}
+    got = all_gather_windows(local, nwin, rank, world)
+    ok = len(got) == nwin and all(float(got[w]["dec.depth"].mean()) == float(w) and
+                                  torch.equal(got[w]["last"], torch.arange(6.0).reshape(1, 2, 3) + 100 * w) for w in range(nwin))
+    q0, q1 = shard_queries(nq, rank, world)
+    full = torch.arange(nq * 2 * 4, dtype=torch.float32).reshape(1, nq, 2, 4)
+    back = all_gather_queries(full[:, q0:q1].contiguous(), nq, rank, world, dim=1)
+    q.put((rank, bool(ok), bool(torch.equal(back, full)), (s, e), (q0, q1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_and_query_exchange_world2():
+    """The one exchange step of the window-sharded long-video path (config 5): unequal chunks, padded all-gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_windows, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True] and [r[2] for r in res] == [True, True]
+    assert [r[3] for r in res] == [(0, 4), (4, 7)] and [r[4] for r in res] == [(0, 3), (3, 5)]
+
+
+def test_window_chunks_cover():
+    from l4p_amd.parallel import window_chunks
+
+    assert [e - s for s, e in window_chunks(31, 8)] == [4, 4, 4, 4, 4, 4, 4, 3]
+    for n, w in ((31, 8), (3, 8), (16, 4), (1, 2)):
+        ch = window_chunks(n, w)
+        assert ch[0][0] == 0 and ch[-1][1] == n and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
