@@ -213,12 +213,14 @@ def main():
     #      stream.  Kept out of the timed region because the event packets themselves cost ~13 % of a step at batch 1
     #      (15.1 ms -> 17.5 ms measured); kernel durations are unaffected up to a few %.
     if not args.no_prof and rank == 0:
+        os.environ["L4P_TRACK_STREAMS"] = "0"  # kernel durations are taken with the clips' trackers serialised on one stream
         lib.l4p_prof_reset()
         lib.l4p_prof_enable(1)
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         lib.l4p_prof_enable(0)
+        os.environ.pop("L4P_TRACK_STREAMS", None)
     if world > 1:
         dist.barrier()
     if world > 1:

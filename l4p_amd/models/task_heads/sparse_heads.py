@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Literal, Optional, Tuple
 
 import torch
@@ -303,7 +304,10 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         vis_all = torch.full((B, N, 1, T), -10.0, **f32)
         dep_all = torch.zeros(B, N, 1, T, **f32)
         nwin = len(time_strides)
-        for b in range(B):  # the reference asserts B == 1 (sparse_heads.py:241); clips are independent here
+        # Clips are independent (the reference asserts B == 1, sparse_heads.py:241).  Each clip's tracker runs on its own
+        # HIP stream: its many token-side launches are tiny (M = 6N rows -> a few dozen workgroups) and leave most CUs
+        # idle, so the clips fill each other's gaps.
+        def run_clip(b: int) -> None:
             orig_q = track_2d_pointquerries_bn3[b].to(**f32).contiguous()
             cur_q = orig_q.clone()
             pfeat = torch.zeros(N, Cc, **f32)
@@ -339,6 +343,23 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                                                 N, Cc), "l4p_track_commit")
                 if self.trace is not None and not last:
                     self.trace[-1]["best_vis_id"] = best.clone()
+
+        use_streams = B > 1 and dev.type == "cuda" and os.environ.get("L4P_TRACK_STREAMS", "1") != "0" and self.trace is None
+        if use_streams:
+            main = torch.cuda.current_stream()
+            pool = getattr(self, "_clip_streams", None)
+            if pool is None or len(pool) < B:
+                pool = [torch.cuda.Stream(device=dev) for _ in range(B)]
+                self._clip_streams = pool
+            for b in range(B):
+                pool[b].wait_stream(main)
+                with torch.cuda.stream(pool[b]):
+                    run_clip(b)
+            for b in range(B):
+                main.wait_stream(pool[b])
+        else:
+            for b in range(B):
+                run_clip(b)
         return {f"{self.task_name}_traj_est_bn2t": traj_all, f"{self.task_name}_vis_est_bn1t": vis_all,
                 f"{self.task_name}_depth_est_bn1t": dep_all}
 
