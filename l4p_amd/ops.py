@@ -102,9 +102,9 @@ def splitk_for(M: int, N: int, K: int, es: int) -> int:
     (the low-resolution DPT convs: M = 256..2048 voxels, K = 27*256..27*1024)."""
     tiles = ((M + 127) // 128) * ((N + 63) // 64)
     nk = (K + 128 // es - 1) // (128 // es)
-    if tiles >= 192 or nk < 32:
+    if tiles >= 512 or nk < 32:  # aim at ~1024 workgroups (4 per CU): one 4-wave workgroup per CU is latency-bound
         return 1
-    return max(1, min(16, 512 // tiles, nk // 8))
+    return max(1, min(16, 1024 // tiles, nk // 8))
 
 
 def kv_block(dtype: torch.dtype) -> int:
