@@ -57,6 +57,7 @@ __global__ void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int 
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
                     const float wgt = (a ? lt : 1.f - lt) * (bb ? lh : 1.f - lh) * (cc ? lw : 1.f - lw);
+                    if (wgt == 0.f) continue;  // an axis that is not resized (lambda == 0) has one tap, not two: skip the load
                     const T* p = xb + (((long long)(a ? t1 : t0) * Hi + (bb ? h1 : h0)) * Wi + (cc ? w1 : w0)) * C;
                     if (sizeof(T) == 2) {
                         const bf16x8 v = *(const bf16x8*)p;

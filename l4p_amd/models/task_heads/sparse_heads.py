@@ -198,9 +198,10 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             else:
                 _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), res1=k32, out_f32=k32)
             del ia
+            # (after the last layer nothing adds to the float keys any more: only the T copies are written)
             _lib.check(lib.l4p_layernorm_ex(_stream(), dt, _p(k32), _p(self._w(lo + "norm4.g")), _p(self._w(lo + "norm4.b")),
-                                            1e-5, _p(kT), _p(k32), N * P, Cc, _p(pos), P, _p(kP), ACT_NONE),
-                       "l4p_layernorm_ex")
+                                            1e-5, _p(kT), _p(k32) if l + 1 < cfg.sam_depth else None, N * P, Cc, _p(pos), P,
+                                            _p(kP), ACT_NONE), "l4p_layernorm_ex")
         # --- final tokens -> image attention (transformer.py:103-109) ---
         fq = self._proj(qP, "final.q", Dh)
         fk = self._proj(kP, "final.k", Dh)
