@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL across processes)
+
 import torch
 import torch.distributed as dist
 

@@ -25,6 +25,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # these hosts support dmabuf IPC only (RCCL needs it)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
