@@ -176,13 +176,14 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     issue_v(grp, 0);
     if (nit > 1) issue_k(SPLIT + grp, 1);
     __syncthreads();
-    f32x16 s_cur[NST], s_nxt[NST];
-    qk_tile(Ks, s_cur);
-    float mx = row_max(s_cur);
+    f32x16 s_a[NST], s_b[NST];  // score registers, used ping-pong (no copy between pipeline steps)
+    qk_tile(Ks, s_a);
+    float mx = row_max(s_a);
+    __syncthreads();  // every wave has read K_0 before the first iteration re-stages its slot
 
     // one pipeline step; HAS_NEXT is a compile-time flag so that the steady-state body is ONE basic block in which the
     // scheduler is free to interleave the two MFMA batches with the VALU work (the last block is peeled)
-    auto step = [&](int it, auto has_next) {
+    auto step = [&](int it, auto has_next, f32x16* s_cur, f32x16* s_nxt) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         const int cur = it & 1;
 #ifndef ATTN_DBG_NOLOAD  // (tools/probes/attn_variants.hip: compute-only timing)
@@ -206,13 +207,21 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         // ---- next block's scores (MFMA) alongside this block's exponentials (VALU) ----------------
         if (HAS_NEXT) qk_tile(Ks + (cur ^ 1) * KBYTES, s_nxt);
         frag_t pf[NST][2];
+        {
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            const f32x2 c2 = {c_scale, c_scale}, m2 = {-m_run, -m_run};
 #pragma unroll
-        for (int t = 0; t < NST; ++t)
+            for (int t = 0; t < NST; ++t)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    pf[t][j][e] = from_f32<T>(__builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[t][8 * j + e], c_scale, -m_run)));
+                    for (int e = 0; e < 8; e += 2) {  // two scores per v_pk_fma_f32
+                        const f32x2 a = {s_cur[t][8 * j + e], s_cur[t][8 * j + e + 1]};
+                        const f32x2 x = __builtin_elementwise_fma(a, c2, m2);
+                        pf[t][j][e] = from_f32<T>(__builtin_amdgcn_exp2f(x[0]));
+                        pf[t][j][e + 1] = from_f32<T>(__builtin_amdgcn_exp2f(x[1]));
+                    }
+        }
         // ---- O^T += V^T P^T (MFMA) alongside the row max of the next scores (VALU) ------------------
         const char* Vb = Vs + cur * VBYTES;
 #pragma unroll
@@ -231,16 +240,27 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
             }
         if (HAS_NEXT) {
             mx = row_max(s_nxt);
-#pragma unroll
-            for (int t = 0; t < NST; ++t) s_cur[t] = s_nxt[t];
-            __syncthreads();  // (drains the LDS-DMA issued at the top: vmcnt(0) + barrier)
+            __syncthreads();  // (drains the LDS-DMA issued at the top: vmcnt(0) + barrier; a 3-deep ring with a counted
+                              //  vmcnt was measured and is no faster: the DMA latency is not what bounds the loop)
         }
     };
-    for (int it = 0; it + 1 < nit; ++it) step(it, std::true_type{});
-    step(nit - 1, std::false_type{});
+    {
+        int it = 0;
+        for (; it + 2 < nit; it += 2) {
+            step(it, std::true_type{}, s_a, s_b);
+            step(it + 1, std::true_type{}, s_b, s_a);
+        }
+        if (it + 2 == nit) {
+            step(it, std::true_type{}, s_a, s_b);
+            step(it + 1, std::false_type{}, s_b, s_a);
+        } else {
+            step(it, std::false_type{}, s_a, s_b);
+        }
+    }
 
     // ---- SPLIT: merge the partial states of the KV groups through LDS (tile buffers are free now) -----
     if (SPLIT > 1) {
+        __syncthreads();  // the other group may still be reading its tiles where the exchange buffer goes
         float* xch = (float*)smem;  // [4 waves][NDT*16 + 1][64 lanes]
         constexpr int NX = NDT * 16 + 1;
         if (grp == 1) {
