@@ -22,6 +22,7 @@
 //  * the softmax denominator comes out of the MFMA: padding row d = DH of the V^T tile is sourced
 //    from a constant "ones" chunk, so O^T[DH][q] = sum_k P[q][k] with exactly the weights used for O.
 //  * exp via v_exp_f32 (exp2 of non-positive arguments), scale*log2(e) folded into one fma.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -34,7 +35,16 @@ __device__ __attribute__((aligned(16))) static const float g_ones_f32[4] = {1.f,
 // SAME 128 query rows, and the two partial (m, O, denominator) states are merged through LDS at the end.
 // Used when the launch has too few workgroups to put two of them on a CU (batch 1: 256 workgroups), so
 // every SIMD still holds two waves whose MFMA / VALU / wait phases overlap.
-template <typename T, int DP, int KVB, int DH, int SPLIT>
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// HS (bf16 only): the KV-block body is hand scheduled - see the comment at its definition below.
+template <typename T, int DP, int KVB, int DH, int SPLIT, bool HS = false>
 __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__ q, const T* __restrict__ kt,
                                                            const T* __restrict__ vt, T* __restrict__ out, int S, int H,
                                                            float c_scale) {
@@ -204,6 +214,82 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             m_run = m_new;
         }
+        if constexpr (HS) {
+            // Hand-scheduled block body.  hipcc emits lgkmcnt(0) for every LDS wait of its own while an LDS-DMA is in
+            // flight, which makes each MFMA wait for its own ds_read; and it clusters the VALU work away from the MFMAs.
+            // Here the 24 fragment reads (12 K for S_{j+1} = K Q^T, then 12 V^T for O^T += V^T P^T) are inline-asm
+            // ds_read_b128 with hand-counted lgkmcnt (LDS reads return in order: MFMA m may issue once only the reads
+            // requested after its operand are outstanding); PRE reads run ahead.  Behind every MFMA sits a slice of the
+            // block's VALU work: the exp2 / bf16 packing of P_j under the QK MFMAs, the row max of S_{j+1} under the PV ones.
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+#ifndef ATTN_HS_PRE
+#define ATTN_HS_PRE 6
+#endif
+            constexpr int PRE = ATTN_HS_PRE;  // fragment reads in flight ahead of the MFMA that consumes them
+            constexpr int NR = HAS_NEXT ? 24 : 12, R0 = HAS_NEXT ? 0 : 12;  // the last block has no next scores to build
+            const unsigned lds_k = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Ks;
+            const unsigned lds_v = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Vs;
+            const unsigned kb = lds_k + (cur ^ 1) * KBYTES, vb = lds_v + cur * VBYTES;
+            unsigned ka[NST], va[NST * 2];
+#pragma unroll
+            for (int t = 0; t < NST; ++t) ka[t] = kb + koff[t];
+#pragma unroll
+            for (int tj = 0; tj < NST * 2; ++tj) va[tj] = vb + lq * 128 + ((((tj * 16 + hi * 8) >> 3) ^ vsw) << 4);
+            u32x4 fr[24];
+            auto rd = [&fr, &ka, &va](auto i_) {  // (explicit captures: asm operands do not trigger implicit capture)
+                constexpr int r = R0 + decltype(i_)::value;
+                if constexpr (r < 12)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[r]) : "v"(ka[r % NST]), "n"((r / NST) * (KVB * 2 * 16)) : "memory");
+                else
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[r]) : "v"(va[(r - 12) / NDT]), "n"(((r - 12) % NDT) * 4096) : "memory");
+            };
+            const f32x2 c2 = {c_scale, c_scale}, m2 = {-m_run, -m_run};
+            frag_t pf[NST][2];
+            auto exp_pair = [&](auto p_) {  // P elements 2p, 2p+1 of the 32 scores of this lane
+                constexpr int e = decltype(p_)::value * 2, t = e / 16, r = e % 16, j = r / 8, ee = r % 8;
+                const f32x2 a = {s_cur[t][r], s_cur[t][r + 1]};
+                const f32x2 x = __builtin_elementwise_fma(a, c2, m2);
+                pf[t][j][ee] = from_f32<T>(__builtin_amdgcn_exp2f(x[0]));
+                pf[t][j][ee + 1] = from_f32<T>(__builtin_amdgcn_exp2f(x[1]));
+            };
+            float mxn = -INFINITY;
+            auto max_pair = [&](auto p_) {
+                constexpr int e = decltype(p_)::value * 2, t = e / 16, r = e % 16;
+                mxn = fmaxf(fmaxf(mxn, s_nxt[t][r]), s_nxt[t][r + 1]);
+            };
+            static_for<0, PRE>(rd);
+            if constexpr (!HAS_NEXT) static_for<0, 16>(exp_pair);
+            __builtin_amdgcn_s_setprio(1);  // the MFMA run outranks the co-resident waves' vector work (+4 % at batch 4)
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            static_for<0, NR>([&](auto m_) {
+                constexpr int m = decltype(m_)::value, r = R0 + m;
+                constexpr int issued = (PRE + m < NR) ? PRE + m : NR;
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(issued - m - 1) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (r < 12) {
+                    s_nxt[r % NST] = mma32(__builtin_bit_cast(frag_t, fr[r]), qf[r / NST], r < NST ? zero : s_nxt[r % NST]);
+                } else {
+                    constexpr int i = r - 12;
+                    o[i % NDT] = mma32(__builtin_bit_cast(frag_t, fr[r]), pf[(i / NDT) >> 1][(i / NDT) & 1], o[i % NDT]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PRE + m < NR) rd(std::integral_constant<int, PRE + m>{});
+                // VALU slice riding behind this MFMA: 16 pairs over 12 slots (2 pairs in the first four, then 1)
+                constexpr int slot = r < 12 ? r : r - 12;
+                constexpr int p0 = slot < 4 ? 2 * slot : 4 + slot, np = slot < 4 ? 2 : 1;
+                if constexpr (r < 12) {
+                    static_for<p0, p0 + np>(exp_pair);
+                } else if constexpr (HAS_NEXT) {
+                    static_for<p0, p0 + np>(max_pair);
+                }
+            });
+            __builtin_amdgcn_s_setprio(0);
+            if (HAS_NEXT) {
+                mx = fmaxf(mxn, __shfl_xor(mxn, 32));
+                __syncthreads();
+            }
+            return;
+        }
         // ---- next block's scores (MFMA) alongside this block's exponentials (VALU) ----------------
         if (HAS_NEXT) qk_tile(Ks + (cur ^ 1) * KBYTES, s_nxt);
         frag_t pf[NST][2];
@@ -308,12 +394,12 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         }
 }
 
-template <typename T, int KVB, int DH, int SPLIT>
+template <typename T, int KVB, int DH, int SPLIT, bool HS = false>
 static int launch_attn_t(const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, float scale,
                          hipStream_t stream) {
     constexpr int DP = 96;
     const size_t lds = SPLIT * 2 * (size_t)(DP / 16 * KVB * 2 * 8 * sizeof(T) + DP * 128);
-    auto kern = attn_kernel<T, DP, KVB, DH, SPLIT>;
+    auto kern = attn_kernel<T, DP, KVB, DH, SPLIT, HS>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -336,6 +422,14 @@ int launch_attention(int dtype, const void* q, const void* kt, const void* vt, v
     }
     // too few workgroups for two per CU (256 CUs): split the KV range over two wave groups inside each workgroup
     const bool split = (long long)(S / 128) * H * B < 512 && (S / 64) % 2 == 0;
+    static const int variant = getenv("L4P_ATTN_VARIANT") ? atoi(getenv("L4P_ATTN_VARIANT")) : 0;  // tuning aid: 1 = compiler-scheduled body
+    if (dtype == L4P_BF16 && variant != 1) {
+        if (Dh == 88)
+            return split ? launch_attn_t<bf16_t, 64, 88, 2, true>(q, kt, vt, out, B, S, H, scale, stream)
+                         : launch_attn_t<bf16_t, 64, 88, 1, true>(q, kt, vt, out, B, S, H, scale, stream);
+        return split ? launch_attn_t<bf16_t, 64, 64, 2, true>(q, kt, vt, out, B, S, H, scale, stream)
+                     : launch_attn_t<bf16_t, 64, 64, 1, true>(q, kt, vt, out, B, S, H, scale, stream);
+    }
     if (dtype == L4P_BF16) {
         if (Dh == 88)
             return split ? launch_attn_t<bf16_t, 64, 88, 2>(q, kt, vt, out, B, S, H, scale, stream)
