@@ -197,8 +197,11 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         const int cur = it & 1;
 #ifndef ATTN_DBG_NOLOAD  // (tools/probes/attn_variants.hip: compute-only timing)
-        if (it + 2 < nit) issue_k((it + 2) * SPLIT + grp, cur);      // K_{it} (ring slot cur) was consumed last iteration
-        if (HAS_NEXT) issue_v((it + 1) * SPLIT + grp, cur ^ 1);      // V_{it-1} (slot cur^1) was consumed last iteration
+        constexpr bool DMA_IN_SLOTS = HS && SPLIT > 1;  // measured: +4 % for the KV-split (batch 1) form, -2 % otherwise
+        if (!DMA_IN_SLOTS) {
+            if (it + 2 < nit) issue_k((it + 2) * SPLIT + grp, cur);  // K_{it} (ring slot cur) was consumed last iteration
+            if (HAS_NEXT) issue_v((it + 1) * SPLIT + grp, cur ^ 1);  // V_{it-1} (slot cur^1) was consumed last iteration
+        }
 #endif
 #ifdef ATTN_DBG_NOCOMPUTE  // (probe: staging-only timing)
         __syncthreads();
@@ -274,6 +277,18 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (PRE + m < NR) rd(std::integral_constant<int, PRE + m>{});
+                // KV-split form: one LDS-DMA request of the tiles the NEXT iterations read behind each of the first MFMAs
+                // instead of a block of six at the top of the iteration
+                if constexpr (!DMA_IN_SLOTS) {
+                } else if constexpr (m < K_IT) {
+                    if (it + 2 < nit)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (long long)((it + 2) * SPLIT + grp) * KBYTES + m * 4096),
+                                                         (lptr_t)(Ks + cur * KBYTES + (wave * 64 + m * 256) * 16), 16, 0, 0);
+                } else if constexpr (m < K_IT + V_IT && HAS_NEXT) {
+                    constexpr int i = m - K_IT;
+                    const char* src = vones[i] ? ones : vsrc[i] + (long long)((it + 1) * SPLIT + grp) * 128;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vs + (cur ^ 1) * VBYTES + (wave * 64 + i * 256) * 16), 16, 0, 0);
+                }
                 // VALU slice riding behind this MFMA: 16 pairs over 12 slots (2 pairs in the first four, then 1)
                 constexpr int slot = r < 12 ? r : r - 12;
                 constexpr int p0 = slot < 4 ? 2 * slot : 4 + slot, np = slot < 4 ? 2 : 1;
