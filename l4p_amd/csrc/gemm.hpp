@@ -21,6 +21,16 @@
 #pragma once
 #include "common.hpp"
 
+#include <type_traits>
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_<I + 1, N>(f);
+    }
+}
+
 enum { EPI_DENSE = L4P_EPI_DENSE, EPI_QKV = L4P_EPI_QKV, EPI_CONVT = L4P_EPI_CONVT };
 enum { ACT_NONE = L4P_ACT_NONE, ACT_GELU = L4P_ACT_GELU, ACT_RELU = L4P_ACT_RELU };
 
@@ -517,6 +527,49 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         }
         const char* Ab = As + cur * BM * 128;
         const char* Wb = Ws + cur * BN * 128;
+#if !defined(GEMM_DBG_NOMMA) && !defined(GEMM_NO_HANDSCHED)
+        if constexpr (ES == 2 && GLDS && STAGES == 2) {
+            // Hand-scheduled k-tile (bf16, LDS-DMA staging).  hipcc answers every LDS wait with lgkmcnt(0) while an LDS-DMA is
+            // in flight (four full drains of the read queue per k-tile in its own schedule).  The fragment reads are therefore
+            // inline-asm ds_read_b128 with hand-counted lgkmcnt: LDS reads return in order, so MFMA m may issue as soon as the
+            // only outstanding reads are those requested after its two operands.  Read order per k-step: A_0, W_0..W_{TN-1},
+            // A_1..A_{TM-1}; MFMA order per k-step: i-major; PRE reads run ahead, one more is requested behind each MFMA.
+            constexpr int RPK = TM + TN, NR = KK * RPK, NM = KK * TM * TN, PRE = RPK;
+            const unsigned a_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Ab + (wm * (TM * 16) + li) * 128;
+            const unsigned w_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Wb +
+                                    (wn * (TN * 16) + 4 * TN * (li >> 2) + (li & 3)) * 128;
+            const int swa = (li >> 1) & 7, swq = (((li >> 2) & 3) << 1) | ((li >> 1) & 1);
+            unsigned a_ad[KK], w_ad[KK];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                a_ad[kk] = a_base + (((kk * 4 + kg) ^ swa) << 4);
+                w_ad[kk] = w_base + (((kk * 4 + kg) ^ swq) << 4);
+            }
+            u32x4 fr[NR];
+            auto rd = [&fr, &a_ad, &w_ad](auto r_) {  // (explicit captures: asm operands do not trigger implicit capture)
+                constexpr int r = decltype(r_)::value, kk = r / RPK, q = r % RPK;
+                if constexpr (q == 0)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fr[r]) : "v"(a_ad[kk]) : "memory");
+                else if constexpr (q <= TN)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[r]) : "v"(w_ad[kk]), "n"((q - 1) * 512) : "memory");
+                else
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[r]) : "v"(a_ad[kk]), "n"((q - TN) * 2048) : "memory");
+            };
+            static_for_<0, (PRE < NR ? PRE : NR)>(rd);
+            static_for_<0, NM>([&](auto m_) {
+                constexpr int m = decltype(m_)::value, kk = m / (TM * TN), i = (m % (TM * TN)) / TN, j = m % TN;
+                constexpr int ra = kk * RPK + (i == 0 ? 0 : TN + i), rw = kk * RPK + 1 + j;  // reads holding A_i / W_j
+                constexpr int need = ra > rw ? ra : rw;
+                constexpr int issued = (PRE + m < NR) ? PRE + m : NR;
+                static_assert(need < issued, "operand requested before use");
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(issued - need - 1 > 15 ? 15 : issued - need - 1) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i][j] = mma16(__builtin_bit_cast(frag_t, fr[rw]), __builtin_bit_cast(frag_t, fr[ra]), acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PRE + m < NR) rd(std::integral_constant<int, PRE + m>{});
+            });
+        } else
+#endif
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             frag_t xf[TM], wf[TN];
