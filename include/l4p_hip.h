@@ -64,6 +64,7 @@ long long l4p_prof_detail(char* buf, long long cap);
 #define L4P_EPI_DENSE 0
 #define L4P_EPI_QKV 1
 #define L4P_EPI_CONVT 2
+#define L4P_EPI_MASKDOT 3
 #define L4P_ACT_NONE 0
 #define L4P_ACT_GELU 1
 #define L4P_ACT_RELU 2
@@ -116,6 +117,13 @@ typedef struct l4p_gemm_desc {
      * caller-provided), a second kernel sums them and applies the epilogue. */
     int splitk;
     float* partial;
+    /* L4P_EPI_MASKDOT (the tracker's last up-scaling ConvTranspose fused with the hyper-network mask product,
+     * mask_decoder.py:136-139): the activated outputs are not stored; for every 32-column chunk c of row m
+     *   out_f32[(c * 3 + i) * M + m] = sum_{n in chunk} act(acc + bias)[m][n] * hyper[((m / hyper_rows) * 3 + i) * Cout + n % Cout]
+     * (i = 0..2).  Columns are tap-major with Cout (a multiple of 32, zero padded) columns per tap;
+     * l4p_mask_gather sums a tap's chunks and scatters the taps to the up-scaled grid. */
+    const float* hyper;
+    int hyper_rows;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
@@ -239,6 +247,11 @@ int l4p_small_attn(l4p_stream stream, int dtype, int kind, const void* q, const 
 /* masks[n][m][vox] = hyper[n][m][:] . up[n][vox][:]  (mask_decoder.py:139); up channels-last T. */
 int l4p_mask_product(l4p_stream stream, int dtype, const void* up, const float* hyper, float* masks, int N,
                      long long vox, int C);
+
+/* masks[n][i][t][y][x] (the [N][3][T][2h][2w] logits of mask_decoder.py:139) from the L4P_EPI_MASKDOT partial sums of
+ * the (1,2,2) ConvTranspose over M = N*T*h*w rows: row m = ((n*T + t)*h + y/2)*w + x/2, tap = (y%2)*2 + x%2, chunks_per_tap
+ * chunks each. */
+int l4p_mask_gather(l4p_stream stream, const float* partial, float* masks, int N, int T, int h, int w, int chunks_per_tap);
 
 /* Fused read-out (sparse_heads.py:572-589,645-647): trilinear (align_corners=False) resize of masks
  * [N][3][T][h][w] to H x W, soft-argmax of channel 0 (traj [N][2][T]), spatial mean of channel 1

@@ -13,7 +13,7 @@ from typing import Optional
 L4P_BF16 = 0
 L4P_F32 = 1
 
-EPI_DENSE, EPI_QKV, EPI_CONVT = 0, 1, 2
+EPI_DENSE, EPI_QKV, EPI_CONVT, EPI_MASKDOT = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("out_relu_T", C.c_void_p),
         ("k_tiled", C.c_void_p),
         ("splitk", C.c_int), ("partial", C.c_void_p),
+        ("hyper", C.c_void_p), ("hyper_rows", C.c_int),
     ]
 
 
@@ -102,6 +103,7 @@ SIGNATURES = {
     "l4p_fill_rows": (_I, [_VP, _VP, _VP, _LL, _I, _LL, _LL, _LL]),
     "l4p_small_attn": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I]),
     "l4p_mask_product": (_I, [_VP, _I, _VP, _VP, _VP, _I, _LL, _I]),
+    "l4p_mask_gather": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
     "l4p_track_readout": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     "l4p_track_prepare": (_I, [_VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _I]),
     "l4p_track_commit": (_I, [_VP] * 9 + [_I] * 5 + [_VP] * 5 + [_I, _I]),

@@ -14,6 +14,7 @@ int launch_fill_rows(float* out, const float* v, long long rows, int C, long lon
                      long long group_off, hipStream_t stream);
 int launch_small_attn(int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P, int D,
                       int heads, hipStream_t stream);
+int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, int w, int cpt, hipStream_t stream);
 int launch_mask_product(int dtype, const void* up, const float* hyper, float* masks, int N, long long vox, int Cc,
                         hipStream_t stream);
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
@@ -53,6 +54,9 @@ int l4p_small_attn(l4p_stream s, int dtype, int kind, const void* q, const void*
 int l4p_mask_product(l4p_stream s, int dtype, const void* up, const float* hyper, float* masks, int N, long long vox,
                      int C) {
     return launch_mask_product(dtype, up, hyper, masks, N, vox, C, (hipStream_t)s);
+}
+int l4p_mask_gather(l4p_stream s, const float* partial, float* masks, int N, int T, int h, int w, int chunks_per_tap) {
+    return launch_mask_gather(partial, masks, N, T, h, w, chunks_per_tap, (hipStream_t)s);
 }
 int l4p_track_readout(l4p_stream s, const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w,
                       int H, int W) {

@@ -31,7 +31,7 @@ __device__ __forceinline__ void static_for_(F&& f) {
     }
 }
 
-enum { EPI_DENSE = L4P_EPI_DENSE, EPI_QKV = L4P_EPI_QKV, EPI_CONVT = L4P_EPI_CONVT };
+enum { EPI_DENSE = L4P_EPI_DENSE, EPI_QKV = L4P_EPI_QKV, EPI_CONVT = L4P_EPI_CONVT, EPI_MASKDOT = L4P_EPI_MASKDOT };
 enum { ACT_NONE = L4P_ACT_NONE, ACT_GELU = L4P_ACT_GELU, ACT_RELU = L4P_ACT_RELU };
 
 // The kernel parameter block IS the public descriptor (include/l4p_hip.h): plain pointers and ints.
@@ -46,6 +46,83 @@ __device__ __attribute__((aligned(16))) static const unsigned g_zero_chunk[4] = 
 template <typename T, int NV>
 __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v)[NV], const float (&bv)[NV],
                                                   const long long (&coff)[NV / 8], int m, int nb);
+
+// L4P_EPI_MASKDOT epilogue (see include/l4p_hip.h): activated outputs x the three hyper-network vectors of the row's
+// query, summed over the 32-column chunk the lane shares with 1 (NV = 16) or 3 (NV = 8) neighbours.  Kept apart from
+// gemm_epilogue so that its 3 x NV hyper-vector registers never weigh on the ordinary epilogues.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_maskdot(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0, int li,
+                                                      int kg) {
+    constexpr int NV = 4 * TN;
+    const int nb = n_wave0 + NV * kg;
+    if (nb >= p.N) return;  // (N % 32 == 0: the lanes sharing a chunk leave together)
+    const int co = nb % p.Cout;
+    float bv[NV], hv[3][NV];
+#pragma unroll
+    for (int c = 0; c < NV; c += 4) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + nb + c) : z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[c + e] = b4[e];
+    }
+    int hq = -1;
+    const bool writer = NV == 16 ? (kg & 1) == 0 : kg == 0;
+#pragma nounroll
+    for (int i = 0; i < TM; ++i) {
+        float v[NV];
+#define L4P_ACC_ROW(I)                                                                                   \
+    case I:                                                                                              \
+        if (I < TM) {                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[I < TM ? I : 0][j][r]; \
+        }                                                                                                \
+        break;
+        switch (i) {
+            L4P_ACC_ROW(0) L4P_ACC_ROW(1) L4P_ACC_ROW(2) L4P_ACC_ROW(3) L4P_ACC_ROW(4) L4P_ACC_ROW(5) L4P_ACC_ROW(6) L4P_ACC_ROW(7)
+        }
+#undef L4P_ACC_ROW
+        const int m = m_wave0 + i * 16 + li;
+        const bool ok = m < p.M;
+        const int qn = (ok ? m : p.M - 1) / p.hyper_rows;
+        if (qn != hq) {  // (a tile normally lies inside one query: loaded once)
+#pragma unroll
+            for (int h = 0; h < 3; ++h)
+#pragma unroll
+                for (int c = 0; c < NV; c += 4) {
+                    const f32x4 h4 = *(const f32x4*)(p.hyper + ((long long)qn * 3 + h) * p.Cout + co + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[h][c + e] = h4[e];
+                }
+            hq = qn;
+        }
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            float x = v[c] + bv[c];
+            if (p.act == ACT_GELU)
+                x = gelu_for<T>(x);
+            else if (p.act == ACT_RELU)
+                x = fmaxf(x, 0.f);
+            d0 += x * hv[0][c];
+            d1 += x * hv[1][c];
+            d2 += x * hv[2][c];
+        }
+        d0 += __shfl_xor(d0, 16);
+        d1 += __shfl_xor(d1, 16);
+        d2 += __shfl_xor(d2, 16);
+        if (NV == 8) {
+            d0 += __shfl_xor(d0, 32);
+            d1 += __shfl_xor(d1, 32);
+            d2 += __shfl_xor(d2, 32);
+        }
+        if (writer && ok) {
+            float* op = p.out_f32 + (long long)(nb >> 5) * 3 * p.M + m;  // [chunk][i][m]: 16 consecutive rows per store
+            op[0] = d0;
+            op[(long long)p.M] = d1;
+            op[2 * (long long)p.M] = d2;
+        }
+    }
+}
 
 // ROLLED = false: the row loop is fully unrolled (registers die row by row: 120 VGPRs for the 128x128 kernel, which
 // keeps 2-3 workgroups per CU).  ROLLED = true (gemm8p.hpp, alone on its CU with registers to spare): the row body -
@@ -620,6 +697,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         return;
     }
 
+    if (p.epi == EPI_MASKDOT) {
+        gemm_epilogue_maskdot<T, TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), li, kg);
+        return;
+    }
     gemm_epilogue<T, TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), li, kg);
 }
 

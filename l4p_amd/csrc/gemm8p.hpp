@@ -245,6 +245,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-    gemm_epilogue<T, TM, TN, true>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
+    if (p.epi == EPI_MASKDOT)
+        gemm_epilogue_maskdot<T, TM, TN>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
+    else
+        gemm_epilogue<T, TM, TN, true>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
 #endif
 }

@@ -692,6 +692,42 @@ int launch_mask_product(int dtype, const void* up, const float* hyper, float* ma
     return 0;
 }
 
+// masks[n][i][t][y][x] = sum over the chunks of tap (y%2, x%2) of the L4P_EPI_MASKDOT partial sums [chunk][i][m] of row
+// m = ((n*T + t)*h + y/2)*w + x/2 (see include/l4p_hip.h).  One thread per output voxel, fixed summation order.
+__global__ void mask_gather_kernel(const float* __restrict__ partial, float* __restrict__ masks, int N, int T, int h, int w,
+                                   int cpt) {
+    const int H2 = 2 * h, W2 = 2 * w;
+    const long long vox = (long long)T * H2 * W2, total = vox * N, M = (long long)N * T * h * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W2);
+        long long r = i / W2;
+        const int y = (int)(r % H2);
+        r /= H2;
+        const int t = (int)(r % T), n = (int)(r / T);
+        const long long m = (((long long)n * T + t) * h + (y >> 1)) * w + (x >> 1);
+        const int tap = (y & 1) * 2 + (x & 1);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int c = 0; c < cpt; ++c) {
+            const float* pp = partial + (long long)(tap * cpt + c) * 3 * M + m;
+            a0 += pp[0];
+            a1 += pp[M];
+            a2 += pp[2 * M];
+        }
+        const long long p = ((long long)t * H2 + y) * W2 + x;
+        masks[((long long)n * 3 + 0) * vox + p] = a0;
+        masks[((long long)n * 3 + 1) * vox + p] = a1;
+        masks[((long long)n * 3 + 2) * vox + p] = a2;
+    }
+}
+
+int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, int w, int cpt, hipStream_t stream) {
+    const long long total = (long long)N * T * 4 * h * w;
+    ProfScope prof(PROF_TRACK, stream, "mask_gather");
+    hipLaunchKernelGGL(mask_gather_kernel, dim3(GRID1D(total, 16384)), dim3(256), 0, stream, partial, masks, N, T, h, w, cpt);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
                          int W, hipStream_t stream) {
     const size_t lds = (size_t)3 * h * w * 4;

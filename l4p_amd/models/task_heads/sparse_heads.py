@@ -17,7 +17,7 @@ from typing import Dict, List, Literal, Optional, Tuple
 import torch
 
 from ... import _lib, ops
-from ..._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, GemmDesc
+from ..._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, EPI_MASKDOT, GemmDesc
 from ...ops import _p, _stream
 
 
@@ -213,14 +213,16 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
 
         # --- hyper-network MLPs on the 3 mask tokens (mask_decoder.py:130-133,160-180) ---
         d1 = Cc // self.decoding_out_dim_factor
-        hyper = torch.empty((N, 3, d1), **f32)
+        d1p = (d1 + 31) // 32 * 32  # channels per tap of the padded up1 weight (packing.py)
+        cpt = d1p // 32             # 32-column chunks per tap
+        hyper = torch.zeros((N, 3, d1p), **f32)
         for i in range(3):
             h1 = torch.empty((N, Cc), dtype=td, device=dev)
             _gemm(hsT, N, Cc, 6 * Cc, self._w(f"hyper{i}.0.w"), Cc, bias=self._w(f"hyper{i}.0.b"), act=ACT_RELU, out_T=h1,
                   a_off=i * Cc)
             h2 = self._proj(h1, f"hyper{i}.1", Cc, act=ACT_RELU)
-            _gemm(h2, N, Cc, Cc, self._w(f"hyper{i}.2.w"), d1, bias=self._w(f"hyper{i}.2.b"), out_f32=hyper, ldc=3 * d1,
-                  f32_off=i * d1)
+            _gemm(h2, N, Cc, Cc, self._w(f"hyper{i}.2.w"), d1, bias=self._w(f"hyper{i}.2.b"), out_f32=hyper, ldc=3 * d1p,
+                  f32_off=i * d1p)
         # prompt feature for the next window (sparse_heads.py:650-658): io token 5
         new_pfeat = torch.empty((N, Cc), **f32)
         _gemm(hsT, N, Cc, 6 * Cc, self._w("prompt_lin.w"), Cc, bias=self._w("prompt_lin.b"), out_f32=new_pfeat, a_off=5 * Cc)
@@ -251,13 +253,23 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         _lib.check(lib.l4p_layernorm_ex(_stream(), dt, _p(u0), _p(self._w("up_ln.g")), _p(self._w("up_ln.b")), 1e-6, _p(u0T),
                                         None, u0.shape[0], d0, None, 0, None, ACT_GELU), "l4p_layernorm_ex(up)")
         del u0
-        u1 = ops.conv_transpose(u0T.view(N, nt * 2, nh * 2, nw * 2, d0), self._w("up1.w"), d1, (1, 2, 2),
-                                bias_taps=self._w("up1.b"), act=ACT_GELU)
-        del u0T
+        # up1 (ConvTranspose (1,2,2) + GELU) fused with the hyper-network mask product (mask_decoder.py:136-139): the
+        # [N,16,64,64,176] activation is never written; the GEMM epilogue leaves 3 partial sums per 32-column chunk
         Tl, hl, wl = nt * 2, nh * 4, nw * 4
+        M1 = u0T.shape[0]
+        partial = torch.empty((4 * cpt, 3, M1), **f32)
+        dsc = GemmDesc()
+        dsc.A, dsc.lda, dsc.W, dsc.ldw = _p(u0T), d0, _p(self._w("up1.w")), d0
+        dsc.M, dsc.N, dsc.K = M1, 4 * d1p, d0
+        dsc.bias, dsc.act = _p(self._w("up1.b")), ACT_GELU
+        dsc.out_f32 = _p(partial)
+        dsc.epi, dsc.Cout = EPI_MASKDOT, d1p
+        dsc.hyper, dsc.hyper_rows = _p(hyper), M1 // N
+        _lib.check(lib.l4p_gemm(_stream(), dt, C.byref(dsc)), "l4p_gemm(up1 + mask product)")
+        del u0T
         masks = torch.empty((N, 3, Tl, hl, wl), **f32)
-        _lib.check(lib.l4p_mask_product(_stream(), dt, _p(u1), _p(hyper), _p(masks), N, Tl * hl * wl, d1), "l4p_mask_product")
-        del u1
+        _lib.check(lib.l4p_mask_gather(_stream(), _p(partial), _p(masks), N, Tl, nh * 2, nw * 2, cpt), "l4p_mask_gather")
+        del partial
         assert Tl == T, "temporal size of the decoded masks must equal the window length"
         traj = torch.empty((N, 2, T), **f32)
         vis = torch.empty((N, T), **f32)

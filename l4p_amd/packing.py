@@ -191,9 +191,14 @@ def pack_track(pk: Packer, sd: Dict[str, torch.Tensor], c: ModelCfg, task: str =
     pk.T(o + "up0.w", convT_matrix(w0))
     pk.F(o + "up0.b", sd[m + "output_upscaling.0.bias"].repeat(8))
     norm(m + "output_upscaling.1", o + "up_ln")
+    # last up-scaling ConvTranspose (1,2,2): every tap's d1 output channels are zero-padded to a multiple of 32 so that
+    # a 32-column chunk of the fused mask-product epilogue (L4P_EPI_MASKDOT) never straddles two taps
     w3 = sd[m + "output_upscaling.3.weight"]
-    pk.T(o + "up1.w", convT_matrix(w3))
-    pk.F(o + "up1.b", sd[m + "output_upscaling.3.bias"].repeat(4))
+    d1 = w3.shape[1]
+    d1p = (d1 + 31) // 32 * 32
+    w3m = convT_matrix(w3).reshape(4, d1, -1)
+    pk.T(o + "up1.w", torch.nn.functional.pad(w3m, (0, 0, 0, d1p - d1)).reshape(4 * d1p, -1))
+    pk.F(o + "up1.b", torch.nn.functional.pad(sd[m + "output_upscaling.3.bias"].float(), (0, d1p - d1)).repeat(4))
     for i in range(3):
         for j in range(3):
             pk.T(f"{o}hyper{i}.{j}.w", sd[f"{m}output_hypernetworks_mlps.{i}.layers.{j}.weight"])
