@@ -611,7 +611,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
             // inline-asm ds_read_b128 with hand-counted lgkmcnt: LDS reads return in order, so MFMA m may issue as soon as the
             // only outstanding reads are those requested after its two operands.  Read order per k-step: A_0, W_0..W_{TN-1},
             // A_1..A_{TM-1}; MFMA order per k-step: i-major; PRE reads run ahead, one more is requested behind each MFMA.
-            constexpr int RPK = TM + TN, NR = KK * RPK, NM = KK * TM * TN, PRE = RPK;
+            #ifndef GEMM_HS_PRE
+#define GEMM_HS_PRE (TM + TN)
+#endif
+            constexpr int RPK = TM + TN, NR = KK * RPK, NM = KK * TM * TN, PRE = (GEMM_HS_PRE) < NR ? (GEMM_HS_PRE) : NR;
             const unsigned a_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Ab + (wm * (TM * 16) + li) * 128;
             const unsigned w_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)Wb +
                                     (wn * (TN * 16) + 4 * TN * (li >> 2) + (li & 3)) * 128;
