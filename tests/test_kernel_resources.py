@@ -1,0 +1,45 @@
+"""Build-time guard (no GPU needed): the hot MFMA kernels must not spill.  A spill inside the 8-phase GEMM loop is not just
+slow - the compiler waits `vmcnt(0)` for its scratch reload and thereby drains the LDS-DMA queue the loop is built around
+(measured: -35 %)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _usage(src):
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", f"-I{ROOT}/include",
+           "-c", os.path.join(ROOT, "l4p_amd", "csrc", src), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, name = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            res[name] = {}
+        for key in ("VGPRs", "ScratchSize [bytes/lane]"):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m and name:
+                res[name][key] = int(m.group(1))
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_hot_kernels_do_not_spill():
+    gemm = _usage("gemm_bf16.hip")
+    hot = [k for k in gemm if "gemm8p_kernel" in k or ("gemm_kernel" in k and "ELb1E" in k)]
+    assert len(hot) >= 4, sorted(gemm)
+    for k in hot:
+        assert gemm[k]["ScratchSize [bytes/lane]"] == 0, (k, gemm[k])
+        assert gemm[k]["VGPRs"] <= 256
+    attn = _usage("attention.hip")
+    hot = [k for k in attn if "DF16b" in k]
+    assert hot
+    for k in hot:
+        assert attn[k]["ScratchSize [bytes/lane]"] == 0, (k, attn[k])
