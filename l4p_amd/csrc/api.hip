@@ -126,8 +126,16 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct EncWs {
     float* x;
     char *xn, *qk, *vt, *ao, *hb;
+    float* sk;  // split-K partials of fc2 (small batches only)
     size_t total;
 };
+// fc2 (K = mlp_hidden = 6144: 96 k-tiles in a row) at batch 1 gives each CU one latency-bound chain of k-tiles; two K slices
+// double the workgroups in flight (69 -> ~50 us including the reduction pass).  Not worth it once M fills the chip.
+static int enc_fc2_splitk(const l4p_engine* e, size_t M) {
+    const l4p_encoder_cfg& c = e->enc;
+    const size_t tiles = ((M + 127) / 128) * (((size_t)c.dim + 63) / 64);
+    return (e->dtype == L4P_BF16 && tiles < 512 && c.mlp_hidden >= 4096) ? 2 : 1;
+}
 static EncWs enc_layout(const l4p_engine* e, int B, char* base) {
     const l4p_encoder_cfg& c = e->enc;
     const size_t es = e->dtype == L4P_BF16 ? 2 : 4;
@@ -147,6 +155,8 @@ static EncWs enc_layout(const l4p_engine* e, int B, char* base) {
     off += align256(M * c.dim * es);
     w.hb = base + off;
     off += align256(M * c.mlp_hidden * es);
+    w.sk = (float*)(base + off);
+    if (enc_fc2_splitk(e, M) > 1) off += align256((size_t)enc_fc2_splitk(e, M) * M * c.dim * 4);
     w.total = off;
     return w;
 }
@@ -341,6 +351,8 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
         p.ldr = C;
         p.out_f32 = w.x;
         p.ldc = C;
+        p.splitk = enc_fc2_splitk(e, (size_t)M);
+        p.partial = p.splitk > 1 ? w.sk : nullptr;
         rc = launch_gemm(dt, 0, p, stream);
         if (rc) return rc;
         if (l + 1 < c.depth) {
