@@ -235,3 +235,50 @@ def test_conv3d_relu_copy_and_kpadded_gemm(dev, mode):
         wk, wk_ref = as_mode(rnd((176, K), 83, K ** -0.5), mode)
         yT, _ = ops.gemm(a, ops.pad_rows(wk), 176)
         check(yT, a_ref @ wk_ref.t(), mode, True)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("Nq,T,h,w,Cin,d1", [(3, 2, 8, 8, 96, 40), (2, 4, 16, 16, 352, 176)])
+def test_maskdot_fused_upscaling(dev, mode, Nq, T, h, w, Cin, d1):
+    """L4P_EPI_MASKDOT + l4p_mask_gather (mask_decoder.py:136-139): GELU(ConvTranspose3d(k = s = (1,2,2))) contracted with
+    the per-query hyper-network vectors, against the unfused statement on the same (storage-rounded) inputs.  d1 = 40
+    exercises the per-tap zero padding to a multiple of 32; the second shape is the full model's geometry."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+    from l4p_amd._lib import EPI_MASKDOT, GemmDesc
+
+    x, x_ref = as_mode(rnd((Nq, T, h, w, Cin), 90), mode)
+    wt = rnd((Cin, d1, 1, 2, 2), 91, Cin ** -0.5)  # ConvTranspose3d layout
+    bias = rnd((d1,), 92)
+    hyper = rnd((Nq, 3, d1), 93)
+    d1p = (d1 + 31) // 32 * 32
+    wm = wt.permute(2, 3, 4, 1, 0).reshape(4, d1, Cin)
+    wp, w_ref = as_mode(F.pad(wm, (0, 0, 0, d1p - d1)).reshape(4 * d1p, Cin), mode)
+    up = F.gelu(F.conv_transpose3d(x_ref.permute(0, 4, 1, 2, 3), w_ref.view(4, d1p, Cin)[:, :d1].reshape(1, 2, 2, d1, Cin)
+                                   .permute(4, 3, 0, 1, 2), bias, stride=(1, 2, 2)))  # [Nq, d1, T, 2h, 2w]
+    ref = torch.einsum("nic,nctyx->nityx", hyper, up)
+    M = Nq * T * h * w
+    cpt = d1p // 32
+    hp = torch.zeros(Nq, 3, d1p)
+    hp[..., :d1] = hyper
+    hp = hp.cuda()
+    bp = F.pad(bias, (0, d1p - d1)).repeat(4).cuda()
+    partial = torch.empty(4 * cpt, 3, M, dtype=torch.float32, device="cuda")
+    wpad = ops.pad_rows(wp, 256)
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = x.data_ptr(), Cin, wpad.data_ptr(), Cin
+    d.M, d.N, d.K = M, 4 * d1p, Cin
+    d.bias, d.act = bp.data_ptr(), ACT_GELU
+    d.out_f32 = partial.data_ptr()
+    d.epi, d.Cout = EPI_MASKDOT, d1p
+    d.hyper, d.hyper_rows = hp.data_ptr(), M // Nq
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.l4p_gemm(st, mode, C.byref(d)), "l4p_gemm(maskdot)")
+    masks = torch.empty(Nq, 3, T, 2 * h, 2 * w, dtype=torch.float32, device="cuda")
+    _lib.check(lib.l4p_mask_gather(st, partial.data_ptr(), masks.data_ptr(), Nq, T, h, w, cpt), "l4p_mask_gather")
+    torch.cuda.synchronize()
+    # bf16 mode: the fused path keeps the activation in float (the unfused engine path rounds it to bf16), so it is the
+    # more accurate of the two; the bf16 GELU is the A&S erfc form (1.5e-7 absolute)
+    check(masks, ref, mode, False)
