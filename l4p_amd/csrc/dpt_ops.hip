@@ -25,31 +25,31 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, bool align, 
     i1 = i0 + (i0 < in - 1 ? 1 : 0);
 }
 
+// One workgroup row = one output (b, to, ho) line (blockIdx.y): its t / h source indices and weights are wave-uniform
+// scalars, and a thread only splits its x index into (wo, channel group) - the flat-index form spent five integer
+// divisions per 16 output bytes.
 template <typename T>
-__global__ void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Ti, int Hi, int Wi, int To, int Ho,
-                                int Wo, int C, int align) {
+__global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Ti, int Hi, int Wi,
+                                                       int To, int Ho, int Wo, int C, int align) {
     constexpr int V = 8;  // channels per thread
     const int cv = C / V;
-    const long long total = (long long)B * To * Ho * Wo * cv;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * V;
-        long long r = i / cv;
-        const int wo = (int)(r % Wo);
-        r /= Wo;
-        const int ho = (int)(r % Ho);
-        r /= Ho;
-        const int to = (int)(r % To);
-        const int b = (int)(r / To);
-        int t0, t1, h0, h1, w0, w1;
-        float lt, lh, lw;
-        src_index(to, Ti, To, align, t0, t1, lt);
-        src_index(ho, Hi, Ho, align, h0, h1, lh);
+    const int line = blockIdx.y + blockIdx.z * 65535;  // (b * To + to) * Ho + ho
+    if (line >= B * To * Ho) return;
+    const int ho = line % Ho, to = (line / Ho) % To, b = line / (Ho * To);
+    int t0, t1, h0, h1;
+    float lt, lh;
+    src_index(to, Ti, To, align, t0, t1, lt);
+    src_index(ho, Hi, Ho, align, h0, h1, lh);
+    const T* xb = x + (long long)b * Ti * Hi * Wi * C;
+    T* yl = y + (long long)line * Wo * C;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Wo * cv; i += gridDim.x * 256) {
+        const int wo = i / cv, c = (i - wo * cv) * V;
+        int w0, w1;
+        float lw;
         src_index(wo, Wi, Wo, align, w0, w1, lw);
         float acc[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[k] = 0.f;
-        const T* xb = x + (long long)b * Ti * Hi * Wi * C + c;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -58,7 +58,7 @@ __global__ void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int 
                 for (int cc = 0; cc < 2; ++cc) {
                     const float wgt = (a ? lt : 1.f - lt) * (bb ? lh : 1.f - lh) * (cc ? lw : 1.f - lw);
                     if (wgt == 0.f) continue;  // an axis that is not resized (lambda == 0) has one tap, not two: skip the load
-                    const T* p = xb + (((long long)(a ? t1 : t0) * Hi + (bb ? h1 : h0)) * Wi + (cc ? w1 : w0)) * C;
+                    const T* p = xb + (((long long)(a ? t1 : t0) * Hi + (bb ? h1 : h0)) * Wi + (cc ? w1 : w0)) * C + c;
                     if (sizeof(T) == 2) {
                         const bf16x8 v = *(const bf16x8*)p;
 #pragma unroll
@@ -72,7 +72,7 @@ __global__ void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int 
                         }
                     }
                 }
-        T* yp = y + ((((long long)b * To + to) * Ho + ho) * Wo + wo) * C + c;
+        T* yp = yl + (long long)wo * C + c;
         if (sizeof(T) == 2) {
             bf16x8 o;
 #pragma unroll
@@ -91,14 +91,14 @@ int launch_upsample(int dtype, const void* x, void* y, int B, int Ti, int Hi, in
         l4p_set_error("upsample: C=%d must be a multiple of 8", C);
         return L4P_E_INVALID;
     }
-    const long long total = (long long)B * To * Ho * Wo * (C / 8);
-    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    const int lines = B * To * Ho, per_line = Wo * (C / 8);
+    const dim3 grid((per_line + 255) / 256 < 64 ? (per_line + 255) / 256 : 64, lines < 65535 ? lines : 65535, (lines + 65534) / 65535);
     ProfScope prof(PROF_ELEMENTWISE, stream, "upsample");
     if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(upsample_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, B, Ti,
+        hipLaunchKernelGGL(upsample_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, B, Ti,
                            Hi, Wi, To, Ho, Wo, C, align);
     else
-        hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (float*)y, B, Ti, Hi,
+        hipLaunchKernelGGL(upsample_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)y, B, Ti, Hi,
                            Wi, To, Ho, Wo, C, align);
     HIP_TRY(hipGetLastError());
     return 0;
