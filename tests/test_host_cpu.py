@@ -105,3 +105,28 @@ def test_config_surface_and_loud_failure_without_gpu():
     if not torch.cuda.is_available():
         with pytest.raises((RuntimeError, _lib.L4PHipError)):
             net.forward({"rgb_b3thw": torch.zeros(1, 3, 16, 224, 224)}, ["depth"])
+
+
+def test_bench_algorithmic_flops_match_survey():
+    """bench.py's roofline numerators are the SURVEY.md §8(d) figures (2*MAC, padding excluded)."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from l4p_amd.weights import ModelCfg
+
+    cfg = ModelCfg.full()
+    S, D = cfg.tokens, cfg.dim
+    fl = bench.algorithmic_flops(cfg, ["track_2d"], 1)  # the tracker needs all 40 encoder blocks
+    assert fl["attention"] == 944_892_805_120  # 4 * 2048^2 * 88 * 16 * 40
+    tracker = 73.81e9  # per query and window
+    assert abs((fl["gemm"] - tracker) + fl["attention"] - 5_085_581_017_088) <= 1e-6 * 5_085_581_017_088
+    dense = bench.algorithmic_flops(cfg, ["depth"], 0)
+    enc36 = 2.0 * S * (3 * 2 * 14 * 14) * D + 36 * 2.0 * S * (D * 3 * D + D * D + 2 * D * cfg.mlp_hidden)
+    head = dense["gemm"] + dense["conv3d"] - enc36
+    # the engine applies the fusion blocks' 1x1x1 out_conv before the up-sampling (DESIGN.md §4): 1.2 % fewer FLOPs than the
+    # reference graph, and bench.py counts what is executed
+    assert 0.985 * 2_838_780_444_672 <= head <= 2_838_780_444_672, head
