@@ -22,6 +22,9 @@
 //  * the softmax denominator comes out of the MFMA: padding row d = DH of the V^T tile is sourced
 //    from a constant "ones" chunk, so O^T[DH][q] = sum_k P[q][k] with exactly the weights used for O.
 //  * exp via v_exp_f32 (exp2 of non-positive arguments), scale*log2(e) folded into one fma.
+//  * the KV loop is software pipelined (S of block j+1 is built while P of block j is formed; the two score register
+//    sets are used ping-pong) and, for bf16, hand scheduled (template flag HS: inline-asm fragment reads with counted
+//    lgkmcnt, the vector work sliced behind the MFMAs) - see the comments at `step` below.
 #include <cstdlib>
 #include <type_traits>
 
