@@ -92,3 +92,20 @@ def test_shared_first_window_keys_equal_per_track_path(dev, mini, precision, mon
     torch.cuda.synchronize()
     for key in ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]:
         assert torch.equal(fast[key], slow[key]), key
+
+
+def test_clip_streams_equal_serial(dev, mini, monkeypatch):
+    """B > 1: every clip's tracker runs on its own HIP stream; the result must equal the serial order bit for bit."""
+    cfg, sd = mini
+    model = build(cfg, sd, "bf16")
+    b1 = make_batch(16, 6)
+    batch = {k: (torch.cat([v, v.flip(-1) if k == "rgb_b3thw" else v], dim=0) if torch.is_tensor(v) else v) for k, v in b1.items()}
+    with torch.no_grad():
+        monkeypatch.setenv("L4P_TRACK_STREAMS", "1")
+        a = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+        monkeypatch.setenv("L4P_TRACK_STREAMS", "0")
+        b = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+    torch.cuda.synchronize()
+    for key in ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]:
+        assert a[key].shape[0] == 2 and torch.equal(a[key], b[key]), key
+    assert not torch.equal(a["track_2d_traj_est_bn2t"][0], a["track_2d_traj_est_bn2t"][1])  # the two clips differ
