@@ -45,7 +45,7 @@ int l4p_abi_version(void);
 
 /* Optional per-kernel-class timing: when enabled every kernel launch is bracketed by a HIP event pair
  * recorded on the launch stream (bench.py's live roofline numbers).  Classes: gemm, conv3d, attention,
- * layernorm, elementwise, track.  l4p_prof_read sums the pair durations of one class since the last
+ * layernorm, elementwise, track, preprocess.  l4p_prof_read sums the pair durations of one class since the last
  * reset; the caller synchronises the stream first. */
 int l4p_prof_enable(int on);
 int l4p_prof_reset(void);
@@ -315,6 +315,37 @@ typedef struct l4p_dpt_cfg {
 size_t l4p_dpt_workspace_bytes(const l4p_engine* e, const l4p_dpt_cfg* cfg, int B);
 int l4p_dpt_forward(l4p_engine* e, l4p_stream stream, const char* task, const l4p_dpt_cfg* cfg, const void* const* hooks,
                     int B, void* workspace, size_t ws_bytes, float* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Clip preparation (the caller side of the hot path): decoded uint8 frames in HBM ->
+ * the network's input tensor.  Replaces VideoDataset.getitem_helper's per-frame PIL resize-blur-resize +
+ * to_tensor (l4p/data/video_dataset.py:86-93) and L4PDataset.__getitem__'s mirror-pad / resize / crop /
+ * normalise (l4p/data/l4p_dataset_mini.py:543-587, :126-190, :236-288, :290-391).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* HOST function (no GPU work): Pillow's coefficient tables for one axis of Image.resize(BILINEAR) over the
+ * full axis (libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc: triangle filter, support scaled
+ * by the down-scale factor, 22-bit fixed point).  bounds: host int[2*out_size] (first tap, tap count);
+ * coeffs: host int[out_size * ksize].  With bounds == NULL or coeffs == NULL only *ksize is written. */
+int l4p_pil_coeffs(int in_size, int out_size, int* bounds, int* coeffs, int coeffs_cap, int* ksize);
+
+/* One 8-bit pass of Pillow's resampler on n_img images [in_h][in_w][channels] (uint8, device):
+ * axis 1 = horizontal (in_w -> out_size), axis 0 = vertical (in_h -> out_size).  bounds / coeffs: the tables of
+ * l4p_pil_coeffs copied to the device.  Integer arithmetic, bit-exact with Pillow. */
+int l4p_pil_resample_u8(l4p_stream stream, const unsigned char* src, unsigned char* dst, long long n_img, int in_h,
+                        int in_w, int channels, int axis, int out_size, const int* bounds, const int* coeffs, int ksize);
+
+/* rgb_out[c][t][y][x] (float, [3][T_out][out_h][out_w]) =
+ *   (bilinear(frame[frame_index[t]] / 255 resized to res_h x res_w)[y + crop_i0][x + crop_j0] - mean[c]) / std[c]
+ * with F.interpolate(align_corners=False) arithmetic (skipped, as in the reference, when res == in).  frame_index
+ * (device int[T_out]) carries stride, temporal mirror-padding and the temporal crop.  mean3 / std3: HOST float[3],
+ * read at call time.  frames: uint8 [n][in_h][in_w][3]; OR, when vbounds != NULL, [n][src_h][in_w][3] = the frames
+ * before a final vertical Pillow pass src_h -> in_h (tables vbounds / vcoeffs / vksize on the device), which is then
+ * evaluated on the fly for the <= 4 pixels an output pixel needs instead of being written out. */
+int l4p_clip_resize_normalize(l4p_stream stream, const unsigned char* frames, const int* frame_index, float* rgb_out,
+                              int T_out, int in_h, int in_w, int res_h, int res_w, int crop_i0, int crop_j0, int out_h,
+                              int out_w, const float* mean3, const float* std3, int src_h, const int* vbounds,
+                              const int* vcoeffs, int vksize);
 
 #ifdef __cplusplus
 }

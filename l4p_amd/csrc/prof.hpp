@@ -13,6 +13,7 @@ enum ProfClass {
     PROF_LAYERNORM,
     PROF_ELEMENTWISE,   // cast / patch gather / upsample / head_out / alignment / pose
     PROF_TRACK,         // tracker-specific small kernels
+    PROF_PREP,          // clip preparation (preprocess.hip): Pillow resample passes, resize + normalise
     PROF_NUM
 };
 

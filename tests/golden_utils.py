@@ -28,3 +28,34 @@ def sample_indices(numel: int, n: int = 4096) -> torch.Tensor:
     if numel <= n:
         return torch.arange(numel)
     return torch.linspace(0, numel - 1, n, dtype=torch.float64).round().long()
+
+
+# ---- clip preparation: seeded synthetic "decoded video" frames and the fixture cases ----------
+PREPROCESS_CASES = {
+    # up-scale 120x160 -> 224x224 and back (the blur is nearly the identity), mirror-pad 20 -> 39 frames, crop to 32
+    "small_up": dict(seed=11, T=20, H=120, W=160, crop_size=(32, 224, 224), resize_size=(224, 224), max_frames=192,
+                     stride=1, spacing=0.04),
+    # down-scale 270x480 (support 1.2 / 2.1 taps), stride 2, crop_size None -> ceil(max(T,16)/8)*8 frames
+    "down_stride": dict(seed=12, T=21, H=270, W=480, crop_size=None, resize_size=(224, 224), max_frames=192, stride=2,
+                        spacing=0.1),
+    # max_frames cuts the video (the reference keeps max_frames - 1 frames), odd sizes, non-square resize + centre crop
+    "cut_nonsquare": dict(seed=13, T=12, H=135, W=241, crop_size=(16, 224, 224), resize_size=(298, 224), max_frames=10,
+                          stride=1, spacing=0.25),
+    # a single frame is repeated (l4p_dataset_mini.py:553-554)
+    "single_frame": dict(seed=14, T=1, H=64, W=96, crop_size=(16, 224, 224), resize_size=(224, 224), max_frames=192,
+                         stride=1, spacing=0.5),
+}
+
+
+def synthetic_video(seed: int, T: int, H: int, W: int):
+    """uint8 frames [T,H,W,3]: smooth moving gradients + blocks + noise, so every filter tap matters."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    t = np.arange(T)[:, None, None, None]
+    y = np.arange(H)[None, :, None, None]
+    x = np.arange(W)[None, None, :, None]
+    c = np.arange(3)[None, None, None, :]
+    v = 127 + 90 * np.sin(0.07 * x + 0.3 * t + c) * np.cos(0.05 * y - 0.2 * t) + 40 * (((x // 8 + y // 8 + t) % 2) - 0.5)
+    v = v + rng.normal(0, 12, size=(T, H, W, 3))
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
