@@ -341,11 +341,19 @@ int l4p_pil_resample_u8(l4p_stream stream, const unsigned char* src, unsigned ch
  * (device int[T_out]) carries stride, temporal mirror-padding and the temporal crop.  mean3 / std3: HOST float[3],
  * read at call time.  frames: uint8 [n][in_h][in_w][3]; OR, when vbounds != NULL, [n][src_h][in_w][3] = the frames
  * before a final vertical Pillow pass src_h -> in_h (tables vbounds / vcoeffs / vksize on the device), which is then
- * evaluated on the fly for the <= 4 pixels an output pixel needs instead of being written out. */
+ * evaluated on the fly for the <= 4 pixels an output pixel needs instead of being written out.
+ * Compact rows (x_lambda != NULL): an output column j only reads source columns i0[j], i1[j] (l4p_resize_index_table),
+ * so the caller may produce just those — frames is then [n][src_h][2*out_w][3] with columns (i0[0], i1[0], i0[1], ...)
+ * and x_lambda the device copy of lambda1[out_w]; the previous horizontal pass shrinks accordingly. */
 int l4p_clip_resize_normalize(l4p_stream stream, const unsigned char* frames, const int* frame_index, float* rgb_out,
                               int T_out, int in_h, int in_w, int res_h, int res_w, int crop_i0, int crop_j0, int out_h,
                               int out_w, const float* mean3, const float* std3, int src_h, const int* vbounds,
-                              const int* vcoeffs, int vksize);
+                              const int* vcoeffs, int vksize, const float* x_lambda);
+
+/* HOST function: the source indices / weight of F.interpolate(align_corners=False) along one axis, exactly as the
+ * kernel evaluates them (float32, source coordinate = one fma): output j (0 <= j < out_size) of the crop starting at
+ * crop0 of the axis resized in_size -> res_size reads i0[j], i1[j] with weights 1 - lambda1[j], lambda1[j]. */
+int l4p_resize_index_table(int in_size, int res_size, int crop0, int out_size, int* i0, int* i1, float* lambda1);
 
 #ifdef __cplusplus
 }

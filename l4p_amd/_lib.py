@@ -106,7 +106,8 @@ SIGNATURES = {
     "l4p_mask_gather": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
     "l4p_pil_coeffs": (_I, [_I, _I, _VP, _VP, _I, C.POINTER(_I)]),
     "l4p_pil_resample_u8": (_I, [_VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _VP, _VP, _I]),
-    "l4p_clip_resize_normalize": (_I, [_VP, _VP, _VP, _VP] + [_I] * 9 + [_VP, _VP, _I, _VP, _VP, _I]),
+    "l4p_clip_resize_normalize": (_I, [_VP, _VP, _VP, _VP] + [_I] * 9 + [_VP, _VP, _I, _VP, _VP, _I, _VP]),
+    "l4p_resize_index_table": (_I, [_I, _I, _I, _I, _VP, _VP, _VP]),
     "l4p_track_readout": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     "l4p_track_prepare": (_I, [_VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _I]),
     "l4p_track_commit": (_I, [_VP] * 9 + [_I] * 5 + [_VP] * 5 + [_I, _I]),

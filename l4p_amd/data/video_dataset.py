@@ -50,20 +50,52 @@ def _pil_tables(in_size: int, out_size: int, device: torch.device) -> Tuple[torc
     return out
 
 
-def _resample(x: torch.Tensor, axis: int, out_size: int) -> torch.Tensor:
-    """One Pillow pass over uint8 images [n,h,w,c]; axis 1 = width, 0 = height."""
+def _resample(x: torch.Tensor, axis: int, out_size: int, cols: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One Pillow pass over uint8 images [n,h,w,c]; axis 1 = width, 0 = height.  ``cols`` (device int64 indices): produce
+    only these output positions of the axis, in this order (the pass is a table-driven gather: rows of the tables)."""
     n, h, w, c = x.shape
     bounds, kk, ks = _pil_tables(w if axis == 1 else h, out_size, x.device)
+    if cols is not None:  # gathered rows of the tables, cached with the column list (an attribute set by _x_columns)
+        key = (w if axis == 1 else h, out_size, str(x.device), getattr(cols, "_l4p_key", None))
+        hit = _tables.get(key) if key[3] is not None else None
+        if hit is None:
+            hit = (bounds[cols].contiguous(), kk[cols].contiguous(), ks)
+            if key[3] is not None:
+                _tables[key] = hit
+        bounds, kk, out_size = hit[0], hit[1], int(cols.numel())
     out = torch.empty((n, h, out_size, c) if axis == 1 else (n, out_size, w, c), dtype=torch.uint8, device=x.device)
     _lib.check(_lib.load().l4p_pil_resample_u8(_stream(), _p(x), _p(out), n, h, w, c, axis, out_size, _p(bounds), _p(kk), ks),
                "l4p_pil_resample_u8")
     return out
 
 
-def pil_resize_blur_resize(frames: torch.Tensor, pil_size: Tuple[int, int], keep_last_pass: bool = True):
+_xcols: Dict[Tuple[int, int, int, int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _x_columns(W: int, res_w: int, j0: int, Wn: int, device: torch.device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The two source columns (interleaved, int64 [2*Wn]) and the lerp weight (float [Wn]) of every output column of the
+    resize W -> res_w cropped at j0, from the library's own index rule (l4p_resize_index_table); cached."""
+    key = (W, res_w, j0, Wn, str(device))
+    hit = _xcols.get(key)
+    if hit is None:
+        xi0, xi1 = np.empty(Wn, dtype=np.int32), np.empty(Wn, dtype=np.int32)
+        xlam = np.empty(Wn, dtype=np.float32)
+        _lib.check(_lib.load().l4p_resize_index_table(W, res_w, j0, Wn, xi0.ctypes.data, xi1.ctypes.data, xlam.ctypes.data),
+                   "l4p_resize_index_table")
+        cols = torch.from_numpy(np.stack([xi0, xi1], axis=1).reshape(-1).astype(np.int64)).to(device)
+        cols._l4p_key = key
+        hit = (cols, torch.from_numpy(xlam).to(device))
+        _xcols[key] = hit
+    return hit
+
+
+def pil_resize_blur_resize(frames: torch.Tensor, pil_size: Tuple[int, int], keep_last_pass: bool = True,
+                           x_cols: Optional[torch.Tensor] = None):
     """video_dataset.py:86-92 for uint8 frames [n,H,W,3] on the GPU: Image.resize(pil_size = (width, height), BILINEAR)
     and back to (W, H).  With ``keep_last_pass=False`` the final vertical pass is NOT run: returns (rows, tables) with
-    rows [n,ph,W,3] and the (bounds, coeffs, ksize) of the pending ph -> H pass, for the fused kernel."""
+    rows [n,ph,W,3] and the (bounds, coeffs, ksize) of the pending ph -> H pass, for the fused kernel; ``x_cols`` then
+    restricts the horizontal up-scaling pass to the listed columns of the full-width frame (rows [n,ph,len(x_cols),3])."""
+    assert x_cols is None or not keep_last_pass
     n, H, W, _ = frames.shape
     pw, ph = int(pil_size[0]), int(pil_size[1])
     x = frames
@@ -72,7 +104,7 @@ def pil_resize_blur_resize(frames: torch.Tensor, pil_size: Tuple[int, int], keep
     if ph != H:
         x = _resample(x, 0, ph)
     if pw != W:
-        x = _resample(x, 1, W)
+        x = _resample(x, 1, W, cols=x_cols)
     if ph == H:
         return x if keep_last_pass else (x, None)
     if keep_last_pass:
@@ -152,14 +184,19 @@ def prepare_clip(frames: torch.Tensor, crop_size: Optional[Tuple[int, int, int]]
     remap = {f: k for k, f in enumerate(used)}
     if len(used) < T0:
         frames = frames[torch.tensor(used, device=dev)]
-    rows, vt = pil_resize_blur_resize(frames, pil_size, keep_last_pass=False)
+    # an output column only reads two columns of the blurred frame: the horizontal up-scaling pass produces just those
+    xl = None
+    x_cols = None
+    if int(pil_size[0]) != W and not (factor[0] == 1.0 and factor[1] == 1.0):
+        x_cols, xl = _x_columns(W, res_w, j0, Wn, dev)
+    rows, vt = pil_resize_blur_resize(frames, pil_size, keep_last_pass=False, x_cols=x_cols)
     fidx = torch.tensor([remap[f] for f in idx], dtype=torch.int32, device=dev)
     rgb = torch.empty((3, Tn, Hn, Wn), dtype=torch.float32, device=dev)
     mean = (C.c_float * 3)(*_MEAN)
     std = (C.c_float * 3)(*_STD)
     vb, vk, vks = (vt if vt is not None else (None, None, 0))
     _lib.check(_lib.load().l4p_clip_resize_normalize(_stream(), _p(rows), _p(fidx), _p(rgb), Tn, H, W, res_h, res_w, i0, j0, Hn,
-                                                     Wn, mean, std, rows.shape[1], _p(vb), _p(vk), vks),
+                                                     Wn, mean, std, rows.shape[1], _p(vb), _p(vk), vks, _p(xl)),
                "l4p_clip_resize_normalize")
 
     # -- queries and the dummy ground truth of sample_tracks (:438-495) --

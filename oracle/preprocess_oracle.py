@@ -101,24 +101,26 @@ def resize_blur_resize(frame_hwc: np.ndarray, resize_size: Tuple[int, int]) -> n
     return pil_resize_u8(small, w, h)
 
 
+def interp_axis(n_in: int, n_out: int):
+    """ATen area_pixel_compute_source_index (align_corners=False) + guard_index_and_lambda for one axis, float32:
+    returns i0, i1, w0, w1 per output position."""
+    scale = np.float32(n_in) / np.float32(n_out)
+    # ATen's CPU kernel evaluates scale * (dst + 0.5) - 0.5 as ONE fused multiply-add (measured: with two roundings
+    # the weights are off by an ulp of the source coordinate, 8e-6 at 128); emulated through the exact f64 product
+    src = (np.float64(scale) * (np.arange(n_out, dtype=np.float64) + 0.5) - 0.5).astype(np.float32)
+    src = np.maximum(src, np.float32(0.0)).astype(np.float32)
+    i0 = np.minimum(src.astype(np.int64), n_in - 1)
+    i1 = np.minimum(i0 + 1, n_in - 1)
+    l1 = (src - i0.astype(np.float32)).astype(np.float32)
+    return i0, i1, (np.float32(1.0) - l1).astype(np.float32), l1
+
+
 def interp_bilinear(x_cthw: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
     """F.interpolate(x[None], (T, out_h, out_w), mode="trilinear") with T unchanged (l4p_dataset_mini.py:255):
     src = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out in float32, neighbour index clamped at in - 1."""
     C, T, H, W = x_cthw.shape
-
-    def axis(n_in: int, n_out: int):
-        scale = np.float32(n_in) / np.float32(n_out)
-        # ATen's CPU kernel evaluates scale * (dst + 0.5) - 0.5 as ONE fused multiply-add (measured: with two roundings
-        # the weights are off by an ulp of the source coordinate, 8e-6 at 128); emulated through the exact f64 product
-        src = (np.float64(scale) * (np.arange(n_out, dtype=np.float64) + 0.5) - 0.5).astype(np.float32)
-        src = np.maximum(src, np.float32(0.0)).astype(np.float32)
-        i0 = np.minimum(src.astype(np.int64), n_in - 1)
-        i1 = np.minimum(i0 + 1, n_in - 1)
-        l1 = (src - i0.astype(np.float32)).astype(np.float32)
-        return i0, i1, (np.float32(1.0) - l1).astype(np.float32), l1
-
-    y0, y1, wy0, wy1 = axis(H, out_h)
-    x0, x1, wx0, wx1 = axis(W, out_w)
+    y0, y1, wy0, wy1 = interp_axis(H, out_h)
+    x0, x1, wx0, wx1 = interp_axis(W, out_w)
     x = x_cthw.astype(np.float32)
     top = x[:, :, y0][:, :, :, x0] * wx0 + x[:, :, y0][:, :, :, x1] * wx1
     bot = x[:, :, y1][:, :, :, x0] * wx0 + x[:, :, y1][:, :, :, x1] * wx1

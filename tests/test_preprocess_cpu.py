@@ -70,6 +70,21 @@ def test_abi_pil_coeffs_equal_oracle_tables():
     assert lib.l4p_pil_coeffs(0, 5, None, None, 0, C.byref(ks)) != 0
 
 
+def test_abi_resize_index_table_equals_oracle():
+    from l4p_amd import _lib
+
+    lib = _lib.load()
+    for n_in, res, crop0, n_out in [(854, 224, 0, 224), (480, 224, 0, 224), (120, 224, 0, 224), (241, 224, 0, 224),
+                                    (135, 298, 37, 224), (224, 224, 0, 224), (1920, 224, 0, 224), (5, 7, 2, 3)]:
+        i0, i1 = np.empty(n_out, dtype=np.int32), np.empty(n_out, dtype=np.int32)
+        lam = np.empty(n_out, dtype=np.float32)
+        assert lib.l4p_resize_index_table(n_in, res, crop0, n_out, i0.ctypes.data, i1.ctypes.data, lam.ctypes.data) == 0
+        o0, o1, _, ol = po.interp_axis(n_in, res)
+        sl = slice(crop0, crop0 + n_out)
+        assert np.array_equal(i0, o0[sl]) and np.array_equal(i1, o1[sl]) and np.array_equal(lam, ol[sl]), (n_in, res)
+    assert lib.l4p_resize_index_table(10, 8, 4, 8, i0.ctypes.data, i1.ctypes.data, lam.ctypes.data) != 0  # crop outside the axis
+
+
 def test_product_path_does_not_import_the_oracle():
     src = open(os.path.join(ROOT, "l4p_amd", "data", "video_dataset.py")).read()
     assert "oracle" not in src.replace("never imports oracle/", "")

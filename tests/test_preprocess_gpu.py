@@ -1,5 +1,7 @@
 """Clip preparation on the GPU (csrc/preprocess.hip through the C ABI) against the oracle and the reference fixtures:
-uint8 blur passes bit-exact, float tensor within 2e-6 abs (values are O(1): ~1e-6 relative), control values exact."""
+uint8 blur passes bit-exact with Pillow; the float tensor BIT-EQUAL to the oracle's un-contracted float32 restatement and
+within 2e-6 abs of the reference's own output (ATen fuses some multiply-adds: 1-ulp lerp differences, amplified by 1/std;
+values are O(1)); control values (intrinsics, queries, labels, lengths) exact."""
 import hashlib
 import os
 
@@ -31,7 +33,7 @@ def test_video_dataset_matches_oracle_and_reference_fixture(dev, name):
                            stride=c["stride"], spacing=c["spacing"])
     rgb = s["rgb_b3thw"].cpu().numpy()
     assert rgb.shape == o["rgb_b3thw"].shape and rgb.dtype == np.float32
-    assert np.abs(rgb - o["rgb_b3thw"]).max() <= TOL                                        # full tensor vs the oracle
+    assert np.array_equal(rgb, o["rgb_b3thw"])                                              # full tensor, bit-equal to the oracle
     assert np.abs(rgb.reshape(-1)[GOLD[name + ".rgb_idx"]] - GOLD[name + ".rgb_val"]).max() <= TOL  # vs the reference itself
     assert np.array_equal(s["intrinsics_b44t"].cpu().numpy(), GOLD[name + ".intrinsics_b44t"])
     assert np.array_equal(s["track_2d_pointquerries_bn3"].cpu().numpy(), GOLD[name + ".queries"])
@@ -66,7 +68,7 @@ def test_fused_last_pass_equals_materialised_blur(dev):
     mean, std = (C.c_float * 3)(*vd._MEAN), (C.c_float * 3)(*vd._STD)
     _lib.check(_lib.load().l4p_clip_resize_normalize(torch.cuda.current_stream().cuda_stream, blurred.data_ptr(), idx.data_ptr(),
                                                      rgb.data_ptr(), 8, 270, 480, 224, 224, 0, 0, 224, 224, mean, std, 270, None,
-                                                     None, 0))
+                                                     None, 0, None))
     torch.cuda.synchronize()
     assert torch.equal(rgb, s["rgb_b3thw"])
 
@@ -89,7 +91,7 @@ def test_full_size_video_properties_and_oracle_frames(dev):
     assert np.abs(rgb[:, 7].cpu().numpy() - const[:, None, None]).max() <= TOL
     sub = frames[[0, 49]]
     o = po.preprocess_clip(sub, crop_size=(2, 224, 224), resize_size=(224, 224), spacing=0.5)
-    assert np.abs(rgb[:, [0, 49]].cpu().numpy() - o["rgb_b3thw"]).max() <= TOL
+    assert np.array_equal(rgb[:, [0, 49]].cpu().numpy(), o["rgb_b3thw"])
     assert s["track_2d_pointquerries_bn3"].shape == (625, 3)
 
 

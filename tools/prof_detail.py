@@ -1,5 +1,5 @@
 """Per-shape kernel time table for one bench workload (event profiler, l4p_prof_detail).
-usage: python tools/prof_detail.py [c2|c3] [steps]"""
+usage: python tools/prof_detail.py [c2|c3|prep] [steps]"""
 import ctypes as C
 import os
 import sys
@@ -18,14 +18,23 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    tasks = ["depth"] if wl == "c2" else list(bench.ALL_TASKS)
-    B = 1 if wl == "c2" else 4
-    model, data, _ = bench.build_workload(tasks, B, 64, dev)
     lib = _lib.load()
+    if wl == "prep":  # the clip-preparation workload of bench.py --workload prep
+        from l4p_amd.data import prepare_clip
+        from tests.golden_utils import synthetic_video
 
-    def run():
-        with torch.no_grad():
-            return model.forward(data, tasks)
+        frames = torch.from_numpy(synthetic_video(100, 50, 480, 854)).to(dev)
+
+        def run():
+            return prepare_clip(frames, (64, 224, 224), (224, 224), spacing=0.04)
+    else:
+        tasks = ["depth"] if wl == "c2" else list(bench.ALL_TASKS)
+        B = 1 if wl == "c2" else 4
+        model, data, _ = bench.build_workload(tasks, B, 64, dev)
+
+        def run():
+            with torch.no_grad():
+                return model.forward(data, tasks)
 
     for _ in range(2):
         run()
