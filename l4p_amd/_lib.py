@@ -138,6 +138,11 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C l4p_amd/csrc`. There is no CPU/eager fallback."
         )
+    # PyTorch-ROCm bundles its own libamdhip64 and must be the FIRST to load one: the library then binds to that runtime
+    # by soname.  Loaded the other way round (our /opt/rocm copy first, torch's afterwards) the process holds two HIP
+    # runtimes and hipSetDevice in ours reports "no ROCm-capable device" (measured: build() followed by smoke()).
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

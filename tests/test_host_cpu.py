@@ -130,3 +130,15 @@ def test_bench_algorithmic_flops_match_survey():
     # the engine applies the fusion blocks' 1x1x1 out_conv before the up-sampling: 1.2 % fewer FLOPs than the
     # reference graph, and bench.py counts what is executed
     assert 0.985 * 2_838_780_444_672 <= head <= 2_838_780_444_672, head
+
+
+def test_library_load_brings_torch_runtime_first():
+    """build() followed by smoke() in ONE process: the HIP library must not be loaded before torch (two HIP runtimes in a
+    process -> hipSetDevice fails on the GPU box).  _lib.load() imports torch itself; checked in a fresh interpreter."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); from l4p_amd import _lib; assert 'torch' not in sys.modules; _lib.load(); "
+            "assert 'torch' in sys.modules; print('ok')") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
