@@ -109,3 +109,29 @@ def test_clip_streams_equal_serial(dev, mini, monkeypatch):
     for key in ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]:
         assert a[key].shape[0] == 2 and torch.equal(a[key], b[key]), key
     assert not torch.equal(a["track_2d_traj_est_bn2t"][0], a["track_2d_traj_est_bn2t"][1])  # the two clips differ
+
+
+def test_query_chunks_of_max_queries_match_one_pass(dev, mini):
+    """forward_windowed splits the queries into chunks of max_queries (sparse_heads.py:162-211): ragged last chunk
+    (10 = 4 + 4 + 2), N == max_queries (one full chunk through the loop) and queries at mixed start frames.  Tracks are
+    independent, so chunking only changes GEMM row counts: equal to the one-pass result to float rounding."""
+    cfg, sd = mini
+    model = build(cfg, sd, "32-true")
+    head = model.l4p_model.task_heads["track_2d"]
+    batch = make_batch(32, 10)
+    batch["track_2d_pointquerries_bn3"][0, 3:7, 0] = torch.tensor([8.5, 12.5, 17.5, 24.5])  # queries that start later
+    keys = ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]
+
+    def run(mq):
+        head.max_queries = mq
+        with torch.no_grad():
+            out = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+        torch.cuda.synchronize()
+        return {k: out[k].float().cpu() for k in keys}
+
+    whole = run(192)
+    for mq in (4, 10, 1):
+        part = run(mq)
+        for k in keys:
+            assert part[k].shape == whole[k].shape
+            assert (part[k] - whole[k]).abs().max() <= 1e-4 * whole[k].abs().max(), (mq, k, float((part[k] - whole[k]).abs().max()))
