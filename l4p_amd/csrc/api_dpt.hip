@@ -30,10 +30,18 @@ struct Vol {  // channels-last activation [B][t][h][w][c] of engine dtype
 };
 
 int splitk_for(long long M, int N, int K, int es) {  // keep in sync with l4p_amd/ops.py:splitk_for
-    const long long tiles = ((M + 127) / 128) * ((N + 63) / 64);
     const int nk = (K + 128 / es - 1) / (128 / es);
-    if (tiles >= 512 || nk < 32) return 1;  // aim at ~1024 workgroups (4 per CU): one 4-wave workgroup per CU is latency-bound
-    long long s = 1024 / tiles;
+    if (nk < 32) return 1;
+    long long s;
+    if (N >= 256) {  // 128x128 tiles, two workgroups per CU: aim at 512 workgroups (gemm_launch.inc picks the tile)
+        const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        if (tiles >= 400) return 1;
+        s = 512 / tiles;
+    } else {  // 128x64 tiles: ~1024 workgroups (4 per CU): one 4-wave workgroup per CU is latency-bound
+        const long long tiles = ((M + 127) / 128) * ((N + 63) / 64);
+        if (tiles >= 512) return 1;
+        s = 1024 / tiles;
+    }
     if (s > 16) s = 16;
     if (s > nk / 8) s = nk / 8;
     return s < 1 ? 1 : (int)s;

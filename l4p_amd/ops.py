@@ -98,13 +98,23 @@ def gemm(a: torch.Tensor, w: torch.Tensor, n: int, *, bias: Optional[torch.Tenso
 
 
 def splitk_for(M: int, N: int, K: int, es: int) -> int:
-    """Split-K factor for problems whose output has too few 128x64 tiles to occupy 256 CUs while K is long
-    (the low-resolution DPT convs: M = 256..2048 voxels, K = 27*256..27*1024)."""
-    tiles = ((M + 127) // 128) * ((N + 63) // 64)
+    """Split-K factor for problems whose output has too few tiles to occupy 256 CUs while K is long (the low-resolution
+    DPT convs: M = 256..16384 voxels, K = 27*256..27*1024).  Mirrors csrc/api_dpt.hip:splitk_for: N >= 256 runs on 128x128
+    tiles (512 workgroups aimed at), narrower outputs on 128x64 tiles (1024 workgroups)."""
     nk = (K + 128 // es - 1) // (128 // es)
-    if tiles >= 512 or nk < 32:  # aim at ~1024 workgroups (4 per CU): one 4-wave workgroup per CU is latency-bound
+    if nk < 32:
         return 1
-    return max(1, min(16, 1024 // tiles, nk // 8))
+    if N >= 256:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        if tiles >= 400:
+            return 1
+        s = 512 // tiles
+    else:
+        tiles = ((M + 127) // 128) * ((N + 63) // 64)
+        if tiles >= 512:
+            return 1
+        s = 1024 // tiles
+    return max(1, min(16, s, nk // 8))
 
 
 def kv_block(dtype: torch.dtype) -> int:
