@@ -1,5 +1,7 @@
 // HBM-bound pieces of the DPT decoders: channels-last trilinear resize and the final 1x1x1
 // projection (+exp) that also converts channels-last T back to the reference's NCDHW float layout.
+#include <cstdlib>
+
 #include "common.hpp"
 
 // -------------------------------------------------------------------------------------------------
@@ -28,7 +30,7 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, bool align, 
 // One workgroup row = one output (b, to, ho) line (blockIdx.y): its t / h source indices and weights are wave-uniform
 // scalars, and a thread only splits its x index into (wo, channel group) - the flat-index form spent five integer
 // divisions per 16 output bytes.
-template <typename T>
+template <typename T, bool NT = false>
 __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Ti, int Hi, int Wi,
                                                        int To, int Ho, int Wo, int C, int align) {
     constexpr int V = 8;  // channels per thread
@@ -77,7 +79,10 @@ __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ x, 
             bf16x8 o;
 #pragma unroll
             for (int k = 0; k < V; ++k) o[k] = (bf16_t)acc[k];
-            *(bf16x8*)yp = o;
+            if (NT)
+                __builtin_nontemporal_store(o, (bf16x8*)yp);
+            else
+                *(bf16x8*)yp = o;
         } else {
             *(f32x4*)yp = (f32x4){acc[0], acc[1], acc[2], acc[3]};
             *(f32x4*)((float*)yp + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
@@ -92,9 +97,18 @@ int launch_upsample(int dtype, const void* x, void* y, int B, int Ti, int Hi, in
         return L4P_E_INVALID;
     }
     const int lines = B * To * Ho, per_line = Wo * (C / 8);
-    const dim3 grid((per_line + 255) / 256 < 64 ? (per_line + 255) / 256 : 64, lines < 65535 ? lines : 65535, (lines + 65534) / 65535);
+    // two items per thread (fewer, longer workgroups: 2.55 -> 2.18 ms per c3 step) and non-temporal stores (the output,
+    // up to 822 MB, is streamed to the next conv and never fits a cache: -> 2.02 ms); L4P_UPS_IPT / L4P_UPS_NT: tuning aids
+    static const int ipt = getenv("L4P_UPS_IPT") ? atoi(getenv("L4P_UPS_IPT")) : 2;
+    int gx = (per_line + 256 * ipt - 1) / (256 * ipt);
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    const dim3 grid(gx, lines < 65535 ? lines : 65535, (lines + 65534) / 65535);
     ProfScope prof(PROF_ELEMENTWISE, stream, "upsample");
-    if (dtype == L4P_BF16)
+    static const int nt = getenv("L4P_UPS_NT") ? atoi(getenv("L4P_UPS_NT")) : 1;
+    if (dtype == L4P_BF16 && nt)
+        hipLaunchKernelGGL((upsample_kernel<bf16_t, true>), grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, B, Ti,
+                           Hi, Wi, To, Ho, Wo, C, align);
+    else if (dtype == L4P_BF16)
         hipLaunchKernelGGL(upsample_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, B, Ti,
                            Hi, Wi, To, Ho, Wo, C, align);
     else
