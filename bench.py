@@ -16,6 +16,7 @@ GPUs); c2 = depth head only, bf16, batch 1 (configs[1]).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import ctypes as C
 import json
 import os
@@ -261,7 +262,9 @@ def main():
         model.l4p_model.always_use_windowed_version = True
 
     def step():
-        with torch.no_grad():
+        # the model mirrors the reference's stdout messages ("Joint alignment is not possible ..." for a depth-only task
+        # list, l4p_videomae.py:322); stdout of this script carries the ONE JSON line only
+        with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
             if c5:
                 from l4p_amd.parallel import forward_windows_sharded
                 return forward_windows_sharded(model.l4p_model, batch, tasks, rank, world, group=4)
@@ -363,7 +366,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         bc = {k: (v[:1].cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
         cpu_tasks = [t for t in tasks if t != "track_2d"]  # dense heads only: the tracker port is timed in tests, not here
-        res["cpu_baseline"] = cpu_baseline(sd, cfg, cpu_tasks, bc)
+        with contextlib.redirect_stdout(sys.stderr):
+            res["cpu_baseline"] = cpu_baseline(sd, cfg, cpu_tasks, bc)
     print(json.dumps(res))
 
 
