@@ -161,10 +161,12 @@ class L4P_VideoMAE(torch.nn.Module):
         rgb = data["rgb_b3thw"]
         B, _, T, H, W = rgb.shape
         assert H == self.window_size[1] and W == self.window_size[2], "Supports only fixed spatial size"
+        single = (not self.always_use_windowed_version) and (T == self.window_size[0])
+        # (argument checks come before any device work, in the reference's order: l4p_videomae.py:260,267-269)
+        assert single or T % self.window_stride_T == 0, "Temporal window needs to be a multiple of window stride, for now!"
         data = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in data.items()}
-        if (not self.always_use_windowed_version) and (T == self.window_size[0]):
+        if single:
             return self.forward_single_window(data, tasks)
-        assert T % self.window_stride_T == 0, "Temporal window needs to be a multiple of window stride, for now!"
         time_strides = self.time_strides(T)
         tf, tT = self._taps(tasks)
         ws = self.window_size[0]

@@ -102,6 +102,11 @@ def test_config_surface_and_loud_failure_without_gpu():
     assert net.task_heads["depth"].hooks_idx == [14, 21, 28, 36]
     with pytest.raises(RuntimeError):  # strict key check happens before any device work
         m.load_state_dict({"l4p_model.video_encoder.norm.weight": torch.zeros(1408)})
+    # argument errors of L4P_VideoMAE.forward (l4p_videomae.py:260,267-269): same assertions, same messages
+    with pytest.raises(AssertionError, match="fixed spatial size"):
+        net.forward({"rgb_b3thw": torch.zeros(1, 3, 16, 200, 224)}, ["depth"])
+    with pytest.raises(AssertionError, match="multiple of window stride"):
+        net.forward({"rgb_b3thw": torch.zeros(1, 3, 20, 224, 224)}, ["depth"])
     if not torch.cuda.is_available():
         with pytest.raises((RuntimeError, _lib.L4PHipError)):
             net.forward({"rgb_b3thw": torch.zeros(1, 3, 16, 224, 224)}, ["depth"])
