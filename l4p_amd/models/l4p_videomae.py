@@ -89,6 +89,11 @@ class L4P_VideoMAE(torch.nn.Module):
         self.window_stride_T = window_stride_T
         self.always_use_windowed_version = always_use_windowed_version
         self.joint_alignment = joint_alignment
+        # Engine option (not a reference argument): windows of a long clip that go through the encoder and the dense
+        # decoders TOGETHER as one batch.  1 = one window at a time, the reference's order and bit-identical to it;
+        # > 1 trades bit-identity (row counts change GEMM tile / split-K choices: differences at float rounding level,
+        # tests/test_sharded_windows_gpu.py) for batch-4 efficiency on long videos (demo/demo.py sets 4).
+        self.window_batch = 1
         self.engine_dtype = _engine_dtype(precision)
         self.engine: Optional[Engine] = None
         self.weights: Optional[PackedWeights] = None
@@ -167,6 +172,10 @@ class L4P_VideoMAE(torch.nn.Module):
         data = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in data.items()}
         if single:
             return self.forward_single_window(data, tasks)
+        if self.window_batch > 1:
+            from ..parallel import forward_windows_sharded  # the same code path the multi-GPU split uses, on one rank
+
+            return forward_windows_sharded(self, data, tasks, 0, 1, group=int(self.window_batch))
         time_strides = self.time_strides(T)
         tf, tT = self._taps(tasks)
         ws = self.window_size[0]

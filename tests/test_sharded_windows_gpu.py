@@ -52,7 +52,11 @@ def test_grouped_windows_match_to_rounding(dev):
         ref = model.forward({k: v.clone() for k, v in batch.items()}, TASKS)
         grp = parallel.forward_windows_sharded(model.l4p_model, {k: v.clone() for k, v in batch.items()}, TASKS, rank=0, world=1,
                                                group=4)
+        model.l4p_model.window_batch = 4  # the same through the model's own forward (what demo/demo.py sets)
+        own = model.forward({k: v.clone() for k, v in batch.items()}, TASKS)
+        model.l4p_model.window_batch = 1
     torch.cuda.synchronize()
     for key, val in ref.items():
         if torch.is_tensor(val):
             assert (grp[key] - val).abs().max() <= 1e-4 * val.abs().max(), key
+            assert torch.equal(own[key], grp[key]), key

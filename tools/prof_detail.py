@@ -1,5 +1,5 @@
 """Per-shape kernel time table for one bench workload (event profiler, l4p_prof_detail).
-usage: python tools/prof_detail.py [c2|c3|prep] [steps]"""
+usage: python tools/prof_detail.py [c2|c3|prep|demo] [steps]   (demo: 64 frames, 625 queries, depth+flow+mask+tracks)"""
 import ctypes as C
 import os
 import sys
@@ -27,6 +27,26 @@ def main():
 
         def run():
             return prepare_clip(frames, (64, 224, 224), (224, 224), spacing=0.04)
+    elif wl == "demo":  # the generic-video case of demo/demo.py: one 64-frame clip, 625 grid queries in chunks of 128
+        import time
+
+        from l4p_amd.data import prepare_clip
+        from tests.golden_utils import synthetic_video
+
+        tasks = ["depth", "flow_2d_backward", "dyn_mask", "track_2d"]
+        model, _, _ = bench.build_workload(list(bench.ALL_TASKS), 1, 64, dev)
+        model.l4p_model.task_heads["track_2d"].max_queries = 128
+        clip = prepare_clip(torch.from_numpy(synthetic_video(1, 50, 480, 854)).to(dev), (64, 224, 224), (224, 224), spacing=0.04)
+        data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in clip.items()}
+
+        def run():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                out = model.forward(data, tasks)
+            torch.cuda.synchronize()
+            print(f"demo forward: {(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr)
+            return out
     else:
         tasks = ["depth"] if wl == "c2" else list(bench.ALL_TASKS)
         B = 1 if wl == "c2" else 4
