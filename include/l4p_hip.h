@@ -219,6 +219,12 @@ int l4p_similarity_apply(l4p_stream stream, const float* sim, float* pose, int T
 int l4p_layernorm_ex(l4p_stream stream, int dtype, const float* x, const float* gamma, const float* beta, float eps,
                      void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act);
 
+/* The same LayerNorm (+ optional GELU) for rows that are STORED in the engine dtype: x_T, out_T are T [M][C] and may be the
+ * same buffer.  Used for LayerNorm3d + GELU after the first up-scaling ConvTranspose (mask_decoder.py:60-62), whose 1M x 352
+ * activation per clip is then never held in float (the reference holds it in fp16 under autocast).  L4P_F32: T = float. */
+int l4p_layernorm_t(l4p_stream stream, int dtype, const void* x_T, const float* gamma, const float* beta, float eps,
+                    void* out_T, int M, int C, int act);
+
 /* PromptEncoder (prompt_encoder.py:78-121,196-203) + token concat (mask_decoder.py:107-113):
  * tokens float [N][6][C] = 3 mask tokens | point PE + label embedding | not-a-point | feature prompt. */
 int l4p_track_tokens(l4p_stream stream, const float* queries, const float* labels, const float* pfeat,

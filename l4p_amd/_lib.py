@@ -104,6 +104,7 @@ SIGNATURES = {
     "l4p_small_attn": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I]),
     "l4p_mask_product": (_I, [_VP, _I, _VP, _VP, _VP, _I, _LL, _I]),
     "l4p_mask_gather": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
+    "l4p_layernorm_t": (_I, [_VP, _I, _VP, _VP, _VP, C.c_float, _VP, _I, _I, _I]),
     "l4p_pil_coeffs": (_I, [_I, _I, _VP, _VP, _I, C.POINTER(_I)]),
     "l4p_pil_resample_u8": (_I, [_VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _VP, _VP, _I]),
     "l4p_clip_resize_normalize": (_I, [_VP, _VP, _VP, _VP] + [_I] * 9 + [_VP, _VP, _I, _VP, _VP, _I, _VP]),

@@ -4,6 +4,8 @@
 int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const float* beta, float eps, void* out_T,
                         float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act,
                         hipStream_t stream);
+int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T, int M, int C,
+                       int act, hipStream_t stream);
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
@@ -31,6 +33,10 @@ extern "C" {
 int l4p_layernorm_ex(l4p_stream s, int dtype, const float* x, const float* gamma, const float* beta, float eps,
                      void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act) {
     return launch_layernorm_ex(dtype, x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, (hipStream_t)s);
+}
+int l4p_layernorm_t(l4p_stream s, int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T,
+                    int M, int C, int act) {
+    return launch_layernorm_T(dtype, x_T, gamma, beta, eps, out_T, M, C, act, (hipStream_t)s);
 }
 int l4p_track_tokens(l4p_stream s, const float* queries, const float* labels, const float* pfeat, const float* plabel,
                      const float* gauss, const float* mask_tokens, const float* point_emb0, const float* point_emb1,

@@ -1,5 +1,7 @@
 // HBM-bound kernels of the encoder path: LayerNorm, tubelet im2col (patch embed gather), casts.
 // All are one-pass, 16-byte vectorised, one wave per row where a row reduction is needed.
+#include <cstdlib>
+
 #include "common.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -8,80 +10,105 @@
 // LayerNorm3d over channels, mask_decoder.py:145-157 == the same row LN in channels-last layout).
 // Two-pass in registers (mean, then centred variance) like ATen.  out_T and/or out_f32 may be given.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MAXV>
+// XT: the input row is stored as T (the bf16 engine's activations) instead of float - half the bytes in; it may alias
+// out_T (a wave holds its rows in registers before it stores anything).
+// ROWS: rows per wave (all requested before the first is reduced).  Measured on the 1M x 352 LayerNorm + GELU of the tracker:
+// 1 row 556 us, 2 rows 696 us, 4 rows 889 us - that launch is VALU-bound (GELU on 369 M elements), not latency-bound, and
+// more rows only add register pressure; every launcher uses ROWS = 1.
+template <typename T, int MAXV, bool XT = false, int ROWS = 1>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         T* __restrict__ out_T, float* __restrict__ out_f32, int M, int C,
                                                         const float* __restrict__ add, int add_mod, T* __restrict__ out_T2,
                                                         int act) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= M) return;
     const int nv = C >> 2;
-    const f32x4* xr = (const f32x4*)(x + (long long)row * C);
-    const f32x4* ar = out_T2 ? (const f32x4*)(add + (long long)(row % add_mod) * C) : nullptr;
-    // every load of the row is issued up front (x, gamma, beta, the optional addend): ONE exposed memory round trip per
-    // row instead of three dependent ones (x -> statistics -> gamma/beta/add) - the kernel is latency-, not bandwidth-bound
-    f32x4 v[MAXV], g[MAXV], bb[MAXV], av[MAXV];
+    // every load of the rows is issued up front (x, gamma, beta, the optional addend): ONE exposed memory round trip per
+    // wave instead of three dependent ones (x -> statistics -> gamma/beta/add) - the kernel is latency-, not bandwidth-bound
+    f32x4 v[ROWS][MAXV], g[MAXV], bb[MAXV], av[ROWS][MAXV];
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = row0 + r < M ? row0 + r : M - 1;  // (a clamped duplicate row is loaded but never stored)
+        const f32x4* xr = (const f32x4*)(x + (long long)row * C);
+        const f32x4* ar = out_T2 ? (const f32x4*)(add + (long long)(row % add_mod) * C) : nullptr;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + i * 64;
+            const bool in = idx < nv;
+            if (XT && sizeof(T) == 2) {  // (branch-free: the load is clamped, not predicated, so all slots are requested at once)
+                const bf16x4 t = ((const bf16x4*)((const bf16_t*)x + (long long)row * C))[in ? idx : 0];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[r][i][k] = in ? (float)t[k] : 0.f;
+            } else {
+                v[r][i] = in ? xr[idx] : z;
+            }
+            av[r][i] = (in && ar) ? ar[idx] : z;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + i * 64;
         const bool in = idx < nv;
-        v[i] = in ? xr[idx] : z;
         g[i] = in ? ((const f32x4*)gamma)[idx] : z;
         bb[i] = in ? ((const f32x4*)beta)[idx] : z;
-        av[i] = (in && ar) ? ar[idx] : z;
     }
-    float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = row0 + r;
+        if (row >= M) break;
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        if (lane + i * 64 < nv) {
+        for (int i = 0; i < MAXV; ++i) s += v[r][i][0] + v[r][i][1] + v[r][i][2] + v[r][i][3];
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float d = v[i][k] - mean;
-                q += d * d;
-            }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        for (int i = 0; i < MAXV; ++i) {
+            if (lane + i * 64 < nv) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + i * 64;
-        if (idx < nv) {
-            f32x4 y;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) y[k] = (v[i][k] - mean) * rstd * g[i][k] + bb[i][k];
-            if (act == L4P_ACT_GELU) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = gelu_for<T>(y[k]);
-            }
-            if (out_T2) {  // T(y + add[row % add_mod]): the "+ positional / + prompt token" operand of the tracker
-                if (sizeof(T) == 2) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (bf16_t)(y[k] + av[i][k]);
-                    ((bf16x4*)((bf16_t*)out_T2 + (long long)row * C))[idx] = o;
-                } else {
-                    f32x4 o;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = y[k] + av[i][k];
-                    ((f32x4*)((float*)out_T2 + (long long)row * C))[idx] = o;
+                for (int k = 0; k < 4; ++k) {
+                    const float d = v[r][i][k] - mean;
+                    q += d * d;
                 }
             }
-            if (out_f32) ((f32x4*)(out_f32 + (long long)row * C))[idx] = y;
-            if (out_T) {
-                if (sizeof(T) == 2) {
-                    bf16x4 o;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (bf16_t)y[k];
-                    ((bf16x4*)((bf16_t*)out_T + (long long)row * C))[idx] = o;
-                } else {
-                    ((f32x4*)((float*)out_T + (long long)row * C))[idx] = y;
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + i * 64;
+            if (idx < nv) {
+                f32x4 y;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = (v[r][i][k] - mean) * rstd * g[i][k] + bb[i][k];
+                if (act == L4P_ACT_GELU) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) y[k] = gelu_for<T>(y[k]);
+                }
+                if (out_T2) {  // T(y + add[row % add_mod]): the "+ positional / + prompt token" operand of the tracker
+                    if (sizeof(T) == 2) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = (bf16_t)(y[k] + av[r][i][k]);
+                        ((bf16x4*)((bf16_t*)out_T2 + (long long)row * C))[idx] = o;
+                    } else {
+                        f32x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = y[k] + av[r][i][k];
+                        ((f32x4*)((float*)out_T2 + (long long)row * C))[idx] = o;
+                    }
+                }
+                if (out_f32) ((f32x4*)(out_f32 + (long long)row * C))[idx] = y;
+                if (out_T) {
+                    if (sizeof(T) == 2) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = (bf16_t)y[k];
+                        ((bf16x4*)((bf16_t*)out_T + (long long)row * C))[idx] = o;
+                    } else {
+                        ((f32x4*)((float*)out_T + (long long)row * C))[idx] = y;
+                    }
                 }
             }
         }
@@ -118,6 +145,31 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
         launch_ln<bf16_t>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
     else
         launch_ln<float>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// LayerNorm of rows stored in the engine dtype (bf16 engine: bf16 in, bf16 out, possibly in place; f32 engine: the plain kernel)
+int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T, int M, int C,
+                       int act, hipStream_t stream) {
+    if (dtype != L4P_BF16)
+        return launch_layernorm_ex(dtype, (const float*)x_T, gamma, beta, eps, out_T, nullptr, M, C, nullptr, 0, nullptr, act, stream);
+    if (C % 4 || C > 2048) {
+        l4p_set_error("layernorm_T: C=%d must be a multiple of 4 and <= 2048", C);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d inT act%d", M, C, act);
+    const dim3 grid((M + 3) / 4);
+    const float* xf = (const float*)x_T;  // (re-typed inside the kernel)
+    if (C <= 512)
+        hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2, true>), grid, dim3(256), 0, stream, xf, gamma, beta, eps, (bf16_t*)out_T,
+                           (float*)nullptr, M, C, (const float*)nullptr, 0, (bf16_t*)nullptr, act);
+    else if (C <= 1536)
+        hipLaunchKernelGGL((layernorm_kernel<bf16_t, 6, true>), grid, dim3(256), 0, stream, xf, gamma, beta, eps, (bf16_t*)out_T,
+                           (float*)nullptr, M, C, (const float*)nullptr, 0, (bf16_t*)nullptr, act);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8, true>), grid, dim3(256), 0, stream, xf, gamma, beta, eps, (bf16_t*)out_T,
+                           (float*)nullptr, M, C, (const float*)nullptr, 0, (bf16_t*)nullptr, act);
     HIP_TRY(hipGetLastError());
     return 0;
 }
