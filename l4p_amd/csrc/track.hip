@@ -196,9 +196,26 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, 
     // scores
     for (int p = tid; p < P; p += 256) {
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int d0 = 0; d0 < hd; d0 += 4) {
+        const T* kr = kp + (long long)p * D;
+        // the key row is requested in batches of 4 loads before any is used (a thread reads its row alone: without the
+        // batching every 8-byte load was a separate exposed round trip)
+        int d0 = 0;
+        for (; d0 + 16 <= hd; d0 += 16) {
+            float kv[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Vec4<T>::load(kr + d0 + 4 * c, kv + 4 * c);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 q4 = *(const f32x4*)(qs + i * 96 + d0 + 4 * c);  // b128 LDS read (rows are 384 B apart)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i] += q4[e] * kv[4 * c + e];
+                }
+        }
+        for (; d0 < hd; d0 += 4) {
             float kv[4];
-            Vec4<T>::load(kp + (long long)p * D + d0, kv);
+            Vec4<T>::load(kr + d0, kv);
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -240,7 +257,21 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[i][e] = 0.f;
     if (kg < nkg) {
-        for (int p = kg; p < P; p += nkg) {
+        int p = kg;
+        for (; p + 3 * nkg < P; p += 4 * nkg) {  // four value rows in flight (same summation order as the plain loop)
+            float vv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Vec4<T>::load(vp + (long long)(p + u * nkg) * D + cg * 4, vv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float w = sc[i * P + p + u * nkg];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[i][e] += w * vv[u][e];
+                }
+        }
+        for (; p < P; p += nkg) {
             float vv[4];
             Vec4<T>::load(vp + (long long)p * D + cg * 4, vv);
 #pragma unroll
@@ -349,22 +380,26 @@ __global__ __launch_bounds__(256) void i2t_attn_lds_kernel(const T* __restrict__
     for (int c = 0; c < chunks; c += 256)
         if (c + tid < chunks)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + (long long)(c + tid) * 16), (lptr_t)((char*)tile + (c + wave * 64) * 16), 16, 0, 0);
-    for (int i = tid; i < 6 * D; i += 256) {
-        ks[i] = (float)k[(long long)n * 6 * D + i];
-        vs[i] = (float)v[(long long)n * 6 * D + i];
+    for (int i = tid * 4; i < 6 * D; i += 1024) {  // D % 4 == 0: 4 elements per load (was one 2-byte load per element)
+        Vec4<T>::load(k + (long long)n * 6 * D + i, ks + i);
+        Vec4<T>::load(v + (long long)n * 6 * D + i, vs + i);
     }
     __syncthreads();
     const int pl = tid / heads, h = tid % heads;
     if (pl < nrow) {
         T* qp = tile + (long long)pl * D + (long long)h * hd;
         float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* kh = ks + h * hd;  // (16-byte aligned: D % 4 == 0 and hd % 4 == 0, so the token rows are read as b128)
+        const float* vh = vs + h * hd;
         for (int d0 = 0; d0 < hd; d0 += 4) {
             float qv[4];
             Vec4<T>::load(qp + d0, qv);
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 6; ++i) {
+                const f32x4 k4 = *(const f32x4*)(kh + i * D + d0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s[i] += qv[e] * ks[i * D + h * hd + d0 + e];
+                for (int e = 0; e < 4; ++e) s[i] += qv[e] * k4[e];
+            }
         }
         float m = -INFINITY;
 #pragma unroll
@@ -380,14 +415,15 @@ __global__ __launch_bounds__(256) void i2t_attn_lds_kernel(const T* __restrict__
         }
         const float iz = 1.f / z;
         for (int d0 = 0; d0 < hd; d0 += 4) {
-            float o[4];
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float a = 0.f;
+            for (int i = 0; i < 6; ++i) {
+                const f32x4 v4 = *(const f32x4*)(vh + i * D + d0);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) a += s[i] * vs[i * D + h * hd + d0 + e];
-                o[e] = a * iz;
+                for (int e = 0; e < 4; ++e) o[e] += s[i] * v4[e];
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= iz;
             Vec4<T>::store(qp + d0, o);  // in place: this thread is the only reader of its segment
         }
     }
@@ -641,7 +677,7 @@ int launch_small_attn(int dtype, int kind, const void* q, const void* k, const v
                       int heads, hipStream_t stream) {
     const int hd = D / heads;
     const float scale = 1.0f / sqrtf((float)hd);
-    if (hd * heads != D || (kind != 0 && (hd % 4 || hd > 96))) {
+    if (hd * heads != D || (kind != 0 && (hd % 4 || hd > 96)) || ((kind == 1 || kind == 3) && P % 4)) {  // (P % 4: 16-byte LDS rows)
         l4p_set_error("small_attn: unsupported head geometry D=%d heads=%d", D, heads);
         return L4P_E_INVALID;
     }
