@@ -30,11 +30,77 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, bool align, 
 // One workgroup row = one output (b, to, ho) line (blockIdx.y): its t / h source indices and weights are wave-uniform
 // scalars, and a thread only splits its x index into (wo, channel group) - the flat-index form spent five integer
 // divisions per 16 output bytes.
+// An axis that is not resized (lambda == 0: the time axis of the (1,2,2) resizes, every second line of an align-corners x2)
+// has one tap, not two.  Which of the t / h taps exist is uniform over the line, so the tap set is chosen ONCE per workgroup
+// (NT x NH in {1,2}^2) and inside a specialisation all 2*NT*NH loads of an output are requested before the first is used
+// (the per-tap `if (weight == 0) continue` of the previous form kept every load behind a branch: one round trip each).
+template <typename T, bool NT_STORE, int NT, int NH>
+__device__ __forceinline__ void upsample_line(const T* __restrict__ xb, T* __restrict__ yl, int Hi, int Wi, int Wo, int C, int align,
+                                              int t0, int t1, float lt, int h0, int h1, float lh) {
+    constexpr int V = 8;  // channels per thread
+    const int cv = C / V;
+    const float wt[2] = {NT == 2 ? 1.f - lt : 1.f, lt}, wh[2] = {NH == 2 ? 1.f - lh : 1.f, lh};
+    const int ti[2] = {t0, t1}, hi[2] = {h0, h1};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Wo * cv; i += gridDim.x * 256) {
+        const int wo = i / cv, c = (i - wo * cv) * V;
+        int w0, w1;
+        float lw;
+        src_index(wo, Wi, Wo, align, w0, w1, lw);
+        const float ww[2] = {1.f - lw, lw};
+        const int wi[2] = {w0, w1};
+        float v[NT][NH][2][V];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int bb = 0; bb < NH; ++bb)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const T* p = xb + (((long long)ti[a] * Hi + hi[bb]) * Wi + wi[cc]) * C + c;
+                    if (sizeof(T) == 2) {
+                        const bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+                        for (int k = 0; k < V; ++k) v[a][bb][cc][k] = (float)t[k];
+                    } else {
+                        const f32x4 q0 = *(const f32x4*)p, q1 = *(const f32x4*)((const float*)p + 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[a][bb][cc][k] = q0[k];
+                            v[a][bb][cc][4 + k] = q1[k];
+                        }
+                    }
+                }
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int bb = 0; bb < NH; ++bb)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const float wgt = wt[a] * wh[bb] * ww[cc];  // same product, same tap order as the 8-tap form
+#pragma unroll
+                    for (int k = 0; k < V; ++k) acc[k] += wgt * v[a][bb][cc][k];
+                }
+        T* yp = yl + (long long)wo * C + c;
+        if (sizeof(T) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = (bf16_t)acc[k];
+            if (NT_STORE)
+                __builtin_nontemporal_store(o, (bf16x8*)yp);
+            else
+                *(bf16x8*)yp = o;
+        } else {
+            *(f32x4*)yp = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+            *(f32x4*)((float*)yp + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+        }
+    }
+}
+
 template <typename T, bool NT = false>
 __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Ti, int Hi, int Wi,
                                                        int To, int Ho, int Wo, int C, int align) {
-    constexpr int V = 8;  // channels per thread
-    const int cv = C / V;
     const int line = blockIdx.y + blockIdx.z * 65535;  // (b * To + to) * Ho + ho
     if (line >= B * To * Ho) return;
     const int ho = line % Ho, to = (line / Ho) % To, b = line / (Ho * To);
@@ -44,49 +110,17 @@ __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ x, 
     src_index(ho, Hi, Ho, align, h0, h1, lh);
     const T* xb = x + (long long)b * Ti * Hi * Wi * C;
     T* yl = y + (long long)line * Wo * C;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < Wo * cv; i += gridDim.x * 256) {
-        const int wo = i / cv, c = (i - wo * cv) * V;
-        int w0, w1;
-        float lw;
-        src_index(wo, Wi, Wo, align, w0, w1, lw);
-        float acc[V];
-#pragma unroll
-        for (int k = 0; k < V; ++k) acc[k] = 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    const float wgt = (a ? lt : 1.f - lt) * (bb ? lh : 1.f - lh) * (cc ? lw : 1.f - lw);
-                    if (wgt == 0.f) continue;  // an axis that is not resized (lambda == 0) has one tap, not two: skip the load
-                    const T* p = xb + (((long long)(a ? t1 : t0) * Hi + (bb ? h1 : h0)) * Wi + (cc ? w1 : w0)) * C + c;
-                    if (sizeof(T) == 2) {
-                        const bf16x8 v = *(const bf16x8*)p;
-#pragma unroll
-                        for (int k = 0; k < V; ++k) acc[k] += wgt * (float)v[k];
-                    } else {
-                        const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)((const float*)p + 4);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            acc[k] += wgt * v0[k];
-                            acc[4 + k] += wgt * v1[k];
-                        }
-                    }
-                }
-        T* yp = yl + (long long)wo * C + c;
-        if (sizeof(T) == 2) {
-            bf16x8 o;
-#pragma unroll
-            for (int k = 0; k < V; ++k) o[k] = (bf16_t)acc[k];
-            if (NT)
-                __builtin_nontemporal_store(o, (bf16x8*)yp);
-            else
-                *(bf16x8*)yp = o;
-        } else {
-            *(f32x4*)yp = (f32x4){acc[0], acc[1], acc[2], acc[3]};
-            *(f32x4*)((float*)yp + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
-        }
+    // (a zero weight removes the tap exactly as the skipped term did: 0 * finite contributes nothing to the sum)
+    if (lt == 0.f) {
+        if (lh == 0.f)
+            upsample_line<T, NT, 1, 1>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh);
+        else
+            upsample_line<T, NT, 1, 2>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh);
+    } else {
+        if (lh == 0.f)
+            upsample_line<T, NT, 2, 1>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh);
+        else
+            upsample_line<T, NT, 2, 2>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh);
     }
 }
 
