@@ -478,6 +478,9 @@ __device__ __forceinline__ void src_idx_nc(int dst, int in, int out, int& i0, in
     i1 = i0 + (i0 < in - 1 ? 1 : 0);
 }
 
+// A thread owns output columns x = tid, tid + 256, ... and walks down the rows: its x source indices / weight stay in
+// registers and the row's y indices / weight are wave-uniform, so a sample is 4 LDS reads + 3 lerps (the flat-index form
+// recomputed two source indices and an integer division per sample and was VALU-bound: 242 us per clip).
 __global__ __launch_bounds__(256) void track_readout_kernel(const float* __restrict__ masks, float* __restrict__ traj,
                                                             float* __restrict__ vis, float* __restrict__ depth, int T,
                                                             int h, int w, int H, int W) {
@@ -491,23 +494,26 @@ __global__ __launch_bounds__(256) void track_readout_kernel(const float* __restr
         lo[i] = masks[(((long long)n * 3 + m) * T + t) * hw + r];
     }
     __syncthreads();
-    auto sample = [&](int m, int y, int x) -> float {
-        int y0, y1, x0, x1;
-        float ly, lx;
-        src_idx_nc(y, h, H, y0, y1, ly);
-        src_idx_nc(x, w, W, x0, x1, lx);
-        const float* b = lo + m * hw;
-        const float top = (1.f - lx) * b[y0 * w + x0] + lx * b[y0 * w + x1];
-        const float bot = (1.f - lx) * b[y1 * w + x0] + lx * b[y1 * w + x1];
+    auto lerp2 = [&](const float* b, int r0, int r1, int x0, int x1, float lx, float ly) -> float {
+        const float top = (1.f - lx) * b[r0 + x0] + lx * b[r0 + x1];
+        const float bot = (1.f - lx) * b[r1 + x0] + lx * b[r1 + x1];
         return (1.f - ly) * top + ly * bot;
     };
     // pass 1: max of channel 0, sums of channels 1 and 2
     float mx = -INFINITY, s1 = 0.f, s2 = 0.f;
-    for (int i = tid; i < H * W; i += 256) {
-        const int y = i / W, x = i % W;
-        mx = fmaxf(mx, sample(0, y, x));
-        s1 += sample(1, y, x);
-        s2 += sample(2, y, x);
+    for (int x = tid; x < W; x += 256) {
+        int x0, x1;
+        float lx;
+        src_idx_nc(x, w, W, x0, x1, lx);
+        for (int y = 0; y < H; ++y) {
+            int y0, y1;
+            float ly;
+            src_idx_nc(y, h, H, y0, y1, ly);  // (uniform over the wave: scalar work)
+            const int r0 = y0 * w, r1 = y1 * w;
+            mx = fmaxf(mx, lerp2(lo, r0, r1, x0, x1, lx, ly));
+            s1 += lerp2(lo + hw, r0, r1, x0, x1, lx, ly);
+            s2 += lerp2(lo + 2 * hw, r0, r1, x0, x1, lx, ly);
+        }
     }
     mx = wave_max(mx);
     s1 = wave_sum(s1);
@@ -524,12 +530,20 @@ __global__ __launch_bounds__(256) void track_readout_kernel(const float* __restr
     __syncthreads();
     // pass 2: soft-argmax
     float z = 0.f, sx = 0.f, sy = 0.f;
-    for (int i = tid; i < H * W; i += 256) {
-        const int y = i / W, x = i % W;
-        const float e = expf(sample(0, y, x) - mx);
-        z += e;
-        sx += e * ((float)x + 0.5f);
-        sy += e * ((float)y + 0.5f);
+    for (int x = tid; x < W; x += 256) {
+        int x0, x1;
+        float lx;
+        src_idx_nc(x, w, W, x0, x1, lx);
+        const float xc = (float)x + 0.5f;
+        for (int y = 0; y < H; ++y) {
+            int y0, y1;
+            float ly;
+            src_idx_nc(y, h, H, y0, y1, ly);
+            const float e = expf(lerp2(lo, y0 * w, y1 * w, x0, x1, lx, ly) - mx);
+            z += e;
+            sx += e * xc;
+            sy += e * ((float)y + 0.5f);
+        }
     }
     z = wave_sum(z);
     sx = wave_sum(sx);
