@@ -239,6 +239,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="c5: length of the long video")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default: 1 for c2, 4 for c3)")
     ap.add_argument("--queries", type=int, default=64)
+    ap.add_argument("--group", type=int, default=4, help="c5: windows batched through encoder + dense decoders per launch group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     args = ap.parse_args()
@@ -267,7 +268,7 @@ def main():
         with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
             if c5:
                 from l4p_amd.parallel import forward_windows_sharded
-                return forward_windows_sharded(model.l4p_model, batch, tasks, rank, world, group=4)
+                return forward_windows_sharded(model.l4p_model, batch, tasks, rank, world, group=args.group)
             return model.forward(batch, tasks)
 
     for _ in range(args.warmup):
