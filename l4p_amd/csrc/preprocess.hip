@@ -8,11 +8,12 @@
 //       ImageNet normalisation (:575-580), layout [3][T][h][w] float.
 //
 // This is byte / integer work bound by HBM, not MFMA work:
-//  * `pil_resample_kernel` is one pass of Pillow's 8-bit resampler (libImaging/Resample.c: 22-bit fixed-point triangle
-//    filter whose support grows with the down-scale factor, uint8 between passes) — integer arithmetic, bit-exact.
-//    Horizontal pass: one thread per output byte (row, x, channel), so stores are fully coalesced and the taps of
-//    neighbouring threads overlap in L1/L2; vertical pass: 4 consecutive bytes of a row per thread (one dword
-//    load per tap, one dword store).
+//  * `pil_resample_{h_lds,h,v}_kernel` are one pass of Pillow's 8-bit resampler (libImaging/Resample.c: 22-bit fixed-point
+//    triangle filter whose support grows with the down-scale factor, uint8 between passes) — integer arithmetic, bit-exact.
+//    Horizontal pass: a workgroup stages <= 16 contiguous image rows in LDS with dword loads; a thread owns an output
+//    column (x, channel), holds that column's coefficients in registers and walks down the rows (the table-driven form
+//    also produces any SUBSET of output columns: the up-scaling pass only makes the two columns each final output column
+//    reads).  Vertical pass: 4 consecutive bytes of a row per thread (one dword load per tap, one dword store).
 //  * `clip_resize_normalize_kernel` produces the network input directly.  An output pixel only touches <= 4 source
 //    pixels, so the LAST blur pass (vertical up-scale back to the full frame height — the largest intermediate, as
 //    big as the video itself) is never written: the 4 neighbours are evaluated on the fly from the horizontally
