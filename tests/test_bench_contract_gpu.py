@@ -1,0 +1,49 @@
+"""bench.py's output contract on the GPU box: stdout is exactly ONE JSON line carrying the driver's keys, `roofline` and (at N=1)
+`cpu_baseline`; checked on a 1-step run of the default workload (c3) and of the clip-preparation workload."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"}
+
+
+def _run(args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900,
+                         cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must be one JSON line, got {len(lines)}: {out.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def _check_common(r, steps, warmup):
+    assert KEYS <= set(r), sorted(KEYS - set(r))
+    assert r["n_gpus"] == 1 and r["steps"] == steps and r["warmup"] == warmup and r["higher_is_better"] is True
+    assert r["value"] > 0 and r["ms_per_step"] > 0 and r["vs_baseline"] is None and "workload" in r["config"]
+    roof = r["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+
+
+def test_default_workload_line(dev):
+    r = _run(["--steps", "1", "--warmup", "1"])
+    _check_common(r, 1, 1)
+    assert r["unit"] == "frames/s" and r["dtype"] == "bf16" and r["scaling"] == "weak" and "all heads" in r["metric"]
+    assert r["roofline"]["bound"] == "mfma" and r["roofline"]["peak"] == 2500.0 and "roofline_attention" in r
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "frames/s" and cb["sample"]
+    # frames per step of configs[2]: 4 clips x 16 frames
+    assert abs(r["value"] - 64 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-2
+
+
+def test_prep_workload_line(dev):
+    r = _run(["--workload", "prep", "--steps", "3", "--warmup", "1"])
+    _check_common(r, 3, 1)
+    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["peak"] == 8000.0 and r["cpu_baseline"]["kind"] == "port"
