@@ -16,11 +16,11 @@
 // 1 row 556 us, 2 rows 696 us, 4 rows 889 us - that launch is VALU-bound (GELU on 369 M elements), not latency-bound, and
 // more rows only add register pressure; every launcher uses ROWS = 1.
 template <typename T, int MAXV, bool XT = false, int ROWS = 1>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps,
-                                                        T* __restrict__ out_T, float* __restrict__ out_f32, int M, int C,
-                                                        const float* __restrict__ add, int add_mod, T* __restrict__ out_T2,
-                                                        int act) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, T* out_T, float* out_f32, int M,
+                                                        int C, const float* __restrict__ add, int add_mod, T* out_T2, int act) {
+    // (x and the outputs are NOT restrict-qualified: the tracker normalises its key stream and the up-scaled activation in
+    //  place; a wave has its whole row in registers - every store depends on the row statistics - before it writes)
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
     if (row0 >= M) return;
