@@ -162,10 +162,17 @@ int l4p_head_out(l4p_stream stream, int dtype, const void* x, const float* w, co
                  long long vox_per_b, int B, int C, int Cout, int post_exp);
 
 /* LstSqAffineAligner (aligner.py:29-66): least-squares scale/shift between two overlapping depth
- * windows, in inverse depth (inverse=1: f = safe_inverse, misc.py:48-62) or directly (inverse=0).
- * solve: sol[0..1] = argmin_{s,t} || s f(pred) + t - f(target) ||^2 over n floats; scratch = 6 doubles.
+ * windows, in inverse depth (mode bit 0 set: f = safe_inverse, misc.py:48-62) or directly (bit 0 clear).
+ * solve: sol[0..1] = argmin_{s,t} || s f(pred) + t - f(target) ||^2 over n floats.
+ * Mode bit 1 (L4P_ALIGN_RATIO_MEAN) selects LinearAligner(method="mean") instead (aligner.py:69-118):
+ * sol = (mean(f(target) / (f(pred) + 1e-8)), 0).
+ * scratch: L4P_AFFINE_SCRATCH_DOUBLES doubles (per-workgroup partial sums, added in a fixed order: the
+ * result is bit-reproducible).
  * apply: y = f(s f(x) + t). */
-int l4p_affine_align_solve(l4p_stream stream, const float* pred, const float* target, long long n, int inverse,
+#define L4P_ALIGN_INVERSE 1
+#define L4P_ALIGN_RATIO_MEAN 2
+#define L4P_AFFINE_SCRATCH_DOUBLES 4096
+int l4p_affine_align_solve(l4p_stream stream, const float* pred, const float* target, long long n, int mode,
                            double* scratch, float* sol);
 int l4p_affine_align_apply(l4p_stream stream, const float* x, float* y, long long n, int inverse, const float* sol);
 

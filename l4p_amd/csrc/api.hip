@@ -22,7 +22,7 @@ void l4p_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* l4p_last_error(void) { return g_err; }
-int l4p_abi_version(void) { return 1; }
+int l4p_abi_version(void) { return 2; }
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d) {
     if (!d) {

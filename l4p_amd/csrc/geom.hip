@@ -5,20 +5,30 @@
 // -------------------------------------------------------------------------------------------------
 // LstSqAffineAligner (aligner.py:29-66): min_{s,t} || s*f(pred) + t - f(target) ||^2, f = safe_inverse
 // (misc.py:48-62) or identity.  The reference builds a (401k x 2) matrix and calls torch.linalg.lstsq;
-// the same minimiser is the 2x2 normal-equation solve over five sums, accumulated here in double.
-// scratch: double[6] (zeroed by the launcher): n, Sa, Saa, Sb, Sab.   sol: float[2] = (s, t).
+// the same minimiser is the 2x2 normal-equation solve over four sums, accumulated here in double.
+// LinearAligner(method="mean") (aligner.py:69-118): s = mean(f(target) / (f(pred) + 1e-8)), t = 0 (mode bit 1).
+// Two-stage reduction in a FIXED order (bit-reproducible, unlike atomics): every workgroup leaves its four partial
+// sums in scratch[4 * block .. ], one workgroup then adds the L4P_AFFINE_BLOCKS partials in index order and solves.
+// scratch: double[4 * L4P_AFFINE_BLOCKS].   sol: float[2] = (s, t).   mode: bit 0 = inverse, bit 1 = ratio mean.
 // -------------------------------------------------------------------------------------------------
+#define L4P_AFFINE_BLOCKS 1024
 __device__ __forceinline__ float pre_fn(float x, int inverse) { return inverse ? (x > 0.f ? 1.0f / x : 0.f) : x; }
 
 __global__ __launch_bounds__(256) void affine_sums_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
-                                                          long long n, int inverse, double* __restrict__ scratch) {
+                                                          long long n, int mode, double* __restrict__ scratch) {
+    const int inverse = mode & 1, ratio = mode & 2;
     double sa = 0, saa = 0, sb = 0, sab = 0;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const double a = pre_fn(pred[i], inverse), b = pre_fn(tgt[i], inverse);
-        sa += a;
-        saa += a * a;
-        sb += b;
-        sab += a * b;
+        const float af = pre_fn(pred[i], inverse), bf = pre_fn(tgt[i], inverse);
+        if (ratio) {
+            sb += (double)(bf / (af + 1e-8f));  // (the reference divides in float: aligner.py:103-104)
+        } else {
+            const double a = af, b = bf;
+            sa += a;
+            saa += a * a;
+            sb += b;
+            sab += a * b;
+        }
     }
     __shared__ double red[4][4];
     double v[4] = {sa, saa, sb, sab};
@@ -31,18 +41,34 @@ __global__ __launch_bounds__(256) void affine_sums_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0)
         for (int k = 0; k < 4; ++k) red[wave][k] = v[k];
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(&scratch[1 + threadIdx.x], t);
-    }
+    if (threadIdx.x < 4)
+        scratch[4 * blockIdx.x + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void affine_solve_kernel(const double* __restrict__ scratch, long long n, float* __restrict__ sol) {
-    const double N = (double)n, sa = scratch[1], saa = scratch[2], sb = scratch[3], sab = scratch[4];
-    const double det = N * saa - sa * sa;
+// one workgroup of 256 threads: thread j sums partials j, j + 256, ... in order, then a fixed tree over the 256 threads
+__global__ __launch_bounds__(256) void affine_solve_kernel(const double* __restrict__ scratch, int nblocks, long long n, int mode,
+                                                           float* __restrict__ sol) {
+    __shared__ double red[256][4];
+    double v[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        for (int k = 0; k < 4; ++k) v[k] += scratch[4 * b + k];
+    for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = v[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double N = (double)n, sa = red[0][0], saa = red[0][1], sb = red[0][2], sab = red[0][3];
     double s = 0.0, t = 0.0;
-    if (fabs(det) > 0.0) {
-        s = (N * sab - sa * sb) / det;
-        t = (saa * sb - sa * sab) / det;
+    if (mode & 2) {
+        s = n > 0 ? sb / N : 1.0;
+    } else {
+        const double det = N * saa - sa * sa;
+        if (fabs(det) > 0.0) {
+            s = (N * sab - sa * sb) / det;
+            t = (saa * sb - sa * sab) / det;
+        }
     }
     sol[0] = (float)s;
     sol[1] = (float)t;
@@ -56,20 +82,19 @@ __global__ void affine_apply_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
-int launch_affine_solve(const float* pred, const float* tgt, long long n, int inverse, double* scratch, float* sol,
+int launch_affine_solve(const float* pred, const float* tgt, long long n, int mode, double* scratch, float* sol,
                         hipStream_t stream) {
     ProfScope prof(PROF_ELEMENTWISE, stream, "affine_solve");
-    HIP_TRY(hipMemsetAsync(scratch, 0, 6 * sizeof(double), stream));
-    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(affine_sums_kernel, dim3(grid), dim3(256), 0, stream, pred, tgt, n, inverse, scratch);
-    hipLaunchKernelGGL(affine_solve_kernel, dim3(1), dim3(1), 0, stream, scratch, n, sol);
+    const int grid = (int)((n + 255) / 256 < L4P_AFFINE_BLOCKS ? (n + 255) / 256 : L4P_AFFINE_BLOCKS);
+    if (grid > 0) hipLaunchKernelGGL(affine_sums_kernel, dim3(grid), dim3(256), 0, stream, pred, tgt, n, mode, scratch);
+    hipLaunchKernelGGL(affine_solve_kernel, dim3(1), dim3(256), 0, stream, scratch, grid, n, mode, sol);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 int launch_affine_apply(const float* x, float* y, long long n, int inverse, const float* sol, hipStream_t stream) {
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     ProfScope prof(PROF_ELEMENTWISE, stream, "affine_apply");
-    hipLaunchKernelGGL(affine_apply_kernel, dim3(grid), dim3(256), 0, stream, x, y, n, inverse, sol);
+    if (grid > 0) hipLaunchKernelGGL(affine_apply_kernel, dim3(grid), dim3(256), 0, stream, x, y, n, inverse & 1, sol);
     HIP_TRY(hipGetLastError());
     return 0;
 }

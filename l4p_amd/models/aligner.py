@@ -32,8 +32,14 @@ def _mode(pre_post_fn: Optional[str]) -> int:
     raise ValueError(f"Unknown pre_post_fn: {pre_post_fn}")
 
 
+AFFINE_SCRATCH_DOUBLES = 4096  # L4P_AFFINE_SCRATCH_DOUBLES (include/l4p_hip.h)
+ALIGN_INVERSE, ALIGN_RATIO_MEAN = 1, 2
+
+
 class LstSqAffineAligner(WindowOverlapAligner):
     """Scale + shift least squares between overlapping windows (aligner.py:29-66); one solve per batch item."""
+
+    _mode_bits = 0
 
     def __init__(self, pre_post_fn: Optional[str] = "identity") -> None:
         self.inverse = _mode(pre_post_fn)
@@ -44,11 +50,11 @@ class LstSqAffineAligner(WindowOverlapAligner):
         lib = _lib.load()
         bs = pred.shape[0]
         self.sol = torch.empty(bs, 2, dtype=torch.float32, device=pred.device)
-        scratch = torch.empty(6, dtype=torch.float64, device=pred.device)
+        scratch = torch.empty(AFFINE_SCRATCH_DOUBLES, dtype=torch.float64, device=pred.device)
         for b in range(bs):
             pb, tb = pred[b].contiguous(), target[b].contiguous()
-            _lib.check(lib.l4p_affine_align_solve(_stream(), _p(pb), _p(tb), pb.numel(), self.inverse, _p(scratch),
-                                                  self.sol[b].data_ptr()), "l4p_affine_align_solve")
+            _lib.check(lib.l4p_affine_align_solve(_stream(), _p(pb), _p(tb), pb.numel(), self.inverse | self._mode_bits,
+                                                  _p(scratch), self.sol[b].data_ptr()), "l4p_affine_align_solve")
 
     def apply(self, pred):
         assert self.sol is not None, "solve() first"
@@ -61,18 +67,20 @@ class LstSqAffineAligner(WindowOverlapAligner):
         return out
 
 
-class LinearAligner(WindowOverlapAligner):
-    """Scale-only aligner (aligner.py:69-118).  Not selected by configs/model.yaml (align_type defaults to
-    'affine'); kept for API completeness and not implemented on the engine."""
+class LinearAligner(LstSqAffineAligner):
+    """Scale-only aligner (aligner.py:69-118): scale = mean of f(target) / (f(pred) + 1e-8), shift = 0.  The same two
+    kernels as the affine aligner in their ratio-mean mode.  ``method="median"`` (a selection over 401k ratios) is not
+    built into the engine and is rejected here, at construction."""
+
+    _mode_bits = ALIGN_RATIO_MEAN
 
     def __init__(self, pre_post_fn: Optional[str] = "identity", method: str = "mean") -> None:
-        raise NotImplementedError("LinearAligner is not used by the shipped configuration; use align_type='affine'")
-
-    def solve(self, pred, target, intrinsics, img_info):  # pragma: no cover
-        raise NotImplementedError
-
-    def apply(self, pred):  # pragma: no cover
-        raise NotImplementedError
+        super().__init__(pre_post_fn)
+        if method not in ["mean", "median"]:
+            raise ValueError(f"Unknown method: {method}")
+        if method != "mean":
+            raise NotImplementedError("LinearAligner(method='median') is not built into the engine; use 'mean'")
+        self.method = method
 
 
 class KabaschUmeyama3DAligner(WindowOverlapAligner):

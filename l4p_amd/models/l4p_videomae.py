@@ -100,6 +100,18 @@ class L4P_VideoMAE(torch.nn.Module):
         self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         for key, head in self.task_heads.items():
             head._engine_task = key
+            # the packed weight layout and the decoder geometry are keyed by the ModuleDict key (weights.actpost_of /
+            # fusion_of: the ray head's tables under "camray", the dense tables otherwise): a head whose constructor
+            # arguments disagree with its key would decode with the wrong strides — refuse it here, not at the first forward
+            if isinstance(head, VideoMAEFlowDPTHead):
+                from ..weights import actpost_of, fusion_of
+
+                as_t = lambda x: tuple(tuple(int(v) for v in r) for r in x)  # noqa: E731
+                if as_t(head.actpost_scale_factors) != as_t(actpost_of(key)) or as_t(head.fusion_scale_factors) != as_t(fusion_of(key)):
+                    raise NotImplementedError(
+                        f"task head '{key}': actpost/fusion scale factors {head.actpost_scale_factors} / {head.fusion_scale_factors} "
+                        f"differ from the geometry the engine packs for this key ({actpost_of(key)} / {fusion_of(key)}); "
+                        "register ray heads under 'camray' and dense heads under any other key, with the default factors")
 
     # ---- weights ---------------------------------------------------------------------------------
     def expected_keys(self) -> "OrderedDict[str, Tuple[int, ...]]":
@@ -113,12 +125,17 @@ class L4P_VideoMAE(torch.nn.Module):
         missing = [k for k in exp if k not in sd]
         unexpected = [k for k in sd if k not in exp]
         bad = [k for k in exp if k in sd and tuple(sd[k].shape) != tuple(exp[k])]
-        if bad or (strict and (missing or unexpected)):
+        # strict=False tolerates UNEXPECTED keys only: the engine packs every expected tensor into its arena, so a missing
+        # one cannot be skipped (the reference would keep its random initialisation — never wanted for inference)
+        if bad or missing or (strict and unexpected):
             raise RuntimeError(
                 f"Error(s) in loading state_dict for L4P_VideoMAE: missing={missing[:5]} ({len(missing)}), "
                 f"unexpected={unexpected[:5]} ({len(unexpected)}), shape mismatch={bad[:5]} ({len(bad)})")
-        if self.device.type != "cuda":
+        if not torch.cuda.is_available():
             raise _lib.L4PHipError("no AMD GPU visible: the L4P engine has no CPU path")
+        # the device is resolved when the weights arrive, not at construction: a rank that builds the model before
+        # torch.cuda.set_device(local_rank) must still end up on its own GPU
+        self.device = torch.device("cuda", torch.cuda.current_device())
         self.set_weights(pack_state_dict(sd, self.cfg, torch.bfloat16 if self.engine_dtype == L4P_BF16 else torch.float32,
                                          self.device, tasks=list(self.task_heads.keys())))
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
@@ -126,6 +143,8 @@ class L4P_VideoMAE(torch.nn.Module):
     def set_weights(self, weights: PackedWeights) -> None:
         """Attach an already packed arena (e.g. received by RCCL broadcast, parallel.py)."""
         self.weights = weights
+        if weights.arena.is_cuda:
+            self.device = weights.arena.device  # the engine lives where its weights are
         self.engine = Engine(self.cfg, weights, self.engine_dtype, self.device)
         rt = _Runtime(self.cfg, weights, self.engine_dtype)
         rt.engine = self.engine

@@ -182,6 +182,8 @@ class VideoMAEDepthDPTHead(VideoMAEFlowDPTHead):
     def __init__(self, task_name: str, out_nchan: int = 1, depth: int = 40, embed_dim: int = 1408,
                  depth_fn: str = "linear", hooks_idx: Optional[List[int]] = None,
                  align_window_overlap_fn: Optional[str] = None, align_type: str = "affine") -> None:
+        if align_type not in ("affine", "linear"):
+            raise ValueError(f"align_type={align_type!r}: expected 'affine' or 'linear'")
         super().__init__(task_name, out_nchan, depth, embed_dim, hooks_idx,
                          overlap_aligner_type=LstSqAffineAligner if align_type == "affine" else LinearAligner,
                          aligner_kwargs=dict(pre_post_fn=align_window_overlap_fn))

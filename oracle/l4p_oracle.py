@@ -10,9 +10,11 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 product path (l4p_amd/*) never does and fails loudly when the HIP library is missing.
 
 Parity status: encoder, DPT heads, LstSq window stitching, tracker (incl. multi-window memory /
-re-seeding) and rays->camera with given intrinsics are pinned by golden vectors.  The two third-party
-RANSAC steps of the reference (cv2.findHomography / RQDecomp3x3, skimage.measure.ransac — unpinned
-versions, not installed here) are "parity unpinned": see DESIGN.md.
+re-seeding), rays->camera with given intrinsics and the multi-window joint depth + camera flow
+(oracle/joint_oracle.py: point maps, q98 threshold, similarity apply, stitching) are pinned by golden
+vectors.  The RANDOM DRAWS of the two third-party RANSAC steps of the reference (cv2.findHomography /
+RQDecomp3x3, skimage.measure.ransac — unpinned versions, not installed here) are "parity unpinned":
+see DESIGN.md.
 """
 from __future__ import annotations
 
@@ -443,10 +445,12 @@ class OracleModel:
     """Functional restatement of L4P_VideoMAE(always_use_windowed_version=True, joint_alignment=True) with the
     five heads of configs/model.yaml.  ``use_intrinsics`` mirrors task_heads['camray'].use_intrinsics."""
 
-    def __init__(self, sd: Dict[str, Tensor], cfg, use_intrinsics: bool = True, max_queries: int = 192):
+    def __init__(self, sd: Dict[str, Tensor], cfg, use_intrinsics: bool = True, max_queries: int = 192, seam: str = "engine"):
         self.sd, self.cfg = sd, cfg
         self.use_intrinsics = use_intrinsics
         self.max_queries = max_queries
+        self.seam = seam  # how the multi-window joint alignment draws its samples (oracle/joint_oracle.py)
+        self.seam_log: list = []
         # actpost / fusion scale factors: dense_heads.py:30-31 and :269-271
         self._actpost = lambda t: ((1, 0, 0), (1, 0, 0), (0, 0, 0), (-1, -1, -1)) if t == "camray" else ((1, 2, 2), (1, 1, 1), (0, 0, 0), (-1, -1, -1))
         self._fusion = lambda t: ((1, 1, 1), (1, 1, 1), (2, 1, 1), (2, 2, 2)) if t == "camray" else ((1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2))
@@ -496,17 +500,26 @@ class OracleModel:
         return {key: buf}
 
     def joint_depth_camray(self, feats2d, strides, intrinsics_b44t) -> Dict[str, Tensor]:
-        """joint_windowed_estimation dense_heads.py:360-492 — single-window case only (the multi-window seam
-        alignment is skimage RANSAC: parity unpinned)."""
-        if len(strides) != 1:
-            raise NotImplementedError("KabaschUmeyama3DAligner needs skimage.measure.ransac: parity unpinned")
-        out = {}
-        out.update(self.dense_single("depth", feats2d[0], intrinsics_b44t[..., :self.cfg.frames]))
-        out.update(self.dense_single("camray", feats2d[0], intrinsics_b44t[..., :self.cfg.frames]))
-        # no estimated K when use_intrinsics: the input K is echoed (dense_heads.py:419-422)
+        """joint_windowed_estimation dense_heads.py:360-492.  One window: the two heads, K echoed (:419-422).  Several
+        windows: oracle/joint_oracle.py — point maps, q98 threshold, similarity, apply; the two random draws of the
+        reference are replaced as ``self.seam`` says ("engine": the engine's deterministic sampler / trial schedule;
+        "fixed": the stand-ins the flow was pinned with against the reference, tools/gen_golden_joint.py)."""
+        from oracle import joint_oracle as jo
+
         ws = self.cfg.frames
-        out["traj3d_intrinsics_est_b16t"] = intrinsics_b44t[..., :ws].clone().reshape(1, 16, ws)
-        return out
+
+        def heads(win_id: int) -> Dict[str, Tensor]:
+            st = int(strides[win_id])
+            K = intrinsics_b44t[..., st:st + ws]
+            d = self.dense_single("depth", feats2d[win_id], K)["depth_est_b1thw"]
+            c = self.dense_single("camray", feats2d[win_id], K)["traj3d_est_b16t"]
+            # no estimated K when use_intrinsics: the input K is echoed (dense_heads.py:419-422)
+            return {"depth": d, "camray": c, "camray_intrinsics_est": K.clone().reshape(1, 16, ws)}
+
+        self.seam_log = []
+        est = jo.joint_windowed(heads, strides, ws, self.seam, self.seam_log)
+        return {"depth_est_b1thw": est["depth"], "traj3d_est_b16t": est["camray"],
+                "traj3d_intrinsics_est_b16t": est["camray_intrinsics_est"]}
 
     def track(self, feats2d, strides, queries_bn3: Tensor, labels_bn: Tensor, trace=None) -> Dict[str, Tensor]:
         """forward_windowed sparse_heads.py:162-211 (chunks of max_queries)."""

@@ -1,0 +1,281 @@
+"""Direct parity of the 8-phase 256x256 bf16 kernel (csrc/gemm8p.hpp) — the kernel that carries the batch-4 encoder
+linears, the tracker's tall GEMMs and the N = 256 DPT convs of the benchmarked workload — against plain PyTorch fp32 on
+the same bf16-rounded inputs, at the SHAPES THE BENCH RUNS.  tests/test_kernels_gpu.py's shapes all fall on the 128x128
+kernel (the 8-phase kernel is selected for >= 192..256 tiles of 256x256, gemm_launch.inc), so every test here asserts
+through the event profiler's tag (l4p_prof_detail) that the launch really was the 8-phase kernel.
+
+Tolerances are tests/test_kernels_gpu.py's: float outputs 1e-3 * max|ref|; bf16 outputs rel-L2 <= 3e-3 and max error
+<= 1 bf16 ulp of max|ref|.  Reference call sites: modeling_finetune.py:169-190 (qkv / proj), :62-69 (fc1 / fc2),
+sam/transformer.py:223-245 (i2t out projection, K = 704), mask_decoder.py:58-66,136-139 (up-scaling ConvTranspose, mask
+product), dpt_block.py:110-157 (3x3x3 convs)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from l4p_amd import _lib, ops
+from l4p_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_DENSE, EPI_MASKDOT, L4P_BF16, GemmDesc
+from tests.test_kernels_gpu import as_mode, check, rnd
+
+MODE = L4P_BF16
+
+
+class prof_tags:
+    """Collect the (class, tag) lines of every launch inside the block (l4p_prof_detail)."""
+
+    def __enter__(self):
+        self.lib = _lib.load()
+        torch.cuda.synchronize()
+        self.lib.l4p_prof_reset()
+        self.lib.l4p_prof_enable(1)
+        self.lines = []
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        self.lib.l4p_prof_enable(0)
+        n = self.lib.l4p_prof_detail(None, 0)
+        buf = C.create_string_buffer(int(n) + 16)
+        self.lib.l4p_prof_detail(buf, len(buf))
+        self.lines = [ln.split("\t") for ln in buf.value.decode().splitlines() if ln]
+        self.lib.l4p_prof_reset()
+        return False
+
+    def assert_8p(self, cls="gemm", n=1):
+        tags = [ln[1] for ln in self.lines if ln[0] == cls]
+        assert len(tags) >= n and all(" 8p " in t for t in tags), f"expected the 8-phase kernel, launches were: {self.lines}"
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 6144, 1408),   # fc1 (+ GELU below)
+                                     (8192, 1408, 6144),   # fc2: 192 tiles
+                                     (8192, 1408, 1408),   # proj
+                                     (16384, 2048, 704),   # odd number of k-tiles (11)
+                                     (8200, 1416, 1216),   # ragged M and N (tile tails), 19 k-tiles
+                                     (16384, 1408, 1176)]) # K not a multiple of the k-tile (18.4 tiles; K % 8 == 0)
+def test_gemm8p_dense_bias(dev, M, N, K):
+    a, a_ref = as_mode(rnd((M, K), 10), MODE)
+    w, w_ref = as_mode(rnd((N, K), 11, K ** -0.5), MODE)
+    bias = rnd((N,), 12)
+    ref = a_ref @ w_ref.t() + bias
+    with prof_tags() as p:
+        yT, yf = ops.gemm(a, ops.pad_rows(w, 256), N, bias=bias.cuda(), out_f32=True, out_T=True)
+    p.assert_8p()
+    check(yf, ref, MODE, False)
+    check(yT, ref, MODE, True)
+
+
+def test_gemm8p_gelu_and_f32_residual_inplace(dev):
+    """fc1's GELU epilogue, and fc2's form: float residual stream read and written IN PLACE (out_f32 aliases res1)."""
+    M, N, K = 8192, 6144, 1408
+    a, a_ref = as_mode(rnd((M, K), 20), MODE)
+    w, w_ref = as_mode(rnd((N, K), 21, K ** -0.5), MODE)
+    bias = rnd((N,), 22)
+    with prof_tags() as p:
+        h, _ = ops.gemm(a, ops.pad_rows(w, 256), N, bias=bias.cuda(), act=ACT_GELU)
+    p.assert_8p()
+    href = F.gelu(a_ref @ w_ref.t() + bias)
+    check(h, href, MODE, True)
+    # fc2 on the kernel's own (bf16) hidden activations, residual in place
+    w2, w2_ref = as_mode(rnd((K, N), 23, N ** -0.5), MODE)
+    b2 = rnd((K,), 24)
+    res = rnd((M, K), 25, 3.0)
+    x = res.clone().cuda()
+    with prof_tags() as p:
+        ops.gemm(h, ops.pad_rows(w2, 256), K, bias=b2.cuda(), res1=x, out=x)
+    p.assert_8p()
+    check(x, h.float().cpu() @ w2_ref.t() + b2 + res, MODE, False)
+
+
+def test_gemm8p_two_residuals_T(dev):
+    """DPT skip connections: two residuals stored in the engine dtype + ReLU."""
+    M, N, K = 65536, 256, 256
+    a, a_ref = as_mode(rnd((M, K), 30), MODE)
+    w, w_ref = as_mode(rnd((N, K), 31, K ** -0.5), MODE)
+    bias = rnd((N,), 32)
+    r1, r1_ref = as_mode(rnd((M, N), 33), MODE)
+    r2, r2_ref = as_mode(rnd((M, N), 34), MODE)
+    with prof_tags() as p:
+        y, _ = ops.gemm(a, ops.pad_rows(w, 256), N, bias=bias.cuda(), act=ACT_RELU, res1=r1, res2=r2)
+    p.assert_8p()
+    check(y, F.relu(a_ref @ w_ref.t() + bias) + r1_ref + r2_ref, MODE, True)
+
+
+def test_gemm8p_tracker_i2t_out_res_inplace_and_row_maps(dev):
+    """The tracker's image->token output projection (M = N_q * 2048 key rows, N = 1408, K = 704) with its f32 residual
+    updated in place; then the same GEMM restricted by the row maps to the second temporal half of every query's token
+    block (sparse_heads.py:406-448: rows (m / 1024) * 2048 + 1024 + m % 1024 of A and of the output)."""
+    Nq, P, Cc, K = 64, 2048, 1408, 704
+    M = Nq * P
+    a, a_ref = as_mode(rnd((M, K), 40), MODE)
+    w, w_ref = as_mode(rnd((Cc, K), 41, K ** -0.5), MODE)
+    bias = rnd((Cc,), 42)
+    keys = rnd((M, Cc), 43)
+    x = keys.clone().cuda()
+    with prof_tags() as p:
+        ops.gemm(a, ops.pad_rows(w, 256), Cc, bias=bias.cuda(), res1=x, out=x)
+    p.assert_8p()
+    ref = a_ref @ w_ref.t() + bias + keys
+    check(x, ref, MODE, False)
+    del x
+    # row-mapped: logical rows = second half (1024 rows) of each of the Nq blocks of 2048
+    half = P // 2
+    out = torch.zeros((M, Cc), dtype=torch.float32, device="cuda")
+    d = GemmDesc()
+    wp = ops.pad_rows(w, 256)
+    bc = bias.cuda()
+    d.A, d.lda, d.W, d.ldw = a.data_ptr(), K, wp.data_ptr(), K
+    d.M, d.N, d.K = Nq * half, Cc, K
+    d.bias = bc.data_ptr()
+    d.out_f32, d.ldc = out.data_ptr(), Cc
+    d.epi = EPI_DENSE
+    d.a_gr, d.a_gs, d.a_go = half, P, half
+    d.c_gr, d.c_gs, d.c_go = half, P, half
+    with prof_tags() as p:
+        _lib.check(_lib.load().l4p_gemm(torch.cuda.current_stream().cuda_stream, MODE, C.byref(d)), "l4p_gemm(row map)")
+    p.assert_8p()
+    o = out.cpu().view(Nq, P, Cc)
+    assert float(o[:, :half].abs().max()) == 0.0, "rows outside the map were written"
+    check(o[:, half:], (ref - keys).view(Nq, P, Cc)[:, half:], MODE, False)
+
+
+def test_gemm8p_qkv_epilogue_and_batch4_attention(dev):
+    """The benchmarked encoder shapes: EPI_QKV at M = 8192, N = 4608 (8-phase kernel: q dense, K in tile order, V
+    transposed) feeding the un-split (SPLIT = 1) hand-scheduled attention kernel that only batch >= 4 selects."""
+    B, S, H, Dh = 4, 2048, 16, 88
+    Cc = H * Dh
+    x, x_ref = as_mode(rnd((B * S, Cc), 50), MODE)
+    wqkv = rnd((3 * Cc, Cc), 51, Cc ** -0.5)
+    qb, vb = rnd((Cc,), 52) * 0.1, rnd((Cc,), 53) * 0.1
+    wp = torch.zeros(3, H, ops.DP, Cc)
+    wp[:, :, :Dh] = wqkv.view(3, H, Dh, Cc)
+    bp = torch.zeros(3, H, ops.DP)
+    bp[0, :, :Dh] = qb.view(H, Dh)
+    bp[2, :, :Dh] = vb.view(H, Dh)
+    w, w_ref = as_mode(wp.view(3 * H * ops.DP, Cc), MODE)
+    with prof_tags() as p:
+        q, kt, vt = ops.qkv_gemm(x, ops.pad_rows(w, 256), bp.view(-1).cuda(), B, S, H)
+    p.assert_8p()
+    full = (x_ref @ w_ref.t() + bp.view(-1)).view(B, S, 3, H, ops.DP)
+    check(q.view(B, S, H, ops.DP), full[:, :, 0], MODE, True)
+    check(vt, full[:, :, 2].permute(0, 2, 3, 1), MODE, True)
+    check(kt, ops.k_tile_order(full[:, :, 1].contiguous().to(torch.bfloat16)).float(), MODE, True)
+    q_ref = q.float().cpu().view(B, S, H, ops.DP).permute(0, 2, 1, 3)
+    k_ref = full[:, :, 1].to(torch.bfloat16).float().permute(0, 2, 1, 3)
+    v_ref = vt.float().cpu().permute(0, 1, 3, 2)
+    out = ops.attention(q, kt, vt, Dh)
+    for b in range(B):  # one clip at a time: the score matrices of a clip are 16 x 2048 x 2048 floats
+        attn = torch.softmax((q_ref[b] * Dh ** -0.5) @ k_ref[b].transpose(-2, -1), dim=-1)
+        ref = (attn @ v_ref[b])[..., :Dh].transpose(0, 1).reshape(S, Cc)
+        check(out[b * S:(b + 1) * S], ref, MODE, True)
+
+
+def test_gemm8p_conv_transpose_upscaling(dev):
+    """The tracker's first up-scaling ConvTranspose3d(1408 -> 352, k = s = 2) for 8 queries: M = 16384, N = 2816, K = 1408,
+    scatter epilogue (EPI_CONVT)."""
+    Nq, T, h, w_, Cin, cout, k = 8, 8, 16, 16, 1408, 352, (2, 2, 2)
+    x, x_ref = as_mode(rnd((Nq, T, h, w_, Cin), 60), MODE)
+    wt = rnd((Cin, cout) + k, 61, Cin ** -0.5)
+    bias = rnd((cout,), 62)
+    wT, w_ref = as_mode(wt.permute(2, 3, 4, 1, 0).reshape(8 * cout, Cin), MODE)
+    w5 = w_ref.view(2, 2, 2, cout, Cin).permute(4, 3, 0, 1, 2)
+    ref = F.conv_transpose3d(x_ref.permute(0, 4, 1, 2, 3), w5, bias, stride=k).permute(0, 2, 3, 4, 1)
+    with prof_tags() as p:
+        y = ops.conv_transpose(x, ops.pad_rows(wT, 256), cout, k, bias_taps=bias.repeat(8).cuda())
+    p.assert_8p()
+    check(y, ref, MODE, True)
+
+
+def test_gemm8p_maskdot_large(dev):
+    """L4P_EPI_MASKDOT on the 8-phase kernel (M = 65536 >= the 256-tile threshold): GELU(ConvTranspose(1,2,2)) contracted
+    with the per-query hyper-network vectors (mask_decoder.py:136-139), against the unfused statement."""
+    Nq, T, h, w_, Cin, d1 = 4, 16, 32, 32, 352, 176
+    x, x_ref = as_mode(rnd((Nq, T, h, w_, Cin), 90), MODE)
+    wt = rnd((Cin, d1, 1, 2, 2), 91, Cin ** -0.5)
+    bias = rnd((d1,), 92)
+    hyper = rnd((Nq, 3, d1), 93)
+    wm = wt.permute(2, 3, 4, 1, 0).reshape(4, d1, Cin)
+    wp, w_ref = as_mode(wm.reshape(4 * d1, Cin), MODE)
+    up = F.gelu(F.conv_transpose3d(x_ref.permute(0, 4, 1, 2, 3), w_ref.view(1, 2, 2, d1, Cin).permute(4, 3, 0, 1, 2), bias,
+                                   stride=(1, 2, 2)))
+    ref = torch.einsum("nic,nctyx->nityx", hyper, up)
+    M = Nq * T * h * w_
+    cpt = d1 // 32  # 176 = 5.5 chunks: d1 must be padded to a multiple of 32 per tap
+    d1p = (d1 + 31) // 32 * 32
+    cpt = d1p // 32
+    wpp, _ = as_mode(F.pad(wm, (0, 0, 0, d1p - d1)).reshape(4 * d1p, Cin), MODE)
+    hp = torch.zeros(Nq, 3, d1p)
+    hp[..., :d1] = hyper
+    hp = hp.cuda()
+    bp = F.pad(bias, (0, d1p - d1)).repeat(4).cuda()
+    partial = torch.empty(4 * cpt, 3, M, dtype=torch.float32, device="cuda")
+    wpad = ops.pad_rows(wpp, 256)
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = x.data_ptr(), Cin, wpad.data_ptr(), Cin
+    d.M, d.N, d.K = M, 4 * d1p, Cin
+    d.bias, d.act = bp.data_ptr(), ACT_GELU
+    d.out_f32 = partial.data_ptr()
+    d.epi, d.Cout = EPI_MASKDOT, d1p
+    d.hyper, d.hyper_rows = hp.data_ptr(), M // Nq
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    masks = torch.empty(Nq, 3, T, 2 * h, 2 * w_, dtype=torch.float32, device="cuda")
+    with prof_tags() as p:
+        _lib.check(lib.l4p_gemm(st, MODE, C.byref(d)), "l4p_gemm(maskdot)")
+    p.assert_8p()
+    _lib.check(lib.l4p_mask_gather(st, partial.data_ptr(), masks.data_ptr(), Nq, T, h, w_, cpt), "l4p_mask_gather")
+    torch.cuda.synchronize()
+    check(masks, ref, MODE, False)
+
+
+def _conv_rows_reference(x_ref, w_ref, bias, rows, stride=(1, 1, 1)):
+    """fp32 reference of SELECTED output voxels of a 3x3x3 / pad 1 conv (channels-last): rows = flat output indices.
+    (The full M = 262144, K = 6912 problem is 0.93 TFLOP — minutes on the host; whole tiles + scattered rows are not.)"""
+    B, Ti, Hi, Wi, Cin = x_ref.shape
+    st, sh, sw = stride
+    To, Ho, Wo = (Ti - 1) // st + 1, (Hi - 1) // sh + 1, (Wi - 1) // sw + 1
+    xp = F.pad(x_ref, (0, 0, 1, 1, 1, 1, 1, 1))  # pad W, H, T by one voxel
+    wo = rows % Wo
+    r = rows // Wo
+    ho = r % Ho
+    r = r // Ho
+    to = r % To
+    b = r // To
+    cols = []
+    for dt in range(3):
+        for dh in range(3):
+            for dw in range(3):
+                cols.append(xp[b, to * st + dt, ho * sh + dh, wo * sw + dw])  # [R, Cin]
+    a = torch.cat(cols, dim=1)  # [R, 27*Cin], k = tap*Cin + c
+    return a @ w_ref.t() + bias
+
+
+@pytest.mark.parametrize("shape,cout", [((4, 16, 64, 64, 256), 256),   # refinenet RCU convs of a B = 4 step: K = 6912
+                                         ((4, 16, 32, 32, 512), 256),   # layer_rn: K = 13824
+                                         ((2, 16, 56, 56, 256), 256)])  # plane 3136 = 12.25 tiles: walk falls back, ragged rows
+def test_gemm8p_conv3d(dev, shape, cout):
+    B, T, H, W, Cin = shape
+    x, x_ref = as_mode(rnd(shape, 70), MODE)
+    w = rnd((cout, Cin, 3, 3, 3), 71, (27 * Cin) ** -0.5)
+    bias = rnd((cout,), 72)
+    wT, w_ref = as_mode(w.permute(0, 2, 3, 4, 1).reshape(cout, 27 * Cin), MODE)
+    M = B * T * H * W
+    skip, s_ref = as_mode(rnd((B, T, H, W, cout), 73), MODE)
+    with prof_tags() as p:
+        y, yr = ops.conv3d_k3(x, ops.pad_rows(wT, 256), cout, bias=bias.cuda(), act=ACT_NONE, res1=skip, relu_copy=True)
+    p.assert_8p("conv3d")
+    g = torch.Generator().manual_seed(7)
+    rows = torch.cat([torch.arange(0, 512),                       # first two tiles (t = 0 border, h = 0 border)
+                      torch.arange(M - 512, M),                   # last tiles (far borders)
+                      torch.arange(M // 2 - 256, M // 2 + 256),   # a tile pair in the interior / across a plane seam
+                      torch.randint(0, M, (3072,), generator=g)])
+    ref = _conv_rows_reference(x_ref, w_ref, bias, rows) + s_ref.reshape(M, cout)[rows]
+    got = y.reshape(M, cout)[rows.cuda()]
+    check(got, ref, MODE, True)
+    check(yr.reshape(M, cout)[rows.cuda()], F.relu(ref), MODE, True)
+    # every row at least finite and of the right scale (catches a tile that was never written)
+    assert bool(torch.isfinite(y.float()).all())
+    rms = y.float().pow(2).mean(dim=-1).sqrt().reshape(-1)
+    assert float(rms.min()) > 0.05 * float(rms.mean())

@@ -5,7 +5,8 @@ against the oracle run live and the reference's golden vectors.
 Float outputs: L4P_F32 engine 1e-3 relative-to-max (north_star); L4P_BF16 engine rel-L2 <= 5e-2 (bf16
 drift through 4 encoder blocks + 2 two-way layers, reported).  Integer / boolean window state (labels,
 prompt labels, validity masks, re-seeded query times = argmax index) is asserted BIT-EXACT in f32 mode
-against both the oracle trace and the reference's recorded trace."""
+against both the oracle trace and the reference's recorded trace; in bf16 mode the tracks whose state differs
+from the f32 trace are counted and bounded (<= 1 per fixture)."""
 import os
 
 import numpy as np
@@ -67,6 +68,21 @@ def test_tracker_vs_oracle_and_golden(dev, mini, precision, case, T, nq):
             assert np.array_equal(tr["queries"][:, 0].cpu().numpy(), gold[f"trace{w}_queries"][:, 0]), w
             if "best_vis_id" in otrace[w]:
                 assert torch.equal(tr["best_vis_id"].cpu().long(), otrace[w]["best_vis_id"]), w
+    else:
+        # bf16 engine (the shipped dtype): the integer / boolean state is a function of float visibilities (the re-seed
+        # index is an argmax over 8 frames), so it is COUNTED against the f32 oracle trace and bounded: tracks whose state
+        # differs anywhere in the recursion.  Measured 0 of 8 / 0 of 12 on these fixtures; the bound allows one near-tie.
+        differing = torch.zeros(nq, dtype=torch.bool)
+        for w in range(nwin):
+            tr = head.trace[w]
+            differing |= tr["labels"].cpu() != otrace[w]["labels"]
+            differing |= tr["prompt_labels"].cpu() != otrace[w]["prompt_labels"]
+            differing |= (tr["valid_t"].cpu().bool() != otrace[w]["valid_t"]).any(dim=-1)
+            differing |= tr["queries"][:, 0].cpu() != otrace[w]["queries"][:, 0]
+            if "best_vis_id" in otrace[w]:
+                differing |= tr["best_vis_id"].cpu().long() != otrace[w]["best_vis_id"]
+        print(f"bf16 integer-state mismatches vs f32 trace ({case}): {int(differing.sum())} of {nq} tracks")
+        assert int(differing.sum()) <= 1, differing
 
 
 @pytest.mark.parametrize("precision", ["32-true", "bf16"])
