@@ -198,7 +198,10 @@ int l4p_rays_to_intrinsics(l4p_stream stream, const float* rays, float* out_K, f
  * validated against synthetic ground truth ("parity unpinned").
  * ---------------------------------------------------------------------------------------------- */
 
-/* approximate q-quantile of n non-negative floats (4096-bin histogram over [min,max]); ws >= 4098 uints */
+/* EXACT q-quantile of n non-negative floats with torch.quantile's linear interpolation (aligner.py:187): radix select
+ * of the order statistics floor(q (n-1)) and the next one on the float bit patterns, then ATen's lerp.
+ * ws >= L4P_QUANTILE_WS_UINTS uints. */
+#define L4P_QUANTILE_WS_UINTS 2052
 int l4p_quantile(l4p_stream stream, const float* x, long long n, float q, unsigned* ws, float* out);
 
 /* world-space points of a hashed 1/ratio pixel subset of F frames: depth [F][H*W], K and P (world_T_cam)

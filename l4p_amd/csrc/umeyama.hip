@@ -12,44 +12,61 @@ __device__ __forceinline__ unsigned hash_u32(unsigned x) {  // PCG-style integer
 }
 
 // -------------------------------------------------------------------------------------------------
-// q-quantile of a positive float array via a 4096-bin histogram over [min, max] (threshold scale only).
-// ws: uint[2] (min/max as ordered uints) + uint[4096] bins.  out[0] = approx quantile.
+// EXACT q-quantile of n non-negative floats with torch.quantile's linear interpolation (aligner.py:187:
+// torch.quantile(depth, 0.98)): pos = q (n - 1) in float, result = lerp(x_(lo), x_(lo+1), pos - lo) over the order
+// statistics.  Non-negative floats order like their bit patterns, so x_(lo) is found by a three-pass radix select on the
+// bits (11 + 11 + 10), one histogram + one pick per pass; x_(lo+1) is x_(lo) again when it has duplicates covering rank
+// lo + 1, else the smallest element above it (one more pass).  Negative inputs (never produced: depth = exp(.)) are
+// treated as 0.
+// ws (uint): [0] prefix bits found so far, [1] rank still to skip inside the prefix, [2] count of x == x_(lo) after the
+// last pass, [3] bits of min{x > x_(lo)}, [4 ..] 2048 histogram bins.
 // -------------------------------------------------------------------------------------------------
-__global__ void minmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ ws) {
-    float mn = INFINITY, mx = -INFINITY;
+#define QSEL_BINS 2048
+__device__ __forceinline__ unsigned qsel_key(float v) { return __float_as_uint(fmaxf(v, 0.f)); }
+
+template <int SHIFT, int BITS, unsigned PMASK>
+__global__ void qsel_hist_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ ws) {
+    const unsigned prefix = ws[0];
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        mn = fminf(mn, x[i]);
-        mx = fmaxf(mx, x[i]);
-    }
-    mn = -wave_max(-mn);
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) {  // values are >= 0 (depth = exp(.)): the uint order equals the float order
-        atomicMin(&ws[0], __float_as_uint(fmaxf(mn, 0.f)));
-        atomicMax(&ws[1], __float_as_uint(fmaxf(mx, 0.f)));
+        const unsigned k = qsel_key(x[i]);
+        if ((k & PMASK) == prefix) atomicAdd(&ws[4 + ((k >> SHIFT) & ((1u << BITS) - 1))], 1u);
     }
 }
-__global__ void hist_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ ws) {
-    const float mn = __uint_as_float(ws[0]), mx = __uint_as_float(ws[1]);
-    const float sc = mx > mn ? 4096.f / (mx - mn) : 0.f;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        int b = (int)((x[i] - mn) * sc);
-        b = b < 0 ? 0 : (b > 4095 ? 4095 : b);
-        atomicAdd(&ws[2 + b], 1u);
-    }
-}
-__global__ void quantile_pick_kernel(const unsigned* __restrict__ ws, long long n, float q, float* __restrict__ out) {
+template <int SHIFT, int BITS, bool LAST>
+__global__ void qsel_pick_kernel(unsigned* __restrict__ ws) {
     if (threadIdx.x != 0) return;
-    const float mn = __uint_as_float(ws[0]), mx = __uint_as_float(ws[1]);
-    const double target = q * (double)(n - 1);
-    double acc = 0;
-    int b = 0;
-    for (; b < 4096; ++b) {
-        if (acc + ws[2 + b] > target) break;
-        acc += ws[2 + b];
+    unsigned rank = ws[1], b = 0;
+    for (; b < (1u << BITS) - 1; ++b) {
+        const unsigned c = ws[4 + b];
+        if (rank < c) break;
+        rank -= c;
     }
-    if (b > 4095) b = 4095;
-    const double frac = ws[2 + b] ? (target - acc) / (double)ws[2 + b] : 0.0;
-    out[0] = mn + (float)((b + frac) * (double)(mx - mn) / 4096.0);
+    ws[0] |= b << SHIFT;
+    ws[1] = rank;
+    if (LAST) ws[2] = ws[4 + b];
+    for (unsigned i = 0; i < QSEL_BINS; ++i) ws[4 + i] = 0;
+}
+__global__ void qsel_next_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ ws) {
+    const unsigned v = ws[0];
+    unsigned mn = 0xFFFFFFFFu;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned k = qsel_key(x[i]);
+        if (k > v && k < mn) mn = k;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = __shfl_xor(mn, o);
+        mn = other < mn ? other : mn;
+    }
+    if ((threadIdx.x & 63) == 0 && mn != 0xFFFFFFFFu) atomicMin(&ws[3], mn);
+}
+__global__ void qsel_finish_kernel(const unsigned* __restrict__ ws, float weight, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const float a = __uint_as_float(ws[0]);
+    // rank lo sits at offset ws[1] inside the ws[2] copies of a: rank lo + 1 is another copy unless it was the last one
+    const float b = (ws[1] + 1 < ws[2] || ws[3] == 0xFFFFFFFFu) ? a : __uint_as_float(ws[3]);
+    // ATen lerp: the weight < 0.5 form and its mirror (aten/src/ATen/native/Lerp.h)
+    const float d = b - a;
+    out[0] = weight < 0.5f ? __builtin_fmaf(weight, d, a) : b - d * (1.f - weight);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -338,16 +355,32 @@ __global__ void scale_by_device_scalar_kernel(float* __restrict__ x, long long n
 
 extern "C" {
 
-/* approx. q-quantile of n non-negative floats (4096-bin histogram). ws: >= 4098 uints. */
+/* exact q-quantile (torch.quantile, linear interpolation) of n non-negative floats. ws: >= L4P_QUANTILE_WS_UINTS uints. */
 int l4p_quantile(l4p_stream s_, const float* x, long long n, float q, unsigned* ws, float* out) {
     hipStream_t s = (hipStream_t)s_;
+    if (n < 1 || n > 0x7FFFFFFFll || !(q >= 0.f && q <= 1.f)) {
+        l4p_set_error("l4p_quantile: need 1 <= n < 2^31 and 0 <= q <= 1 (n=%lld q=%g)", n, (double)q);
+        return L4P_E_INVALID;
+    }
     ProfScope prof(PROF_ELEMENTWISE, s, "l4p_quantile");
-    HIP_TRY(hipMemsetAsync(ws, 0xFF, 4, s));
-    HIP_TRY(hipMemsetAsync(ws + 1, 0, 4097 * 4, s));
+    // torch.quantile computes the rank in the input dtype: pos = q * (n - 1) rounded to float
+    const float pos = q * (float)(n - 1);
+    const float lo_f = floorf(pos);
+    const unsigned lo = (unsigned)lo_f;
+    unsigned init[4] = {0u, lo, 0u, 0xFFFFFFFFu};
+    HIP_TRY(hipMemsetAsync(ws, 0, (4 + QSEL_BINS) * sizeof(unsigned), s));
+    // (init is tiny and lives on the host stack: three 4-byte memsets keep the call free of host -> device copies)
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ws + 1), (int)init[1], 1, s));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ws + 3), (int)init[3], 1, s));
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
-    hipLaunchKernelGGL(hist_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
-    hipLaunchKernelGGL(quantile_pick_kernel, dim3(1), dim3(64), 0, s, ws, n, q, out);
+    hipLaunchKernelGGL((qsel_hist_kernel<21, 11, 0u>), dim3(grid), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL((qsel_pick_kernel<21, 11, false>), dim3(1), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL((qsel_hist_kernel<10, 11, 0xFFE00000u>), dim3(grid), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL((qsel_pick_kernel<10, 11, false>), dim3(1), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL((qsel_hist_kernel<0, 10, 0xFFFFFC00u>), dim3(grid), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL((qsel_pick_kernel<0, 10, true>), dim3(1), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(qsel_next_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL(qsel_finish_kernel, dim3(1), dim3(64), 0, s, ws, pos - lo_f, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

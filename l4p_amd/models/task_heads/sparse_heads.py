@@ -302,8 +302,8 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             raise RuntimeError("tracker head has no weights: call load_state_dict on the model first")
         assert len(self.estimation_directions) == 1 and self.estimation_directions[0] == 1, (
             "Currently only positive direction estimation is supported for sliding window tracking.")
-        if time_strides is None:
-            time_strides = torch.zeros(1, dtype=torch.long)
+        if time_strides is None:  # if windowing is not needed just do a forward pass (sparse_heads.py:223-227)
+            return self.forward(enc_features_bpc_2dlist[0], track_2d_pointquerries_bn3, track_2d_pointlabels_bn)
         lib = _lib.load()
         cfg = self._rt.cfg
         dev = enc_features_bpc_2dlist[0].f32(-1).device
@@ -377,6 +377,40 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 f"{self.task_name}_depth_est_bn1t": dep_all}
 
     def forward(self, enc_features_bpc_list, track_2d_pointquerries_bn3: torch.Tensor, track_2d_pointlabels_bn: torch.Tensor,
-                **kwargs) -> Dict[str, torch.Tensor]:
-        """Single-window entry (l4p_videomae.py:251): same as one window of the sliding tracker."""
-        return self.forward_windowed_core([enc_features_bpc_list], track_2d_pointquerries_bn3, track_2d_pointlabels_bn, None)
+                track_2d_promptfeatures_bnc: Optional[torch.Tensor] = None,
+                track_2d_promptfeaturelabels_bn: Optional[torch.Tensor] = None, **kwargs) -> Dict[str, torch.Tensor]:
+        """Single-window forward (sparse_heads.py:497-600), reached from L4P_VideoMAE.forward_single_window
+        (always_use_windowed_version=False and T == 16) and from forward_windowed_core(time_strides=None).  Unlike a window of
+        the sliding tracker it attends to the raw enc_features[-1] (NO history / mask-token term), takes the caller's point
+        labels as they are, starts from zero prompt features unless they are passed in, and returns the window's estimates
+        for every frame (no validity masking, no -10 visibility fill).
+        Returned: traj [B,N,2,T], vis [B,N,1,T], depth [B,N,1,T], <task>_prompt_features_bnc [B,N,C].  The reference also
+        returns <task>_enc_features_with_track_history_bnpc ([B,N,2048,1408] floats, 11.5 MB per query) which no consumer of
+        a single-window forward reads; it is not materialised here."""
+        if self._rt is None:
+            raise RuntimeError("tracker head has no weights: call load_state_dict on the model first")
+        lib = _lib.load()
+        cfg = self._rt.cfg
+        enc = enc_features_bpc_list.f32(-1)
+        dev = enc.device
+        B, N = track_2d_pointquerries_bn3.shape[:2]
+        T = self.image_size[0]
+        P, Cc = cfg.tokens, cfg.dim
+        f32 = dict(dtype=torch.float32, device=dev)
+        traj_all = torch.empty(B, N, 2, T, **f32)
+        vis_all = torch.empty(B, N, 1, T, **f32)
+        dep_all = torch.empty(B, N, 1, T, **f32)
+        pf_all = torch.empty(B, N, Cc, **f32)
+        zero_hist = torch.zeros(P, Cc, **f32)  # keys = enc_features[-1] + 0: one key set shared by all tracks
+        for b in range(B):
+            q = track_2d_pointquerries_bn3[b].to(**f32).contiguous()
+            labels = track_2d_pointlabels_bn[b].to(**f32).contiguous()
+            pfeat = (torch.zeros(N, Cc, **f32) if track_2d_promptfeatures_bnc is None
+                     else track_2d_promptfeatures_bnc[b].to(**f32).contiguous())
+            plabel = (torch.zeros(N, **f32) if track_2d_promptfeaturelabels_bn is None
+                      else track_2d_promptfeaturelabels_bn[b].to(**f32).contiguous())
+            w_traj, w_vis, w_dep, new_pfeat = self._window(enc[b].contiguous(), zero_hist, q, labels, pfeat, plabel, False,
+                                                           hist_uniform=True)
+            traj_all[b], vis_all[b, :, 0], dep_all[b, :, 0], pf_all[b] = w_traj, w_vis, w_dep, new_pfeat
+        return {f"{self.task_name}_traj_est_bn2t": traj_all, f"{self.task_name}_vis_est_bn1t": vis_all,
+                f"{self.task_name}_depth_est_bn1t": dep_all, f"{self.task_name}_prompt_features_bnc": pf_all}

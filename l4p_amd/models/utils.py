@@ -47,11 +47,31 @@ def build_model(model_config_path: str, max_queries: Optional[int] = None, preci
 
 
 def prepare_model(model_config_path: str, ckpt_path: Optional[str], max_queries: Optional[int] = None,
-                  precision: str = "16-mixed", accelerator: str = "gpu"):
-    """Same signature as the reference.  ``accelerator`` must be "gpu": there is no CPU path."""
+                  precision: str = "16-mixed", accelerator: str = "gpu", model_cfg=None):
+    """Same signature as the reference (l4p/models/utils.py:15-60).  ``accelerator`` must be "gpu": there is no CPU path.
+    ``ckpt_path``: the reference's Lightning checkpoint ({"state_dict": {916 keys prefixed l4p_model.}}, :52-53), or a
+    packed arena written offline by tools/ckpt_to_arena.py (recognised by its magic; skips the repacking at start-up).
+    ``model_cfg`` (engine extension, keyword only in practice): a non-default geometry, used by the tests' mini model."""
     if accelerator not in ("gpu", "cuda", "auto"):
         raise ValueError("the MI355X engine only runs on the GPU (accelerator='gpu')")
-    model = build_model(model_config_path, max_queries, precision)
+    from ..packing import PackedWeights
+
+    model = build_model(model_config_path, max_queries, precision, model_cfg=model_cfg)
+    if PackedWeights.is_arena_file(ckpt_path):
+        net = model.l4p_model
+        if not torch.cuda.is_available():
+            from .. import _lib
+
+            raise _lib.L4PHipError("no AMD GPU visible: the L4P engine has no CPU path")
+        pw = PackedWeights.load(ckpt_path, torch.device("cuda", torch.cuda.current_device()))
+        want = "bfloat16" if net.engine_dtype == 0 else "float32"
+        have = getattr(pw, "extra", {}).get("dtype")
+        if have != want:
+            raise ValueError(f"{ckpt_path} was packed for {have}, the model was built with precision={precision!r} ({want})")
+        if getattr(pw, "extra", {}).get("geometry") != net.cfg.describe():
+            raise ValueError(f"{ckpt_path} was packed for another model geometry")
+        net.set_weights(pw)
+        return model.eval()
     state_dict = torch.load(ckpt_path, weights_only=True)["state_dict"]
     model.load_state_dict(state_dict)
     return model.eval()

@@ -239,6 +239,49 @@ class PackedWeights:
             pw.t[name].copy_(w)
         return pw
 
+    # ---- offline arena files (tools/ckpt_to_arena.py): the packed form of a checkpoint, ready to upload ----------
+    MAGIC = b"L4PARENA1\n"
+
+    def save(self, path: str, extra: Optional[dict] = None) -> None:
+        """magic | u64 header length | JSON header {layout, meta, extra} | zero padding to 4096 | raw arena bytes."""
+        import json
+
+        names = {torch.float32: "float32", torch.bfloat16: "bfloat16"}
+        hdr = json.dumps({"layout": [[n, list(sh), names[dt], off] for n, sh, dt, off in self.layout], "meta": self.meta,
+                          "nbytes": int(self.arena.numel()), "extra": extra or {}}).encode()
+        with open(path, "wb") as f:
+            f.write(self.MAGIC)
+            f.write(len(hdr).to_bytes(8, "little"))
+            f.write(hdr)
+            f.write(b"\0" * ((-f.tell()) % 4096))
+            f.write(self.arena.cpu().numpy().tobytes())
+
+    @staticmethod
+    def is_arena_file(path: str) -> bool:
+        try:
+            with open(path, "rb") as f:
+                return f.read(len(PackedWeights.MAGIC)) == PackedWeights.MAGIC
+        except OSError:
+            return False
+
+    @staticmethod
+    def load(path: str, device: torch.device) -> "PackedWeights":
+        import json
+
+        with open(path, "rb") as f:
+            if f.read(len(PackedWeights.MAGIC)) != PackedWeights.MAGIC:
+                raise ValueError(f"{path} is not a packed L4P arena (tools/ckpt_to_arena.py writes them)")
+            n = int.from_bytes(f.read(8), "little")
+            hdr = json.loads(f.read(n))
+            data_off = (f.tell() + 4095) // 4096 * 4096
+        dts = {"float32": torch.float32, "bfloat16": torch.bfloat16}
+        layout = [(nm, tuple(sh), dts[dt], off) for nm, sh, dt, off in hdr["layout"]]
+        raw = np.memmap(path, dtype=np.uint8, mode="r", offset=data_off, shape=(hdr["nbytes"],))
+        arena = torch.from_numpy(np.array(raw)).to(device)  # (one host copy: the map is read-only)
+        pw = PackedWeights(layout, arena, hdr["meta"])
+        pw.extra = hdr.get("extra", {})
+        return pw
+
     @staticmethod
     def empty_like_layout(layout, nbytes: int, device: torch.device, meta: dict) -> "PackedWeights":
         """Receiver side of the weight broadcast: same layout, uninitialised arena."""

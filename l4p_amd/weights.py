@@ -61,6 +61,11 @@ class ModelCfg:
     def grid(self) -> Tuple[int, int, int]:
         return (self.frames // self.patch[0], self.img // self.patch[1], self.img // self.patch[2])
 
+    def describe(self) -> str:
+        """One-line identity of the geometry (stamped into packed arena files, tools/ckpt_to_arena.py)."""
+        return (f"dim{self.dim}-depth{self.depth}-heads{self.heads}-mlp{self.mlp_hidden}-hooks{'.'.join(map(str, self.hooks))}-"
+                f"f{self.frames}-img{self.img}-p{'x'.join(map(str, self.patch))}-sam{self.sam_depth}.{self.sam_heads}.{self.sam_mlp}")
+
     @staticmethod
     def full() -> "ModelCfg":
         return ModelCfg()

@@ -450,6 +450,7 @@ class OracleModel:
         self.use_intrinsics = use_intrinsics
         self.max_queries = max_queries
         self.seam = seam  # how the multi-window joint alignment draws its samples (oracle/joint_oracle.py)
+        self.always_use_windowed_version = True  # configs/model.yaml:19; False: a 16-frame clip takes forward_single_window
         self.seam_log: list = []
         # actpost / fusion scale factors: dense_heads.py:30-31 and :269-271
         self._actpost = lambda t: ((1, 0, 0), (1, 0, 0), (0, 0, 0), (-1, -1, -1)) if t == "camray" else ((1, 2, 2), (1, 1, 1), (0, 0, 0), (-1, -1, -1))
@@ -533,11 +534,30 @@ class OracleModel:
             outs.append(track_windowed(self.sd, self.cfg, last, queries_bn3[:, sl], labels_bn[:, sl], strides, trace=trace))
         return {k: torch.cat([o[k] for o in outs], dim=1) for k in outs[0]}
 
+    def forward_single_window(self, batch: Dict[str, Tensor], tasks: Sequence[str]) -> Dict[str, Tensor]:
+        """L4P_VideoMAE.forward_single_window l4p_videomae.py:234-254 (always_use_windowed_version=False, T == 16): every
+        head's plain forward on one window; the tracker's is sparse_heads.py:497-600 — raw last feature as keys (no
+        history term), the caller's labels, zero prompt features, no validity masking."""
+        cfg = self.cfg
+        feats = encoder_forward(self.sd, batch["rgb_b3thw"], cfg)
+        out: Dict[str, Tensor] = {}
+        for task in tasks:
+            if task == "track_2d":
+                o = track_single_window(self.sd, cfg, feats[-1], batch["track_2d_pointquerries_bn3"][0],
+                                        batch["track_2d_pointlabels_bn"][0], None, None)
+                out.update({"track_2d_traj_est_bn2t": o["traj"][None], "track_2d_vis_est_bn1t": o["vis"][None],
+                            "track_2d_depth_est_bn1t": o["depth"][None], "track_2d_prompt_features_bnc": o["prompt_features"][None]})
+            else:
+                out.update(self.dense_single(task, feats, batch["intrinsics_b44t"]))
+        return out
+
     def forward(self, batch: Dict[str, Tensor], tasks: Sequence[str], trace=None) -> Dict[str, Tensor]:
         cfg = self.cfg
         rgb = batch["rgb_b3thw"]
         B, _, T, H, W = rgb.shape
         assert H == cfg.img and W == cfg.img
+        if not self.always_use_windowed_version and T == cfg.frames:
+            return self.forward_single_window(batch, tasks)
         assert T % 8 == 0
         strides = list(range(0, T - cfg.frames + 1, 8))
         feats2d = [encoder_forward(self.sd, rgb[:, :, s:s + cfg.frames], cfg) for s in strides]

@@ -59,3 +59,11 @@ def synthetic_video(seed: int, T: int, H: int, W: int):
     v = 127 + 90 * np.sin(0.07 * x + 0.3 * t + c) * np.cos(0.05 * y - 0.2 * t) + 40 * (((x // 8 + y // 8 + t) % 2) - 0.5)
     v = v + rng.normal(0, 12, size=(T, H, W, 3))
     return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def single_window_batch():
+    """One 16-frame clip for the NON-windowed entry (always_use_windowed_version=False): queries at mixed times and point
+    labels 0 / 1 / 2 given by the caller (the single-window forward must use them as they are)."""
+    b = make_batch(16, 6)
+    b["track_2d_pointlabels_bn"] = torch.tensor([[1.0, 0.0, 2.0, 1.0, 2.0, 0.0]])
+    return b

@@ -66,3 +66,74 @@ def test_full_size_goldens_are_present_and_pinned():
     assert rep.get("tracker_state_windows", 0) >= 1
     g = np.load(os.path.join(GOLD, "full_T16_all.npz"))
     assert "depth_est_b1thw" in g.files and "feat36" in g.files
+
+
+def test_joint_oracle_matches_reference_flow_golden(mini):
+    """Rows a11 / f1: the 3-window joint depth + camera flow.  tests/golden/mini_T32_joint.npz was produced by the reference's
+    own joint_windowed_estimation with its two random draws replaced by the fixed stand-ins of oracle/joint_oracle.py
+    (tools/gen_golden_joint.py); the oracle must reproduce the stitched outputs, the per-seam thresholds (exact q98) and
+    the per-seam similarity transforms."""
+    import json
+
+    cfg, sd = mini
+    gold = np.load(os.path.join(GOLD, "mini_T32_joint.npz"))
+    batch = make_batch(32, 4)
+    om = OracleModel(sd, cfg, use_intrinsics=True, seam="fixed")
+    with torch.no_grad():
+        out = om.forward(batch, ["depth", "camray"])
+    for k in ("depth_est_b1thw", "traj3d_est_b16t", "traj3d_intrinsics_est_b16t"):
+        _cmp(k, out[k], gold[k])
+    assert len(om.seam_log) == 2
+    for i, s in enumerate(om.seam_log):
+        assert abs(s["thr"] - float(gold[f"seam{i}_thr"])) <= 1e-6 * abs(s["thr"])
+        assert np.abs(s["T"] - gold[f"seam{i}_T"]).max() <= 1e-5 * np.abs(gold[f"seam{i}_T"]).max()
+        assert abs(s["s"] - float(gold[f"seam{i}_s"])) <= 1e-6 * s["s"]
+    rep = json.load(open(os.path.join(GOLD, "oracle_vs_reference_joint.json")))
+    assert max(rep.values()) <= 1e-4  # function-level pins (generate_point_map, apply) recorded at generation time
+
+
+def test_joint_oracle_pieces():
+    from oracle import joint_oracle as jo
+
+    # Umeyama recovers a known similarity exactly, incl. a reflection-prone (planar-ish) configuration
+    g = np.random.default_rng(0)
+    src = g.normal(size=(200, 3))
+    src[:, 2] *= 1e-3
+    A = np.linalg.qr(g.normal(size=(3, 3)))[0]
+    R = A if np.linalg.det(A) > 0 else -A
+    dst = 2.5 * src @ R.T + np.array([0.3, -1.0, 4.0])
+    rel = jo.umeyama(src, dst)
+    assert abs(rel["s"] - 2.5) < 1e-9 and np.abs(rel["T"][:3, :3] / rel["s"] - R).max() < 1e-6
+    # the fixed permutation is a permutation; the engine's pixel subset takes one pixel per stride cell
+    for n in (150528, 1000, 7919 * 2):
+        assert np.array_equal(np.sort(jo.fixed_permutation(n)), np.arange(n))
+    sub = jo.engine_pixel_subset(224, 224, 10)
+    assert np.array_equal(sub // 10, np.arange(224 * 224 // 10))
+    # hash_u32 known answers (uint32 arithmetic of csrc/umeyama.hip:hash_u32, computed by hand in Python ints)
+    def h(x):
+        x = (x * 747796405 + 2891336453) & 0xFFFFFFFF
+        w = (((x >> ((x >> 28) + 4)) ^ x) * 277803737) & 0xFFFFFFFF
+        return (w >> 22) ^ w
+    for x in (0, 1, 12345, 0xFFFFFFFF, jo.ENGINE_SEED):
+        assert int(jo.hash_u32(np.array([x]))[0]) == h(x)
+    # engine_ransac finds the similarity among 30 % gross outliers
+    dst2 = dst.copy()
+    dst2[:60] += g.normal(size=(60, 3)) * 5
+    rel2, inl = jo.engine_ransac(src.astype(np.float32), dst2.astype(np.float32), thr=1e-3)
+    assert inl.sum() >= 135 and abs(rel2["s"] - 2.5) < 1e-3
+
+
+def test_oracle_single_window_entry_matches_reference_golden(mini):
+    """always_use_windowed_version=False, T == 16: forward_single_window (l4p_videomae.py:234-254); the tracker's plain
+    forward (sparse_heads.py:497-600) uses the raw last feature, the caller's labels and returns unmasked outputs."""
+    from tests.golden_utils import single_window_batch
+
+    cfg, sd = mini
+    gold = np.load(os.path.join(GOLD, "mini_T16_single_window.npz"))
+    om = OracleModel(sd, cfg, use_intrinsics=True)
+    om.always_use_windowed_version = False
+    with torch.no_grad():
+        out = om.forward(single_window_batch(), ["track_2d", "depth", "flow_2d_backward"])
+    assert sorted(out.keys()) == sorted(gold.files)
+    for k in gold.files:
+        _cmp(k, out[k], gold[k])

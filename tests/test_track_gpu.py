@@ -151,3 +151,38 @@ def test_query_chunks_of_max_queries_match_one_pass(dev, mini):
         for k in keys:
             assert part[k].shape == whole[k].shape
             assert (part[k] - whole[k]).abs().max() <= 1e-4 * whole[k].abs().max(), (mq, k, float((part[k] - whole[k]).abs().max()))
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_single_window_entry_vs_reference_golden(dev, mini, precision):
+    """L4P_VideoMAE(always_use_windowed_version=False) on a 16-frame clip -> forward_single_window -> the tracker's plain
+    forward (sparse_heads.py:497-600): no history term, the caller's labels (0 / 1 / 2 mixed), unmasked outputs and the
+    prompt features; forward_windowed_core(time_strides=None) is the same call (:223-227)."""
+    from tests.golden_utils import single_window_batch
+
+    cfg, sd = mini
+    model = build(cfg, sd, precision)
+    model.l4p_model.always_use_windowed_version = False
+    batch = single_window_batch()
+    gold = np.load(os.path.join(GOLD, "mini_T16_single_window.npz"))
+    tasks = ["track_2d", "depth", "flow_2d_backward"]
+    with torch.no_grad():
+        out = model.forward({k: v.clone() for k, v in batch.items()}, tasks)
+        head = model.l4p_model.task_heads["track_2d"]
+        again = head.forward_windowed_core([out["enc_features_bpc_list"]], batch["track_2d_pointquerries_bn3"].cuda(),
+                                           batch["track_2d_pointlabels_bn"].cuda(), None)
+    torch.cuda.synchronize()
+    from tests.golden_utils import sample_indices
+
+    for k in gold.files:
+        y = out[k].float().cpu().reshape(-1)
+        g = torch.from_numpy(gold[k]).reshape(-1)
+        s = y[sample_indices(y.numel())] if y.numel() > 4096 else y
+        if precision == "32-true":
+            assert (s - g).abs().max() <= 1e-3 * g.abs().max(), (k, float((s - g).abs().max() / g.abs().max()))
+        else:
+            assert rel_l2(s, g) <= 5e-2, (k, rel_l2(s, g))
+    for k in ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t", "track_2d_prompt_features_bnc"):
+        assert torch.equal(out[k], again[k]), k
+    # unmasked: frames before the query time carry estimates, not the -10 / 0 fill of the sliding tracker
+    assert float(out["track_2d_vis_est_bn1t"].min()) > -9.0

@@ -1,0 +1,59 @@
+"""tests/golden/mini_T16_single_window.npz from the REAL reference (runs only where /root/reference exists):
+L4P_VideoMAE(always_use_windowed_version=False).forward on one 16-frame clip -> forward_single_window
+(l4p_videomae.py:234-254) -> every head's plain forward; for the tracker that is VideoMAETrack2DSamHead.forward
+(sparse_heads.py:497-600): raw last feature (no history / mask-token term), the caller's point labels (here a mix of
+0 / 1 / 2), zero prompt features, unmasked outputs.  The oracle's forward_single_window must agree (<= 1e-4).
+
+  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_single_window.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from l4p_amd.weights import ModelCfg, seeded_state_dict
+from tests.golden_utils import make_batch, sample_indices, single_window_batch
+from tools.gen_golden import build_reference, install_stubs, rel_err
+
+
+def main():
+    install_stubs()
+    torch.set_num_threads(os.cpu_count() or 8)
+    cfg = ModelCfg.mini()
+    sd = seeded_state_dict(cfg)
+    model = build_reference(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.always_use_windowed_version = False
+    batch = single_window_batch()
+    tasks = ["track_2d", "depth", "flow_2d_backward"]
+    with torch.no_grad():
+        out = model.forward({k: v.clone() for k, v in batch.items()}, tasks)
+    from oracle.l4p_oracle import OracleModel
+
+    om = OracleModel(sd, cfg, use_intrinsics=True)
+    om.always_use_windowed_version = False
+    with torch.no_grad():
+        oout = om.forward(batch, tasks)
+    npz = {}
+    for k, v in out.items():
+        if not torch.is_tensor(v) or k.endswith("_bnpc"):
+            continue
+        e = rel_err(oout[k], v)
+        assert e <= 1e-4, (k, e)
+        v = v.detach().float()
+        npz[k] = v.reshape(-1)[sample_indices(v.numel())].numpy() if v.numel() > 4096 else v.numpy()
+        print(k, tuple(v.shape), f"oracle rel err {e:.2e}")
+    assert "track_2d_prompt_features_bnc" in npz and "track_2d_vis_est_bn1t" in npz
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "mini_T16_single_window.npz"), **npz)
+
+
+if __name__ == "__main__":
+    main()
