@@ -41,9 +41,13 @@ PEAK_BF16_MFMA = 2.5e15  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 ALL_TASKS = ["flow_2d_backward", "track_2d", "depth", "dyn_mask", "camray"]
 
 
-def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int):
-    """FLOPs (2*MAC, padding excluded) of one 16-frame window per kernel class, from the model graph
-    (SURVEY.md §2.1 / BASELINE.md §4)."""
+TRACK_FLOPS_PER_QUERY_WINDOW = 73.81e9  # reference graph, SURVEY.md §2.1 / BASELINE.md §4 (incl. the history projection)
+
+
+def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int, n_windows: int = 1):
+    """FLOPs (2*MAC, padding excluded) of ONE 16-frame window per kernel class, from the model graph
+    (SURVEY.md §2.1 / BASELINE.md §4), counting what the algorithm needs — work the reference executes and then discards
+    is not credited (n_windows = windows of the clip the tracker recursion runs over; the per-window average is returned)."""
     S, D, Hd, H, dh = cfg.tokens, cfg.dim, cfg.mlp_hidden, cfg.heads, cfg.head_dim
     kraw = cfg.in_chans * cfg.patch[0] * cfg.patch[1] * cfg.patch[2]
     dense = [t for t in tasks if t in cfg.dense_tasks]
@@ -83,13 +87,21 @@ def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int):
         osz = (16, 16, 16) if t == "camray" else (cfg.frames, cfg.img, cfg.img)
         vo = osz[0] * osz[1] * osz[2]
         conv += 2.0 * vo * 27 * (F_ // 2) * cfg.last_dim
-    # tracker: 73.81 GFLOP per query and window, all but ~1 % of it in projections / up-scaling
-    # ConvTransposes that run through the GEMM kernel
-    # In a first window every track starts from the same keys, so the engine runs the first layer's three image-side
-    # projections (t2i.k, t2i.v, i2t.q: 2*S*D*(D/2) each) once per clip instead of once per track; they are counted once.
-    if "track_2d" in tasks:
+    # tracker: 73.81 GFLOP per query and window in the reference graph, all but ~1 % of it in projections / up-scaling
+    # ConvTransposes that run through the GEMM kernel.  Two corrections, so that only work whose result is USED is credited:
+    #  * processed_video_features_proj (sparse_heads.py:660-663, 2*S*D*D = 8.12 GF per query) feeds the NEXT window's
+    #    memory tokens only, and only its second temporal half survives (sparse_heads.py:406-448): the last (or only)
+    #    window needs none of it, every other window half of it;
+    #  * in a first window every track starts from the same keys, so the first layer's three image-side projections
+    #    (t2i.k, t2i.v, i2t.q: 2*S*D*(D/2) each) are one computation per clip, not one per track.
+    if "track_2d" in tasks and n_queries > 0:
+        hist_full = 2.0 * S * D * D
+        per_qw = TRACK_FLOPS_PER_QUERY_WINDOW - hist_full
         shared = 3 * 2.0 * S * D * (D // 2)
-        gemm += (73.81e9 - shared) * n_queries + shared
+        total = n_windows * per_qw * n_queries                       # every window, every query
+        total += (n_windows - 1) * 0.5 * hist_full * n_queries       # memory tokens for the windows that have a successor
+        total -= shared * (n_queries - 1)                            # first window: shared image-side projections
+        gemm += total / n_windows
     return {"gemm": gemm, "conv3d": conv, "attention": attn}
 
 
@@ -102,15 +114,18 @@ def read_prof(lib):
     return out
 
 
-def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 4):
-    """Oracle (plain PyTorch fp32 port of the reference algorithm) on the host cores, 1 clip, BOUNDED sample:
-    patch embed + ``sample_blocks`` of the ``depth`` identical encoder blocks are timed and the block time is
-    scaled by depth/sample_blocks; the heads are timed in full on the features of that shortened encoder."""
+def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 4, sample_queries: int = 8):
+    """Oracle (plain PyTorch fp32 port of the reference algorithm) on the host cores, 1 clip of the SAME workload, BOUNDED
+    sample: patch embed + ``sample_blocks`` of the ``depth`` identical encoder blocks are timed and the block time is scaled
+    by depth / sample_blocks; the dense heads are timed in full on the features of that shortened encoder; the tracker port
+    is timed on ``sample_queries`` of the clip's queries and scaled by N / sample_queries (tracks are independent: its cost
+    is linear in N)."""
     from oracle import l4p_oracle as orc
 
     threads = min(os.cpu_count() or 1, 64)  # torch CPU ops stop scaling (and regress) far below 256 threads
     torch.set_num_threads(threads)
     rgb = batch_cpu["rgb_b3thw"]
+    dense = [t for t in tasks if t != "track_2d"]
     with torch.no_grad():
         t0 = time.time()
         feats = orc.encoder_forward(sd, rgb, cfg, upto=0)
@@ -123,24 +138,35 @@ def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 4):
         fl = [x] * (cfg.depth + 1)  # same shapes/statistics class as the real hooks; values are irrelevant for timing
         om = orc.OracleModel(sd, cfg, use_intrinsics=True)
         t0 = time.time()
-        for t in tasks:
+        for t in dense:
             om.dense_single(t, fl, batch_cpu["intrinsics_b44t"])
         t_heads = time.time() - t0
-    dt = t_embed + t_blocks * cfg.depth + t_heads
+        t_track, nq, track_note = 0.0, 0, ""
+        if "track_2d" in tasks:
+            q = batch_cpu["track_2d_pointquerries_bn3"]
+            nq = q.shape[1]
+            ns = min(sample_queries, nq)
+            t0 = time.time()
+            orc.track_windowed(sd, cfg, [x], q[:, :ns], batch_cpu["track_2d_pointlabels_bn"][:, :ns], [0])
+            t_track = (time.time() - t0) * nq / ns
+            track_note = f" + tracker {ns}/{nq} queries scaled x{nq / ns:g} = {t_track:.2f}s"
+    dt = t_embed + t_blocks * cfg.depth + t_heads + t_track
     return {"value": round(16.0 / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": (f"1 clip (16x224x224), tasks={'+'.join(tasks)}: oracle (plain PyTorch fp32 port of the reference) on the host CPU; "
                        f"timed patch-embed {t_embed:.2f}s + {sample_blocks}/{cfg.depth} encoder blocks ({t_blocks:.2f}s each, scaled x{cfg.depth}) "
-                       f"+ heads in full {t_heads:.2f}s -> {dt:.1f}s per clip")}
+                       f"+ dense heads in full {t_heads:.2f}s{track_note} -> {dt:.1f}s per clip")}
 
 
-def build_workload(tasks, B, nq, device, rank=0, frames=16, same_data=False):
+def build_workload(tasks, B, nq, device, rank=0, frames=16, same_data=False, use_intrinsics=None):
     """Model (name-seeded random weights, packed on rank 0 and broadcast once) + one synthetic batch of B clips."""
     cfg = ModelCfg.full()
     model = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision="bf16")
     net = model.l4p_model
     net.task_heads = torch.nn.ModuleDict({t: net.task_heads[t] for t in tasks})
-    if "camray" in tasks:
-        net.task_heads["camray"].use_intrinsics = True
+    if "camray" in tasks and use_intrinsics is not None:
+        # None = configs/model.yaml as shipped (use_intrinsics: false -> the first window estimates K from its ray map,
+        # rays_to_intrinsics kernel); True = the Dycheck mode of demo.py:215 (given intrinsics)
+        net.task_heads["camray"].use_intrinsics = bool(use_intrinsics)
     sd, pw = None, None
     if rank == 0:
         sd = seeded_state_dict(cfg, tasks=tasks)
@@ -237,7 +263,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5", "prep"])
     ap.add_argument("--frames", type=int, default=256, help="c5: length of the long video")
-    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default: 1 for c2, 4 for c3)")
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default: 1 for c2; c3: 4 on one GPU = configs[2], "
+                                                         "8 per GPU on N > 1 GPUs = configs[3]: batch 64 over 8 GPUs)")
+    ap.add_argument("--use-intrinsics", action="store_true", help="camray head with given intrinsics (demo.py:215) instead of "
+                                                                  "the shipped use_intrinsics=false (K estimated from the ray map)")
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--group", type=int, default=4, help="c5: windows batched through encoder + dense decoders per launch group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,10 +284,11 @@ def main():
 
     cfg = ModelCfg.full()
     tasks = ["depth"] if args.workload == "c2" else list(ALL_TASKS)
-    B = args.batch or (4 if args.workload == "c3" else 1)
+    B = args.batch or ((4 if world == 1 else 8) if args.workload == "c3" else 1)
     c5 = args.workload == "c5"  # configs[4]: ONE long video, its windows sharded over the ranks (strong scaling)
 
-    model, batch, sd = build_workload(tasks, B, args.queries, device, rank, frames=args.frames if c5 else 16, same_data=c5)
+    model, batch, sd = build_workload(tasks, B, args.queries, device, rank, frames=args.frames if c5 else 16, same_data=c5,
+                                      use_intrinsics=True if args.use_intrinsics else None)
     if c5:
         model.l4p_model.always_use_windowed_version = True
 
@@ -314,13 +344,17 @@ def main():
         "dtype": "bf16", "data": "synthetic (randn clips, name-seeded random weights of the VideoMAE-v2-giant + DPT geometry)",
         "config": {"workload": ("configs[1]: single MI355X, depth head only, bf16, batch=1 16-frame 224x224 clip" if args.workload == "c2"
                                  else f"configs[4]: one {args.frames}-frame video -> {(args.frames - 16) // 8 + 1} overlapping 16-frame windows sharded over the ranks, all heads, on-GPU pose / window alignment, {args.queries} track queries" if c5
-                                 else f"configs[2]: all heads (depth+flow+track2d/3d+motion-seg+pose), bf16, batch={B} clips, {args.queries} track queries"),
-                   "clips_per_gpu_per_step": B, "tasks": tasks, "parallelism": (f"windows sharded over {world} rank(s); one all-gather of the decoded windows, stitching replicated, track queries sharded" if c5
+                                 else (f"configs[2]: single MI355X, all heads (depth+flow+track2d/3d+motion-seg+pose), bf16, batch={B} clips, {args.queries} track queries per clip" if world == 1
+                                       else f"configs[3]: {world}xMI355X data-parallel over clips, all heads, bf16, batch={world * B} clips ({B} per GPU), {args.queries} track queries per clip, RCCL weight broadcast")),
+                   "clips_per_gpu_per_step": B, "tasks": tasks,
+                   "camray_use_intrinsics": bool(args.use_intrinsics) if "camray" in tasks else None,
+                   "parallelism": (f"windows sharded over {world} rank(s); one all-gather of the decoded windows, stitching replicated, track queries sharded" if c5
                                    else f"dp{world} (clips sharded, no collective in the step)")},
     }
     if not args.no_prof:
         prof = read_prof(lib)
-        fl = algorithmic_flops(cfg, tasks, args.queries if "track_2d" in tasks else 0)
+        nwin_total = (args.frames - 16) // 8 + 1 if c5 else 1
+        fl = algorithmic_flops(cfg, tasks, args.queries if "track_2d" in tasks else 0, n_windows=nwin_total)
         nwin_rank0 = 1
         if c5:  # rank 0's share: its chunk of windows (the tracker term is approximate: queries, not windows, are sharded)
             from l4p_amd.parallel import window_chunks
@@ -346,8 +380,11 @@ def main():
         # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate passes); PMC cannot be collected from inside this
         # process, so the figure is the one measured on the same command and is only attached to the workload it was taken on
         traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_c3_hbm_traffic.json")
-        if args.workload == "c3" and B == 4 and os.path.exists(tpath):
+        import glob
+
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_hbm_traffic.json")))
+        tpath = cands[-1] if cands else ""
+        if args.workload == "c3" and B == 4 and tpath:
             with open(tpath) as f:
                 traffic = {k: v["hbm_total"] for k, v in json.load(f)["per_class_bytes_per_launch"].items()}
 
@@ -355,7 +392,7 @@ def main():
             a = classes[k]["tflops"]
             return {"kernel": kern[k], "bound": "mfma", "achieved": a, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
                     "frac": round(a / (PEAK_BF16_MFMA / 1e12), 4), "traffic": traffic.get(k),
-                    "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c3_hbm_traffic.md)",
+                    "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this command: profiles/{os.path.basename(tpath)})",
                     "method": "algorithmic FLOPs / HIP-event-bracketed kernel time, second pass of the same K steps",
                     "avg_launch_us": classes[k]["avg_launch_us"], "launches_per_step": classes[k]["launches_per_step"],
                     "algorithmic_flops_per_step": fl[k] * B * nwin_rank0}
@@ -366,9 +403,10 @@ def main():
         res["kernel_classes"] = classes
     if world == 1 and not args.no_cpu_baseline:
         bc = {k: (v[:1].cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
-        cpu_tasks = [t for t in tasks if t != "track_2d"]  # dense heads only: the tracker port is timed in tests, not here
+        if c5:  # one 16-frame window of the long video (the CPU port is timed per clip of 16 frames)
+            bc = {k: (v[..., :16, :, :] if k == "rgb_b3thw" else v[..., :16] if k == "intrinsics_b44t" else v) for k, v in bc.items()}
         with contextlib.redirect_stdout(sys.stderr):
-            res["cpu_baseline"] = cpu_baseline(sd, cfg, cpu_tasks, bc)
+            res["cpu_baseline"] = cpu_baseline(sd, cfg, tasks, bc)
     print(json.dumps(res))
 
 
