@@ -124,6 +124,11 @@ typedef struct l4p_gemm_desc {
      * l4p_mask_gather sums a tap's chunks and scatters the taps to the up-scaled grid. */
     const float* hyper;
     int hyper_rows;
+    /* L4P_EPI_QKV: the q columns (n < H*Dp) are multiplied by q_scale (after the bias, before rounding to T) — the
+     * reference's `q = q * self.scale` (modeling_finetune.py:180) folded into the projection; the engine passes
+     * head_dim^-0.5 * log2(e) so that the scores leave the attention MFMA in the exp2 domain (see l4p_attention).
+     * 0 is treated as 1. */
+    float q_scale;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
@@ -137,7 +142,11 @@ int l4p_layernorm(l4p_stream stream, int dtype, const float* x, const float* gam
 
 /* Fused softmax(q k^T * scale) v for the encoder (modeling_finetune.py:180-186).
  * q: [B*S][H*96] T, kt: tiled K, vt: [B][H][96][S] T (all three written by L4P_EPI_QKV), out: [B*S][H*Dh] T.
- * Dh in {88, 64} (head dim < 96: one padding row of V^T carries the softmax denominator). */
+ * Dh in {88, 64} (head dim < 96: the padding carries the softmax denominator (V^T) and the running maximum (Q, K)).
+ * scale > 0: q is the plain projection; the bf16 kernel folds scale * log2(e) into its Q fragments (a second bf16
+ * rounding of q).  scale == 0 (L4P_ATTN_PRESCALED): q was already multiplied by head_dim^-0.5 * log2(e) when it was
+ * produced (l4p_gemm_desc.q_scale) and the weights are exp2(q k^T) — the form the engine uses: one rounding of q. */
+#define L4P_ATTN_PRESCALED 0.0f
 int l4p_attention(l4p_stream stream, int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S,
                   int H, int Dh, float scale);
 

@@ -300,9 +300,10 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
         p.S = S;
         p.H = H;
         p.Dp = Dp;
+        p.q_scale = scale * 1.4426950408889634f;  // q leaves the projection in the exp2 domain: one rounding of q * scale
         rc = launch_gemm(dt, 0, p, stream);
         if (rc) return rc;
-        rc = launch_attention(dt, w.qk, w.qk + (size_t)M * H * Dp * es, w.vt, w.ao, B, S, H, Dh, scale, stream);
+        rc = launch_attention(dt, w.qk, w.qk + (size_t)M * H * Dp * es, w.vt, w.ao, B, S, H, Dh, L4P_ATTN_PRESCALED, stream);
         if (rc) return rc;
         memset(&p, 0, sizeof(p));
         p.A = w.ao;

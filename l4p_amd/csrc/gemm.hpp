@@ -263,6 +263,10 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
 #pragma unroll
                 for (int q = 0; q < 8; ++q) vv[q] = fmaxf(vv[q], 0.0f);
             }
+            if (p.epi == EPI_QKV && n < p.H * p.Dp && p.q_scale != 0.f) {  // q = q * scale (modeling_finetune.py:180)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] *= p.q_scale;
+            }
             const long long off = rowoff + coff[g8 / 8];  // element offset of the 8 outputs
             if (res32) {
 #pragma unroll

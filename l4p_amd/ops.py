@@ -134,8 +134,10 @@ def k_tile_order(k: torch.Tensor) -> torch.Tensor:
     return g.reshape(-1)
 
 
-def qkv_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, S: int, H: int):
-    """Fused qkv projection writing the attention layouts: q [B*S, H*96], kt (tile order, flat), vt [B,H,96,S]."""
+def qkv_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, S: int, H: int, q_scale: float = 0.0):
+    """Fused qkv projection writing the attention layouts: q [B*S, H*96], kt (tile order, flat), vt [B,H,96,S].
+    ``q_scale`` != 0: the q columns are multiplied by it before rounding (the engine passes head_dim^-0.5 * log2 e and
+    then calls attention(..., scale=0.0): pre-scaled)."""
     dtype = code_of(a.dtype)
     M, K = a.shape
     assert M == B * S and w.shape[0] >= 3 * H * DP and S % kv_block(a.dtype) == 0
@@ -150,6 +152,7 @@ def qkv_gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, S: in
     d.epi = EPI_QKV
     d.k_tiled = _p(kt)
     d.vt, d.S, d.H, d.Dp = _p(vt), S, H, DP
+    d.q_scale = q_scale
     lib = _lib.load()
     _lib.check(lib.l4p_gemm(_stream(), dtype, C.byref(d)), "l4p_gemm(qkv)")
     return q, kt, vt

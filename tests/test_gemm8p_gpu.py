@@ -156,18 +156,19 @@ def test_gemm8p_qkv_epilogue_and_batch4_attention(dev):
     bp[2, :, :Dh] = vb.view(H, Dh)
     w, w_ref = as_mode(wp.view(3 * H * ops.DP, Cc), MODE)
     with prof_tags() as p:
-        q, kt, vt = ops.qkv_gemm(x, ops.pad_rows(w, 256), bp.view(-1).cuda(), B, S, H)
+        qs = Dh ** -0.5 * 1.4426950408889634  # the engine's form: q leaves the projection in the exp2 domain
+        q, kt, vt = ops.qkv_gemm(x, ops.pad_rows(w, 256), bp.view(-1).cuda(), B, S, H, q_scale=qs)
     p.assert_8p()
     full = (x_ref @ w_ref.t() + bp.view(-1)).view(B, S, 3, H, ops.DP)
-    check(q.view(B, S, H, ops.DP), full[:, :, 0], MODE, True)
+    check(q.view(B, S, H, ops.DP), full[:, :, 0] * qs, MODE, True)
     check(vt, full[:, :, 2].permute(0, 2, 3, 1), MODE, True)
     check(kt, ops.k_tile_order(full[:, :, 1].contiguous().to(torch.bfloat16)).float(), MODE, True)
     q_ref = q.float().cpu().view(B, S, H, ops.DP).permute(0, 2, 1, 3)
     k_ref = full[:, :, 1].to(torch.bfloat16).float().permute(0, 2, 1, 3)
     v_ref = vt.float().cpu().permute(0, 1, 3, 2)
-    out = ops.attention(q, kt, vt, Dh)
+    out = ops.attention(q, kt, vt, Dh, scale=0.0)
     for b in range(B):  # one clip at a time: the score matrices of a clip are 16 x 2048 x 2048 floats
-        attn = torch.softmax((q_ref[b] * Dh ** -0.5) @ k_ref[b].transpose(-2, -1), dim=-1)
+        attn = torch.softmax((q_ref[b] * 0.6931471805599453) @ k_ref[b].transpose(-2, -1), dim=-1)
         ref = (attn @ v_ref[b])[..., :Dh].transpose(0, 1).reshape(S, Cc)
         check(out[b * S:(b + 1) * S], ref, MODE, True)
 

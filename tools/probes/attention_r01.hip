@@ -33,9 +33,6 @@
 __device__ __attribute__((aligned(16))) static const unsigned short g_ones_bf16[8] = {0x3F80, 0x3F80, 0x3F80, 0x3F80,
                                                                                          0x3F80, 0x3F80, 0x3F80, 0x3F80};
 __device__ __attribute__((aligned(16))) static const float g_ones_f32[4] = {1.f, 1.f, 1.f, 1.f};
-// K-tile chunk holding head dims DH .. DH+7 (all padding) in the deferred-maximum form: dims DH and DH+1 read as 1.0, so
-// the two bf16 halves of -m that sit in the same dims of Q are added to every score by the QK^T MFMA itself
-__device__ __attribute__((aligned(16))) static const unsigned short g_kone_bf16[8] = {0x3F80, 0x3F80, 0, 0, 0, 0, 0, 0};
 
 // SPLIT = 2: the workgroup has 8 waves; waves 0-3 walk the even KV blocks and waves 4-7 the odd ones for the
 // SAME 128 query rows, and the two partial (m, O, denominator) states are merged through LDS at the end.
@@ -69,8 +66,6 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     static_assert(KBYTES % 4096 == 0 && VBYTES % 4096 == 0, "tile = whole LDS-DMA passes of 256 lanes");
     static_assert(DH < DP && DH % 4 == 0, "one padding row carries the denominator");
     constexpr int K_IT = KBYTES / 4096, V_IT = VBYTES / 4096;
-    // DEFER: the hand-scheduled body keeps a deferred running maximum (see `step`)
-    constexpr bool DEFER = HS;
     constexpr int DT_L = DH / 32, I_L = DH % 32;                       // where the denominator row lands in O^T
     constexpr int HI_L = (I_L >> 2) & 1, R_L = (I_L & 3) + 4 * (I_L >> 3);
 
@@ -125,20 +120,11 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         vsrc[i] = (const char*)(vt + (((long long)b * H + h) * DP + d) * S) + vchunk * 16;  // + kb*128
     }
     const char* ones = ES == 2 ? (const char*)g_ones_bf16 : (const char*)g_ones_f32;
-    // chunk c = tid + 256 i of a K tile is (k-step c / (2 KVB), key (c % (2 KVB)) / 2, half (c & 1) ^ ((key >> 3) & 1))
-    bool kpad[K_IT];
-#pragma unroll
-    for (int i = 0; i < K_IT; ++i) {
-        const int c = tid + 256 * i, key = (c % (2 * KVB)) >> 1;
-        kpad[i] = DEFER && (c / (2 * KVB)) * 16 + (((c & 1) ^ ((key >> 3) & 1)) << 3) == DH;
-    }
-    const char* kone = (const char*)g_kone_bf16;
     auto issue_k = [&](int kb, int buf) {
 #pragma unroll
-        for (int i = 0; i < K_IT; ++i) {
-            const char* src = kpad[i] ? kone : kbase + (long long)kb * KBYTES + i * 4096;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ks + buf * KBYTES + (wave * 64 + i * 256) * 16), 16, 0, 0);
-        }
+        for (int i = 0; i < K_IT; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (long long)kb * KBYTES + i * 4096),
+                                             (lptr_t)(Ks + buf * KBYTES + (wave * 64 + i * 256) * 16), 16, 0, 0);
     };
     auto issue_v = [&](int kb, int buf) {
 #pragma unroll
@@ -148,29 +134,12 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         }
     };
 
-    // HS: the softmax scale (times log2 e) is folded into Q once, here (the reference scales q before q k^T as well,
-    // modeling_finetune.py:180), so the scores come out of the MFMA in the exp2 domain
-    if constexpr (DEFER) {
-        if (c_scale != 1.0f) {  // (pre-scaled q: nothing to do, and no second rounding)
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = from_f32<T>(to_f32<T>(qf[ks][e]) * c_scale);
-        }
-    }
-
     f32x16 o[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    // DEFER: scores are kept RELATIVE to the running reference m_run.  -m_run rides in the head-dim padding: Q carries it
-    // (as two bf16 halves, 16 mantissa bits) in dims DH, DH+1, where the K tile reads 1.0 (g_kone_bf16, substituted by the
-    // tile DMA below), so S = K Q^T comes out of the MFMA as score - m_run and P = exp2(S) needs no subtraction.  m_run
-    // starts at 0 and is set by the first block.
-    float m_run = DEFER ? 0.f : -INFINITY;
-    constexpr int KS_P = DH / 16, HI_P = (DH / 8) & 1;  // k-step / lane half whose Q fragment holds dims DH .. DH+7
-    static_assert(DH % 8 == 0, "the first padding chunk starts at DH");
+    float m_run = -INFINITY;
 
     // K tile row read by this lane for score-tile row i = lq: swap bits 2 and 3
     const int krow = (lq & ~12) | ((lq & 4) << 1) | ((lq & 8) >> 1);
@@ -227,13 +196,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
 
     // one pipeline step; HAS_NEXT is a compile-time flag so that the steady-state body is ONE basic block in which the
     // scheduler is free to interleave the two MFMA batches with the VALU work (the last block is peeled)
-    // HS, deferred maximum: the reference m_run only has to keep the exponents in range (P is rounded to bf16, whose
-    // relative precision does not depend on magnitude, and the denominator is accumulated from the same rounded P), so it
-    // is moved — O rescaled, Q's padding dims rewritten, this block's scores shifted in place — only when some row's block
-    // maximum exceeds it by more than RESCALE_THR (P <= 2^THR otherwise), and always at the first block.  The block body
-    // has no multiply-add in front of the exponential.
-    constexpr float RESCALE_THR = 8.f;
-    auto step = [&](int it, auto has_next, f32x16* s_cur, f32x16* s_nxt) __attribute__((always_inline)) {
+    auto step = [&](int it, auto has_next, f32x16* s_cur, f32x16* s_nxt) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         const int cur = it & 1;
 #ifndef ATTN_DBG_NOLOAD  // (tools/probes/attn_variants.hip: compute-only timing)
@@ -247,42 +210,15 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         __syncthreads();
         return;
 #endif
-        if constexpr (DEFER) {
-            // (mx = row maximum of s_cur, relative to m_run)  The rare side path: move the reference, rescale O, rewrite
-            // -m_run in Q's padding dims and shift this block's scores in place; the block body below is the same either way.
-            if (it == 0 || __any(mx > RESCALE_THR)) {
-                const float want = m_run + (it == 0 ? mx : fmaxf(mx, 0.f));
-                const T m_hi = from_f32<T>(want), m_lo = from_f32<T>(want - to_f32<T>(m_hi));
-                const float m_new = to_f32<T>(m_hi) + to_f32<T>(m_lo);  // the reference the MFMA will really subtract
-                const float delta = m_new - m_run;
-                if (it != 0) {  // (at the first block O is still zero, and exp2(-delta) may overflow for very negative scores)
-                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+        // ---- running max / rescale (lane-local; skipped wave-uniformly when no row maximum moved) -----
+        const float m_new = fmaxf(m_run, mx * c_scale);
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
-                    for (int dt = 0; dt < NDT; ++dt)
+            for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-                }
-                m_run = m_new;
-                if (hi == HI_P) {
-                    qf[KS_P][0] = -m_hi;
-                    qf[KS_P][1] = -m_lo;
-                }
-#pragma unroll
-                for (int t = 0; t < NST; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s_cur[t][r] -= delta;
-            }
-        } else {
-            // ---- running max / rescale (lane-local; skipped wave-uniformly when no row maximum moved) -----
-            const float m_new = fmaxf(m_run, mx * c_scale);
-            if (__any(m_new > m_run)) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-                m_run = m_new;
-            }
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            m_run = m_new;
         }
         if constexpr (HS) {
             // Hand-scheduled block body.  hipcc emits lgkmcnt(0) for every LDS wait of its own while an LDS-DMA is in
@@ -308,12 +244,6 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
             u32x4 fr[24];
             auto rd = [&fr, &ka, &va](auto i_) {  // (explicit captures: asm operands do not trigger implicit capture)
                 constexpr int r = R0 + decltype(i_)::value;
-#ifdef ATTN_DBG_NOLDSREAD
-                if constexpr (r >= 2) {
-                    asm volatile("" : "=v"(fr[r]));
-                    return;
-                }
-#endif
                 if constexpr (r < 12)
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[r]) : "v"(ka[r % NST]), "n"((r / NST) * (KVB * 2 * 16)) : "memory");
                 else
@@ -321,45 +251,29 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
             };
             const f32x2 c2 = {c_scale, c_scale}, m2 = {-m_run, -m_run};
             frag_t pf[NST][2];
-#ifdef ATTN_DBG_NOSOFTMAX  // (tools/probes: ablation timing, wrong results)
-#pragma unroll
-            for (int t = 0; t < NST; ++t)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(pf[t][j]));
-#endif
             auto exp_pair = [&](auto p_) {  // P elements 2p, 2p+1 of the 32 scores of this lane
                 constexpr int e = decltype(p_)::value * 2, t = e / 16, r = e % 16, j = r / 8, ee = r % 8;
-#ifdef ATTN_DBG_NOSOFTMAX
-                return;
-#endif
-                f32x2 x = {s_cur[t][r], s_cur[t][r + 1]};
-                if constexpr (!DEFER) x = __builtin_elementwise_fma(x, c2, m2);
-#ifdef ATTN_DBG_NOEXP  // (tools/probes: ablation timing, wrong results)
-                pf[t][j][ee] = from_f32<T>(x[0]);
-                pf[t][j][ee + 1] = from_f32<T>(x[1]);
-#else
+                const f32x2 a = {s_cur[t][r], s_cur[t][r + 1]};
+                const f32x2 x = __builtin_elementwise_fma(a, c2, m2);
                 pf[t][j][ee] = from_f32<T>(__builtin_amdgcn_exp2f(x[0]));
                 pf[t][j][ee + 1] = from_f32<T>(__builtin_amdgcn_exp2f(x[1]));
-#endif
             };
             float mxn = -INFINITY;
             auto max_pair = [&](auto p_) {
                 constexpr int e = decltype(p_)::value * 2, t = e / 16, r = e % 16;
-#ifndef ATTN_DBG_NOMAX
                 mxn = fmaxf(fmaxf(mxn, s_nxt[t][r]), s_nxt[t][r + 1]);
-#endif
             };
             static_for<0, PRE>(rd);
             if constexpr (!HAS_NEXT) static_for<0, 16>(exp_pair);
             __builtin_amdgcn_s_setprio(1);  // the MFMA run outranks the co-resident waves' vector work (+4 % at batch 4)
-            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             static_for<0, NR>([&](auto m_) {
                 constexpr int m = decltype(m_)::value, r = R0 + m;
                 constexpr int issued = (PRE + m < NR) ? PRE + m : NR;
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(issued - m - 1) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (r < 12) {
-                    s_nxt[r % NST] = mma32(__builtin_bit_cast(frag_t, fr[r]), qf[r / NST], r < NST ? zero16 : s_nxt[r % NST]);
+                    s_nxt[r % NST] = mma32(__builtin_bit_cast(frag_t, fr[r]), qf[r / NST], r < NST ? zero : s_nxt[r % NST]);
                 } else {
                     constexpr int i = r - 12;
                     o[i % NDT] = mma32(__builtin_bit_cast(frag_t, fr[r]), pf[(i / NDT) >> 1][(i / NDT) & 1], o[i % NDT]);
@@ -370,10 +284,9 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
                 // instead of a block of six at the top of the iteration
                 if constexpr (!DMA_IN_SLOTS) {
                 } else if constexpr (m < K_IT) {
-                    if (it + 2 < nit) {
-                        const char* src = kpad[m < K_IT ? m : 0] ? kone : kbase + (long long)((it + 2) * SPLIT + grp) * KBYTES + m * 4096;
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ks + cur * KBYTES + (wave * 64 + m * 256) * 16), 16, 0, 0);
-                    }
+                    if (it + 2 < nit)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (long long)((it + 2) * SPLIT + grp) * KBYTES + m * 4096),
+                                                         (lptr_t)(Ks + cur * KBYTES + (wave * 64 + m * 256) * 16), 16, 0, 0);
                 } else if constexpr (m < K_IT + V_IT && HAS_NEXT) {
                     constexpr int i = m - K_IT;
                     const char* src = vones[i] ? ones : vsrc[i] + (long long)((it + 1) * SPLIT + grp) * 128;
@@ -391,9 +304,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
             __builtin_amdgcn_s_setprio(0);
             if (HAS_NEXT) {
                 mx = fmaxf(mxn, __shfl_xor(mxn, 32));
-#ifndef ATTN_DBG_NOBARRIER
                 __syncthreads();
-#endif
             }
             return;
         }
@@ -512,8 +423,7 @@ static int launch_attn_t(const void* q, const void* kt, const void* vt, void* ou
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    // scale == 0 (L4P_ATTN_PRESCALED): q already carries head_dim^-0.5 * log2(e); the kernels then multiply by exactly 1
-    const float c_scale = scale > 0.f ? scale * 1.4426950408889634f : 1.0f;
+    const float c_scale = scale * 1.4426950408889634f;
     ProfScope prof(PROF_ATTENTION, stream);
     hipLaunchKernelGGL(kern, dim3((S / 128) * H * B), dim3(256 * SPLIT), lds, stream, (const T*)q, (const T*)kt, (const T*)vt, (T*)out,
                        S, H, c_scale);
@@ -524,8 +434,8 @@ static int launch_attn_t(const void* q, const void* kt, const void* vt, void* ou
 // scale = Dh^-0.5 (reference :150)
 int launch_attention(int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, int Dh,
                      float scale, hipStream_t stream) {
-    if (S % 128 || (Dh != 88 && Dh != 64) || !(scale >= 0.f)) {
-        l4p_set_error("attention: need S %% 128 == 0, head_dim in {88, 64} and scale >= 0 (S=%d Dh=%d scale=%g)", S, Dh, (double)scale);
+    if (S % 128 || (Dh != 88 && Dh != 64)) {
+        l4p_set_error("attention: need S %% 128 == 0 and head_dim in {88, 64} (S=%d Dh=%d)", S, Dh);
         return L4P_E_INVALID;
     }
     // too few workgroups for two per CU (256 CUs): split the KV range over two wave groups inside each workgroup
