@@ -7,37 +7,63 @@
 // diagonal.  Validated by recovering known intrinsics from synthetic ray maps ("parity unpinned").
 #include "common.hpp"
 
-__device__ void jacobi_sym(double* A, double* V, int n) {  // A: n x n symmetric (destroyed: diag = eigenvalues), V: eigenvectors in columns
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) V[i * n + j] = i == j;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0;
-        for (int p = 0; p < n; ++p)
-            for (int q = p + 1; q < n; ++q) off += fabs(A[p * n + q]);
-        if (off < 1e-300) break;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * n + q];
-                if (fabs(apq) < 1e-300) continue;
-                const double th = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < n; ++k) {
-                    const double x = A[k * n + p], y = A[k * n + q];
-                    A[k * n + p] = c * x - s * y;
-                    A[k * n + q] = s * x + c * y;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double x = A[p * n + k], y = A[q * n + k];
-                    A[p * n + k] = c * x - s * y;
-                    A[q * n + k] = s * x + c * y;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double x = V[k * n + p], y = V[k * n + q];
-                    V[k * n + p] = c * x - s * y;
-                    V[k * n + q] = s * x + c * y;
-                }
-            }
+// Eigenvector of the smallest eigenvalue of a symmetric positive semi-definite 9 x 9 matrix (the DLT normal matrix
+// A^T A; its null / near-null vector is the homography), by shifted inverse iteration: Cholesky of M + eps I in place,
+// then a few rounds of h <- normalise((M + eps I)^-1 h).  The smallest eigenvalue of a DLT system is at the noise level
+// (exactly 0 for a minimal 4-point sample) while the next one is O(1) after Hartley normalisation, so every round
+// gains orders of magnitude; 5 rounds are far beyond double precision for any usable sample.  All loops are fully
+// unrolled: the 45 packed entries live in registers (the cyclic Jacobi sweep this replaces kept two 9 x 9 arrays in
+// scratch memory and ran a fixed 60 sweeps: 4 ms per clip).
+// m: lower triangle packed row-major, m[i*(i+1)/2 + j] (j <= i); destroyed.  h: out, unit length.
+__device__ __forceinline__ void smallest_eigvec9(double (&m)[45], double (&h)[9]) {
+    double tr = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tr += m[i * (i + 1) / 2 + i];
+    const double eps = tr * (1e-13 / 9.0) + 1e-300;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i * (i + 1) / 2 + i] += eps;
+    double dinv[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double sdiag = m[j * (j + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sdiag -= m[j * (j + 1) / 2 + k] * m[j * (j + 1) / 2 + k];
+        const double d = sqrt(fmax(sdiag, eps * 1e-3));
+        dinv[j] = 1.0 / d;
+        m[j * (j + 1) / 2 + j] = d;
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i) {
+            double v = m[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= m[i * (i + 1) / 2 + k] * m[j * (j + 1) / 2 + k];
+            m[i * (i + 1) / 2 + j] = v * dinv[j];
+        }
+    }
+    const double h0[9] = {0.3, -0.5, 0.7, 0.2, -0.9, 0.4, 0.6, -0.1, 0.8};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = h0[i];
+#pragma unroll 1
+    for (int it = 0; it < 5; ++it) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {  // L y = h
+            double v = h[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) v -= m[i * (i + 1) / 2 + k] * h[k];
+            h[i] = v * dinv[i];
+        }
+#pragma unroll
+        for (int i = 8; i >= 0; --i) {  // L^T x = y
+            double v = h[i];
+#pragma unroll
+            for (int k = i + 1; k < 9; ++k) v -= m[k * (k + 1) / 2 + i] * h[k];
+            h[i] = v * dinv[i];
+        }
+        double n2 = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) n2 += h[i] * h[i];
+        const double inv = 1.0 / sqrt(fmax(n2, 1e-300));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) h[i] *= inv;
     }
 }
 
@@ -107,8 +133,9 @@ __global__ __launch_bounds__(256) void rays_to_intrinsics_kernel(const float* __
             ok = ok && lval[idx[k]];
             for (int q = 0; q < k; ++q) ok = ok && idx[q] != idx[k];
         }
-        double A[81], V[81];
-        for (int i = 0; i < 81; ++i) A[i] = 0;
+        double Am[45];
+#pragma unroll
+        for (int i = 0; i < 45; ++i) Am[i] = 0;
         if (ok) {
             // Hartley normalisation of the 4 points
             double mx = 0, my = 0, mu = 0, mv = 0;
@@ -125,20 +152,20 @@ __global__ __launch_bounds__(256) void rays_to_intrinsics_kernel(const float* __
                 dd += sqrt((lu[idx[k]] - mu) * (lu[idx[k]] - mu) + (lv[idx[k]] - mv) * (lv[idx[k]] - mv));
             }
             const double ss = ds > 0 ? 1.4142135623730951 * 4 / ds : 1.0, sd = dd > 0 ? 1.4142135623730951 * 4 / dd : 1.0;
+#pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double xn = (lx[idx[k]] - mx) * ss, yn = (ly[idx[k]] - my) * ss;
                 const double un = (lu[idx[k]] - mu) * sd, vn = (lv[idx[k]] - mv) * sd;
                 const double r1[9] = {-xn, -yn, -1, 0, 0, 0, un * xn, un * yn, un};
                 const double r2[9] = {0, 0, 0, -xn, -yn, -1, vn * xn, vn * yn, vn};
+#pragma unroll
                 for (int i = 0; i < 9; ++i)
-                    for (int j = 0; j < 9; ++j) A[i * 9 + j] += r1[i] * r1[j] + r2[i] * r2[j];
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) Am[i * (i + 1) / 2 + j] += r1[i] * r1[j] + r2[i] * r2[j];
             }
-            jacobi_sym(A, V, 9);
-            int m = 0;
-            for (int i = 1; i < 9; ++i)
-                if (A[i * 9 + i] < A[m * 9 + m]) m = i;
-            double Hn[9], tmp[9], Hd[9];
-            for (int i = 0; i < 9; ++i) Hn[i] = V[i * 9 + m];
+            double Hn[9];
+            smallest_eigvec9(Am, Hn);
+            double tmp[9], Hd[9];
             const double Ts[9] = {ss, 0, -ss * mx, 0, ss, -ss * my, 0, 0, 1};
             const double Tdi[9] = {1 / sd, 0, mu, 0, 1 / sd, mv, 0, 0, 1};
             mul3(Hn, Ts, tmp);
@@ -238,20 +265,16 @@ __global__ __launch_bounds__(256) void rays_to_intrinsics_kernel(const float* __
             for (int k = 0; k < 45; ++k) red[threadIdx.x >> 6][k] = acc[k];
         __syncthreads();
         if (threadIdx.x == 0) {
-            double A[81], V[81];
+            double Am[45], Hn[9];
             int k = 0;
+#pragma unroll
             for (int i = 0; i < 9; ++i)
-                for (int j = i; j < 9; ++j) {
-                    const double s = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-                    A[i * 9 + j] = A[j * 9 + i] = s;
+#pragma unroll
+                for (int j = i; j < 9; ++j) {  // (the sums were accumulated as the upper triangle, row-major)
+                    Am[j * (j + 1) / 2 + i] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
                     ++k;
                 }
-            jacobi_sym(A, V, 9);
-            int m = 0;
-            for (int i = 1; i < 9; ++i)
-                if (A[i * 9 + i] < A[m * 9 + m]) m = i;
-            double Hn[9];
-            for (int i = 0; i < 9; ++i) Hn[i] = V[i * 9 + m];
+            smallest_eigvec9(Am, Hn);
             // denormalise: H = Td^-1 Hn Ts
             const double Ts[9] = {nrm[2], 0, -nrm[2] * nrm[0], 0, nrm[2], -nrm[2] * nrm[1], 0, 0, 1};
             const double Tdi[9] = {1 / nrm[5], 0, nrm[3], 0, 1 / nrm[5], nrm[4], 0, 0, 1};
