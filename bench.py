@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 from l4p_amd import _lib  # noqa: E402
 from l4p_amd.models.utils import build_model  # noqa: E402
 from l4p_amd.packing import pack_state_dict  # noqa: E402
-from l4p_amd.parallel import broadcast_weights, init_distributed  # noqa: E402
+from l4p_amd.parallel import broadcast_weights, collective_selftest, init_distributed  # noqa: E402
 from l4p_amd.weights import ModelCfg, actpost_of, fusion_of, seeded_state_dict  # noqa: E402
 
 PEAK_BF16_MFMA = 2.5e15  # dense bf16 MFMA peak, MI355X_MICROARCH.md
@@ -279,6 +279,9 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     lib = _lib.load()
+    # N > 1: the collectives of the path (weight broadcast, unequal-chunk window all-gather, MAX all-reduce) on the live
+    # backend, before anything is timed; its verdict travels in the JSON line
+    selftest = collective_selftest(device) if world > 1 else {"ranks": 1, "backend": None, "ok": True}
     if args.workload == "prep":
         return bench_prep(args, rank, world, device, lib)
 
@@ -342,6 +345,8 @@ def main():
         "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if c5 else "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (randn clips, name-seeded random weights of the VideoMAE-v2-giant + DPT geometry)",
+        "rccl_ranks": selftest["ranks"] if selftest.get("backend") == "nccl" else (1 if world == 1 else 0),
+        "rccl_selftest": None if world == 1 else selftest,
         "config": {"workload": ("configs[1]: single MI355X, depth head only, bf16, batch=1 16-frame 224x224 clip" if args.workload == "c2"
                                  else f"configs[4]: one {args.frames}-frame video -> {(args.frames - 16) // 8 + 1} overlapping 16-frame windows sharded over the ranks, all heads, on-GPU pose / window alignment, {args.queries} track queries" if c5
                                  else (f"configs[2]: single MI355X, all heads (depth+flow+track2d/3d+motion-seg+pose), bf16, batch={B} clips, {args.queries} track queries per clip" if world == 1

@@ -341,6 +341,26 @@ size_t l4p_dpt_workspace_bytes(const l4p_engine* e, const l4p_dpt_cfg* cfg, int 
 int l4p_dpt_forward(l4p_engine* e, l4p_stream stream, const char* task, const l4p_dpt_cfg* cfg, const void* const* hooks,
                     int B, void* workspace, size_t ws_bytes, float* out);
 
+/* One window of the SAM-style tracker for the N queries of ONE clip as a single call (VideoMAETrack2DSamHead.forward /
+ * forward_single_batch, sparse_heads.py:497-667, with PromptEncoder, TwoWayTransformer and MaskDecoder.predict_masks):
+ * prompt tokens, key initialisation, sam_depth two-way layers + final attention, hyper-network MLPs, prompt feature for
+ * the next window, memory tokens (need_history), up-scaling fused with the mask product, fused up-sample + soft-argmax.
+ * enc_last float [P][C] (enc_features[-1] of the clip); hist float [N][P][C] per-query history tokens (read; rewritten in
+ * place for the next window when need_history) — or, with hist_uniform (every track still has the same history rows: the
+ * first window / the plain single-window forward), only its first P rows are read; q_off float [N][3] (t, x, y) relative
+ * to the window; labels, plabel float [N]; pfeat float [N][C].  Outputs: traj float [N][2][T], vis, depth float [N][T],
+ * new_pfeat float [N][C].  Weights "trk.*" must have been bound with l4p_bind_weight. */
+typedef struct l4p_track_cfg {
+    int dim, tokens, nt, nh, nw; /* key geometry: tokens = nt * nh * nw */
+    int sam_depth, sam_heads, sam_mlp, out_dim_factor;
+    int T, H, W; /* window / image size the masks are read out at */
+} l4p_track_cfg;
+size_t l4p_track_window_workspace_bytes(const l4p_engine* e, const l4p_track_cfg* cfg, int N, int hist_uniform);
+int l4p_track_window_forward(l4p_engine* e, l4p_stream stream, const l4p_track_cfg* cfg, const float* enc_last, float* hist,
+                             const float* q_off, const float* labels, const float* pfeat, const float* plabel, int N,
+                             int need_history, int hist_uniform, void* workspace, size_t ws_bytes, float* traj, float* vis,
+                             float* depth, float* new_pfeat);
+
 /* ------------------------------------------------------------------------------------------------
  * Clip preparation (the caller side of the hot path): decoded uint8 frames in HBM ->
  * the network's input tensor.  Replaces VideoDataset.getitem_helper's per-frame PIL resize-blur-resize +

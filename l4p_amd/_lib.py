@@ -71,6 +71,13 @@ class DptCfg(C.Structure):
     ]
 
 
+class TrackCfg(C.Structure):
+    """Mirror of ``l4p_track_cfg``."""
+
+    _fields_ = [(n, C.c_int) for n in ("dim", "tokens", "nt", "nh", "nw", "sam_depth", "sam_heads", "sam_mlp", "out_dim_factor",
+                                        "T", "H", "W")]
+
+
 # name -> (restype, argtypes); every symbol include/l4p_hip.h declares must appear here
 _VP, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -119,6 +126,8 @@ SIGNATURES = {
     "l4p_encoder_configure": (_I, [_VP, C.POINTER(EncoderCfg)]),
     "l4p_encoder_workspace_bytes": (_SZ, [_VP, _I]),
     "l4p_encoder_forward": (_I, [_VP, _VP, _VP, _I, _VP, _SZ, _I, C.POINTER(_I), C.POINTER(_VP), C.POINTER(_VP)]),
+    "l4p_track_window_workspace_bytes": (_SZ, [_VP, C.POINTER(TrackCfg), _I, _I]),
+    "l4p_track_window_forward": (_I, [_VP, _VP, C.POINTER(TrackCfg)] + [_VP] * 6 + [_I, _I, _I, _VP, _SZ] + [_VP] * 4),
     "l4p_dpt_workspace_bytes": (_SZ, [_VP, C.POINTER(DptCfg), _I]),
     "l4p_dpt_forward": (_I, [_VP, _VP, C.c_char_p, C.POINTER(DptCfg), C.POINTER(_VP), _I, _VP, _SZ, _VP]),
 }

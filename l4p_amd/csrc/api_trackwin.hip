@@ -1,0 +1,386 @@
+// l4p_track_window_forward: one window of the SAM-style tracker for the N queries of a clip
+// (VideoMAETrack2DSamHead.forward / forward_single_batch, sparse_heads.py:497-667; PromptEncoder prompt_encoder.py:67-121;
+// TwoWayTransformer sam/transformer.py:67-111,156-187; MaskDecoder.predict_masks mask_decoder.py:101-141; memory tokens
+// sparse_heads.py:406-448,660-665) as ONE native call: ~125 kernel launches issued back to back from C++ on the caller's
+// stream, intermediates bump-allocated from a caller-provided workspace.  Same kernels, same order, same arguments as the
+// Python composition l4p_amd/models/task_heads/sparse_heads.py:_window (which remains as the readable statement of the
+// graph, selectable with L4P_TRACK_PYTHON=1, and is asserted bit-identical in tests/test_track_gpu.py).  What it buys: the
+// host issues one call per clip and window instead of ~125 ctypes calls with their tensor allocations — with 8 ranks
+// sharing one host's cores that is what keeps the step from becoming launch-bound.
+#include <string.h>
+
+#include <string>
+
+#include "engine.hpp"
+
+int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const float* beta, float eps, void* out_T,
+                        float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act,
+                        hipStream_t stream);
+int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T, int M, int C,
+                       int act, hipStream_t stream);
+int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
+                        const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
+                        const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
+                        int W, hipStream_t stream);
+int launch_track_keys_init(int dtype, const float* enc, const float* hist, const float* pos, float* k32, void* kT,
+                           void* kP, int N, int P, int C, hipStream_t stream);
+int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
+                     long long group_off, hipStream_t stream);
+int launch_small_attn(int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P, int D,
+                      int heads, hipStream_t stream);
+int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, int w, int cpt, hipStream_t stream);
+int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
+                         int W, hipStream_t stream);
+
+namespace {
+
+struct Stack {  // bump allocator with LIFO release (mark / release) and a high-water mark for the size query
+    char* base;
+    size_t off, cap, peak;
+    bool dry;
+    void* take(size_t bytes) {
+        const size_t a = (off + 255) & ~(size_t)255;
+        off = a + bytes;
+        if (off > peak) peak = off;
+        return dry ? (void*)256 : (off <= cap ? base + a : nullptr);
+    }
+};
+
+struct TW {
+    const l4p_engine* e;
+    hipStream_t st;
+    int dt, es;
+    Stack ws;
+    int rc = 0;
+    bool dry = false;
+
+    const void* W(const std::string& k) {
+        if (dry) return (const void*)256;
+        const void* p = e->find("trk." + k);
+        if (!p && !rc) {
+            l4p_set_error("weight 'trk.%s' was never bound", k.c_str());
+            rc = L4P_E_MISSING;
+        }
+        return p;
+    }
+    const float* Wf(const std::string& k) { return (const float*)W(k); }
+    void* alloc(size_t bytes) {
+        void* p = ws.take(bytes);
+        if (!p && !rc) {
+            l4p_set_error("l4p_track_window_forward: workspace too small");
+            rc = L4P_E_INVALID;
+        }
+        return p;
+    }
+    float* f32(long long rows, int cols) { return (float*)alloc((size_t)rows * cols * 4); }
+    void* T(long long rows, int cols) { return alloc((size_t)rows * cols * es); }
+
+    // out = act(a[M][K] (row stride lda) @ w[n][K]^T + bias) (+ res1, float) -> out_T and / or out_f32, row stride ldc
+    void gemm(const void* a, long long M, int K, long long lda, const std::string& wk, int n, bool bias, int act, const float* res1,
+              int res_mod, float* out_f32, void* out_T, long long ldc, const int* a_map = nullptr, const int* c_map = nullptr) {
+        if (rc || dry) return;
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.A = a;
+        p.lda = lda;
+        p.W = W(wk + ".w");
+        p.ldw = K;
+        p.M = (int)M;
+        p.N = n;
+        p.K = K;
+        p.bias = bias ? Wf(wk + ".b") : nullptr;
+        p.act = act;
+        if (res1) {
+            p.res1 = res1;
+            p.res_f32 = 1;
+            p.ldr = n;
+            p.res_mod = res_mod;
+        }
+        p.out_f32 = out_f32;
+        p.out_T = out_T;
+        p.ldc = ldc;
+        p.epi = EPI_DENSE;
+        if (a_map) {
+            p.a_gr = a_map[0];
+            p.a_gs = a_map[1];
+            p.a_go = a_map[2];
+        }
+        if (c_map) {
+            p.c_gr = c_map[0];
+            p.c_gs = c_map[1];
+            p.c_go = c_map[2];
+        }
+        if (!rc) rc = launch_gemm(dt, 0, p, st);
+    }
+    // x[M][K] T -> new T [M][n] = act(x W^T + b)
+    void* proj(const void* x, long long M, int K, const std::string& wk, int n, int act = ACT_NONE) {
+        void* o = T(M, n);
+        gemm(x, M, K, K, wk, n, true, act, nullptr, 0, nullptr, o, n);
+        return o;
+    }
+    // LayerNorm with the tracker's extras (see l4p_layernorm_ex)
+    void ln(const float* x32, const std::string& key, float eps, void* oT, float* o32, long long M, int Cc, const float* add,
+            int add_mod, void* oT2, int act) {
+        if (rc || dry) return;
+        rc = launch_layernorm_ex(dt, x32, Wf(key + ".g"), Wf(key + ".b"), eps, oT, o32, (int)M, Cc, add, add_mod, oT2, act, st);
+    }
+    void attn(int kind, const void* q, const void* k, const void* v, void* out, int N, int P, int D, int heads) {
+        if (rc || dry) return;
+        rc = launch_small_attn(dt, kind, q, k, v, out, N, P, D, heads, st);
+    }
+};
+
+int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const float* q_off, const float* labels,
+        const float* pfeat, const float* plabel, int N, int need_history, int hist_uniform, float* traj, float* vis, float* depth,
+        float* new_pfeat) {
+    const int P = g.tokens, Cc = g.dim, Dh = Cc / 2;
+    const int T = g.T, H = g.H, W = g.W;
+    const long long NP = (long long)N * P;
+    // ---- prompt tokens (prompt_encoder.py:78-121,196-203; mask_decoder.py:107-113) ----
+    float* tok32 = c.f32(6ll * N, Cc);
+    void* tokT = c.T(6ll * N, Cc);
+    if (!c.rc && !c.dry) {
+        c.rc = launch_track_tokens(q_off, labels, pfeat, plabel, c.Wf("gauss"), c.Wf("mask_tokens"), c.Wf("point_emb0"),
+                                   c.Wf("point_emb1"), c.Wf("not_a_point"), c.Wf("feat_emb0"), c.Wf("feat_emb1"), tok32, N, Cc, T, H, W,
+                                   c.st);
+        if (!c.rc) c.rc = launch_cast(c.dt, tok32, tokT, 6ll * N * Cc, c.st);
+    }
+    // ---- keys = enc_features[-1] + history (sparse_heads.py:341-346); one shared [P][C] set while every track still has
+    //      the same history rows (first window), the per-track set from the first image -> token update on ----
+    const float* pos = c.Wf("dense_pe");
+    int Nk = hist_uniform ? 1 : N;
+    float* ks32 = nullptr;
+    void *ksT = nullptr, *ksP = nullptr;
+    if (Nk == 1 && N > 1) {
+        ks32 = c.f32(P, Cc);
+        ksT = c.T(P, Cc);
+        ksP = c.T(P, Cc);
+    }
+    float* k32 = c.f32(NP, Cc);
+    void* kT = c.T(NP, Cc);
+    void* kP = c.T(NP, Cc);
+    const bool start_shared = Nk == 1 && N > 1;
+    if (!c.rc && !c.dry)
+        c.rc = launch_track_keys_init(c.dt, enc_last, hist, pos, start_shared ? ks32 : k32, start_shared ? ksT : kT,
+                                      start_shared ? ksP : kP, Nk, P, Cc, c.st);
+    float* cur32 = start_shared ? ks32 : k32;  // the key set the next projection reads
+    void* curT = start_shared ? ksT : kT;
+    void* curP = start_shared ? ksP : kP;
+
+    const float* q32 = nullptr;
+    const void* qT = tokT;
+    const void* qP = tokT;
+    float* x32 = c.f32(6ll * N, Cc);
+    auto ln_tokens = [&](const std::string& key) {  // (q32, qT, qP) = LN(x32), T(LN), T(LN + token PE)
+        float* o32 = c.f32(6ll * N, Cc);
+        void* oT = c.T(6ll * N, Cc);
+        void* oP = c.T(6ll * N, Cc);
+        c.ln(x32, key, 1e-5f, oT, o32, 6ll * N, Cc, tok32, 6 * N, oP, ACT_NONE);
+        q32 = o32;
+        qT = oT;
+        qP = oP;
+    };
+    for (int l = 0; l < g.sam_depth; ++l) {
+        const std::string lo = "l" + std::to_string(l) + ".";
+        const bool shared = Nk == 1 && N > 1;  // keys still common to all tracks (only in layer 0 of a first window)
+        // --- self attention of the prompt tokens (transformer.py:159-166) ---
+        const size_t mark_self = c.ws.off;
+        {
+            void* sq = c.proj(qP, 6ll * N, Cc, lo + "self.q", Cc);
+            void* sk = c.proj(qP, 6ll * N, Cc, lo + "self.k", Cc);
+            void* sv = c.proj(qT, 6ll * N, Cc, lo + "self.v", Cc);
+            void* sa = c.T(6ll * N, Cc);
+            c.attn(0, sq, sk, sv, sa, N, 6, Cc, g.sam_heads);
+            c.gemm(sa, 6ll * N, Cc, Cc, lo + "self.out", Cc, true, ACT_NONE, q32, 0, x32, nullptr, Cc);
+        }
+        c.ws.off = mark_self;
+        ln_tokens(lo + "norm1");
+        // --- tokens -> image (transformer.py:168-173) ---
+        size_t mark = c.ws.off;
+        {
+            void* tq = c.proj(qP, 6ll * N, Cc, lo + "t2i.q", Dh);
+            void* tk = c.proj(curP, (long long)Nk * P, Cc, lo + "t2i.k", Dh);
+            void* tv = c.proj(curT, (long long)Nk * P, Cc, lo + "t2i.v", Dh);
+            void* ta = c.T(6ll * N, Dh);
+            c.attn(shared ? 3 : 1, tq, tk, tv, ta, N, P, Dh, g.sam_heads);
+            c.gemm(ta, 6ll * N, Dh, Dh, lo + "t2i.out", Cc, true, ACT_NONE, q32, 0, x32, nullptr, Cc);
+        }
+        c.ws.off = mark;
+        ln_tokens(lo + "norm2");
+        // --- MLP (transformer.py:175-178), ReLU ---
+        mark = c.ws.off;
+        {
+            void* hdn = c.proj(qT, 6ll * N, Cc, lo + "mlp1", g.sam_mlp, ACT_RELU);
+            c.gemm(hdn, 6ll * N, g.sam_mlp, g.sam_mlp, lo + "mlp2", Cc, true, ACT_NONE, q32, 0, x32, nullptr, Cc);
+        }
+        c.ws.off = mark;
+        ln_tokens(lo + "norm3");
+        // --- image -> tokens (transformer.py:180-185): keys are updated in place ---
+        mark = c.ws.off;
+        {
+            void* iq = c.proj(curP, (long long)Nk * P, Cc, lo + "i2t.q", Dh);
+            void* ik = c.proj(qP, 6ll * N, Cc, lo + "i2t.k", Dh);
+            void* iv = c.proj(qT, 6ll * N, Cc, lo + "i2t.v", Dh);
+            void* ia = c.T(NP, Dh);
+            c.attn(shared ? 4 : 2, iq, ik, iv, ia, N, P, Dh, g.sam_heads);
+            if (shared) {  // from here on every track owns its keys: residual = the common key set, row m % P
+                c.gemm(ia, NP, Dh, Dh, lo + "i2t.out", Cc, true, ACT_NONE, cur32, P, k32, nullptr, Cc);
+                Nk = N;
+                cur32 = k32;
+                curT = kT;
+                curP = kP;
+            } else {
+                c.gemm(ia, NP, Dh, Dh, lo + "i2t.out", Cc, true, ACT_NONE, cur32, 0, cur32, nullptr, Cc);
+            }
+        }
+        c.ws.off = mark;
+        // (after the last layer nothing adds to the float keys any more: only the T copies are written)
+        c.ln(cur32, lo + "norm4", 1e-5f, curT, l + 1 < g.sam_depth ? cur32 : nullptr, NP, Cc, pos, P, curP, ACT_NONE);
+    }
+    // --- final tokens -> image attention (transformer.py:103-109) ---
+    size_t mark = c.ws.off;
+    {
+        void* fq = c.proj(qP, 6ll * N, Cc, "final.q", Dh);
+        void* fk = c.proj(curP, (long long)Nk * P, Cc, "final.k", Dh);
+        void* fv = c.proj(curT, (long long)Nk * P, Cc, "final.v", Dh);
+        void* fa = c.T(6ll * N, Dh);
+        c.attn(1, fq, fk, fv, fa, N, P, Dh, g.sam_heads);
+        c.gemm(fa, 6ll * N, Dh, Dh, "final.out", Cc, true, ACT_NONE, q32, 0, x32, nullptr, Cc);
+    }
+    c.ws.off = mark;
+    void* hsT = c.T(6ll * N, Cc);
+    c.ln(x32, "norm_final", 1e-5f, hsT, x32, 6ll * N, Cc, nullptr, 0, nullptr, ACT_NONE);
+
+    // --- hyper-network MLPs on the 3 mask tokens (mask_decoder.py:130-133,160-180) ---
+    const int d1 = Cc / g.out_dim_factor, d1p = (d1 + 31) / 32 * 32, cpt = d1p / 32;
+    float* hyper = c.f32(3ll * N, d1p);
+    if (!c.rc && !c.dry) {
+        if (hipMemsetAsync(hyper, 0, (size_t)3 * N * d1p * 4, c.st) != hipSuccess) {
+            l4p_set_error("l4p_track_window_forward: hipMemsetAsync failed");
+            c.rc = L4P_E_HIP;
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        const std::string hk = "hyper" + std::to_string(i);
+        void* h1 = c.T(N, Cc);
+        c.gemm((const char*)hsT + (size_t)i * Cc * c.es, N, Cc, 6ll * Cc, hk + ".0", Cc, true, ACT_RELU, nullptr, 0, nullptr, h1, Cc);
+        void* h2 = c.proj(h1, N, Cc, hk + ".1", Cc, ACT_RELU);
+        c.gemm(h2, N, Cc, Cc, hk + ".2", d1, true, ACT_NONE, nullptr, 0, c.dry ? nullptr : hyper + (size_t)i * d1p, nullptr, 3ll * d1p);
+    }
+    // prompt feature for the next window (sparse_heads.py:650-658): io token 5
+    c.gemm((const char*)hsT + (size_t)5 * Cc * c.es, N, Cc, 6ll * Cc, "prompt_lin", Cc, true, ACT_NONE, nullptr, 0, new_pfeat, nullptr, Cc);
+
+    // --- memory tokens for the next window (sparse_heads.py:406-448,660-665): project the 2nd temporal half of the
+    //     processed video tokens into the 1st half of the history, pad the rest with the learned mask token ---
+    if (need_history) {
+        const int half = P / 2;
+        const int a_map[3] = {half, P, half}, c_map[3] = {half, P, 0};
+        c.gemm(curT, (long long)N * half, Cc, Cc, "history_proj", Cc, true, ACT_NONE, nullptr, 0, hist, nullptr, Cc, a_map, c_map);
+        if (!c.rc && !c.dry) c.rc = launch_fill_rows(hist, c.Wf("history_mask_token"), (long long)N * half, Cc, half, P, half, c.st);
+    }
+
+    // --- output up-scaling (mask_decoder.py:58-66,136-137) on channels-last tokens ---
+    const int nt = g.nt, nh = g.nh, nw = g.nw;
+    const int d0 = (2 * Cc / g.out_dim_factor) < Cc ? 2 * Cc / g.out_dim_factor : Cc;
+    const long long M1 = NP * 8;
+    void* u0T = c.T(M1, d0);
+    if (!c.rc && !c.dry) {
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.A = curT;
+        p.lda = Cc;
+        p.W = c.W("up0.w");
+        p.ldw = Cc;
+        p.M = (int)NP;
+        p.N = 8 * d0;
+        p.K = Cc;
+        p.Ti = nt;
+        p.Hi = nh;
+        p.Wi = nw;
+        p.bias = c.Wf("up0.b");
+        p.out_T = u0T;
+        p.epi = EPI_CONVT;
+        p.kt = p.kh = p.kw = 2;
+        p.Cout = d0;
+        if (!c.rc) c.rc = launch_gemm(c.dt, 0, p, c.st);
+        if (!c.rc) c.rc = launch_layernorm_T(c.dt, u0T, c.Wf("up_ln.g"), c.Wf("up_ln.b"), 1e-6f, u0T, (int)M1, d0, ACT_GELU, c.st);
+    }
+    // up1 (ConvTranspose (1,2,2) + GELU) fused with the hyper-network mask product (mask_decoder.py:136-139)
+    const int Tl = nt * 2, hl = nh * 4, wl = nw * 4;
+    if (Tl != T) {
+        l4p_set_error("l4p_track_window_forward: decoded masks have %d frames, the window %d", Tl, T);
+        return L4P_E_INVALID;
+    }
+    float* partial = (float*)c.alloc((size_t)4 * cpt * 3 * M1 * 4);
+    float* masks = (float*)c.alloc((size_t)N * 3 * Tl * hl * wl * 4);
+    if (!c.rc && !c.dry) {
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.A = u0T;
+        p.lda = d0;
+        p.W = c.W("up1.w");
+        p.ldw = d0;
+        p.M = (int)M1;
+        p.N = 4 * d1p;
+        p.K = d0;
+        p.bias = c.Wf("up1.b");
+        p.act = ACT_GELU;
+        p.out_f32 = partial;
+        p.epi = EPI_MASKDOT;
+        p.Cout = d1p;
+        p.hyper = hyper;
+        p.hyper_rows = (int)(M1 / N);
+        if (!c.rc) c.rc = launch_gemm(c.dt, 0, p, c.st);
+        if (!c.rc) c.rc = launch_mask_gather(partial, masks, N, Tl, nh * 2, nw * 2, cpt, c.st);
+        if (!c.rc) c.rc = launch_track_readout(masks, traj, vis, depth, N, T, hl, wl, H, W, c.st);
+    }
+    return c.rc;
+}
+
+bool cfg_ok(const l4p_track_cfg* g, int N) {
+    if (!g || N < 1 || g->dim % 64 || g->tokens != g->nt * g->nh * g->nw || g->sam_depth < 1 || g->out_dim_factor < 1 ||
+        (long long)N * g->tokens * 8 > 0x7FFFFFFFll) {
+        l4p_set_error("l4p_track_window: bad configuration / query count (N=%d)", N);
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t l4p_track_window_workspace_bytes(const l4p_engine* e, const l4p_track_cfg* cfg, int N, int hist_uniform) {
+    if (!e || !cfg_ok(cfg, N)) return 0;
+    TW c;
+    c.e = e;
+    c.st = nullptr;
+    c.dt = e->dtype;
+    c.es = e->dtype == L4P_BF16 ? 2 : 4;
+    c.ws = Stack{nullptr, 0, 0, 0, true};
+    c.dry = true;
+    run(c, *cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, 1, hist_uniform, nullptr, nullptr, nullptr, nullptr);
+    return c.ws.peak + 256;
+}
+
+int l4p_track_window_forward(l4p_engine* e, l4p_stream stream, const l4p_track_cfg* cfg, const float* enc_last, float* hist,
+                             const float* q_off, const float* labels, const float* pfeat, const float* plabel, int N,
+                             int need_history, int hist_uniform, void* workspace, size_t ws_bytes, float* traj, float* vis,
+                             float* depth, float* new_pfeat) {
+    if (!e || !cfg_ok(cfg, N)) return L4P_E_INVALID;
+    if (!enc_last || !hist || !q_off || !labels || !pfeat || !plabel || !workspace || !traj || !vis || !depth || !new_pfeat) {
+        l4p_set_error("l4p_track_window_forward: null argument");
+        return L4P_E_INVALID;
+    }
+    TW c;
+    c.e = e;
+    c.st = (hipStream_t)stream;
+    c.dt = e->dtype;
+    c.es = e->dtype == L4P_BF16 ? 2 : 4;
+    const size_t mis = (size_t)((uintptr_t)workspace & 255);
+    char* base = (char*)workspace + (mis ? 256 - mis : 0);
+    c.ws = Stack{base, 0, ws_bytes - (mis ? 256 - mis : 0), 0, false};
+    return run(c, *cfg, enc_last, hist, q_off, labels, pfeat, plabel, N, need_history, hist_uniform, traj, vis, depth, new_pfeat);
+}
+
+}  // extern "C"

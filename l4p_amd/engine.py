@@ -27,9 +27,10 @@ class Engine:
         _lib.check(self.lib.l4p_create(device.index or 0, dtype, C.byref(h)), "l4p_create")
         self.handle = h
         for name, t in weights.t.items():
-            if name.startswith("enc.") or name.startswith("dpt."):
+            if name.startswith("enc.") or name.startswith("dpt.") or name.startswith("trk."):
                 _lib.check(self.lib.l4p_bind_weight(self.handle, name.encode(), t.data_ptr(), t.numel()), "l4p_bind_weight")
         self._dpt_ws: Dict[Tuple[str, int], torch.Tensor] = {}
+        self._trk_ws: Dict[Tuple[int, int], torch.Tensor] = {}
         ec = EncoderCfg(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, head_dim=cfg.head_dim, mlp_hidden=cfg.mlp_hidden,
                         in_chans=cfg.in_chans, frames=cfg.frames, img_h=cfg.img, img_w=cfg.img, pt=cfg.patch[0],
                         ph=cfg.patch[1], pw=cfg.patch[2], patch_kp=int(weights.meta["patch_kp"]), ln_eps=cfg.ln_eps)
@@ -99,3 +100,32 @@ class Engine:
         _lib.check(self.lib.l4p_encoder_forward(self.handle, torch.cuda.current_stream().cuda_stream, rgb.data_ptr(), B,
                                                 ws.data_ptr(), ws.numel(), n, lay, pf, pT), "l4p_encoder_forward")
         return out_f, out_T
+
+    def track_window(self, tcfg: "_lib.TrackCfg", enc_last: torch.Tensor, hist: torch.Tensor, q_off: torch.Tensor,
+                     labels: torch.Tensor, pfeat: torch.Tensor, plabel: torch.Tensor, need_history: bool, hist_uniform: bool,
+                     slot: int = 0):
+        """One tracker window of one clip as ONE native call (l4p_track_window_forward).  ``slot`` selects the workspace:
+        clips whose trackers run concurrently on different HIP streams must not share one."""
+        N, Cc = q_off.shape[0], self.cfg.dim
+        T = tcfg.T
+        key = (slot, N, 1 if hist_uniform else 0)
+        ws = self._trk_ws.get(key)
+        if ws is None:
+            need = int(self.lib.l4p_track_window_workspace_bytes(self.handle, C.byref(tcfg), N, 1 if hist_uniform else 0))
+            if need == 0:
+                raise _lib.L4PHipError("l4p_track_window_workspace_bytes: " + self.lib.l4p_last_error().decode())
+            for k in [k for k in self._trk_ws if k[0] == slot]:  # one workspace per slot: drop the one of another shape
+                del self._trk_ws[k]
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._trk_ws[key] = ws
+        f32 = dict(dtype=torch.float32, device=self.device)
+        traj = torch.empty((N, 2, T), **f32)
+        vis = torch.empty((N, T), **f32)
+        dep = torch.empty((N, T), **f32)
+        new_pfeat = torch.empty((N, Cc), **f32)
+        _lib.check(self.lib.l4p_track_window_forward(
+            self.handle, torch.cuda.current_stream().cuda_stream, C.byref(tcfg), enc_last.data_ptr(), hist.data_ptr(),
+            q_off.data_ptr(), labels.data_ptr(), pfeat.data_ptr(), plabel.data_ptr(), N, 1 if need_history else 0,
+            1 if hist_uniform else 0, ws.data_ptr(), ws.numel(), traj.data_ptr(), vis.data_ptr(), dep.data_ptr(),
+            new_pfeat.data_ptr()), "l4p_track_window_forward")
+        return traj, vis, dep, new_pfeat

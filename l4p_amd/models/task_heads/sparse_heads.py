@@ -127,6 +127,15 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         the key initialisation run once instead of N times (identical rows in, identical rows out)."""
         rt = self._rt
         cfg, dt = rt.cfg, rt.dtype
+        eng = getattr(rt, "engine", None)
+        if eng is not None and not os.environ.get("L4P_TRACK_PYTHON"):
+            # the whole window as ONE native call (csrc/api_trackwin.hip: the same kernels in the same order as below)
+            tc = _lib.TrackCfg(dim=cfg.dim, tokens=cfg.tokens, nt=cfg.grid[0], nh=cfg.grid[1], nw=cfg.grid[2],
+                               sam_depth=cfg.sam_depth, sam_heads=cfg.sam_heads, sam_mlp=cfg.sam_mlp,
+                               out_dim_factor=self.decoding_out_dim_factor, T=self.image_size[0], H=self.image_size[1],
+                               W=self.image_size[2])
+            return eng.track_window(tc, enc_last, hist, q_off, labels, pfeat, plabel, need_history, hist_uniform,
+                                    slot=getattr(self, "_ws_slot", 0))
         lib = _lib.load()
         dev = enc_last.device
         td = ops.torch_dtype(dt)
@@ -367,7 +376,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             for b in range(B):
                 pool[b].wait_stream(main)
                 with torch.cuda.stream(pool[b]):
+                    self._ws_slot = b + 1  # concurrent clips: one native workspace each
                     run_clip(b)
+            self._ws_slot = 0
             for b in range(B):
                 main.wait_stream(pool[b])
         else:

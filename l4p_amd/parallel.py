@@ -208,3 +208,50 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
                 out[key] = torch.zeros(data["rgb_b3thw"].shape[0], 0, shp, T, dtype=torch.float32, device=net.device)
             out[key] = all_gather_queries(out[key], nq, rank, world, dim=1)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Collective self-test: callable on any lease with >= 2 ranks (backend "nccl" = RCCL over xGMI on a GPU node, "gloo" in
+# the CPU tests).  bench.py runs it before the timed region when WORLD_SIZE > 1 and prints its verdict into the JSON line
+# ("rccl_ranks", "rccl_selftest"), so a multi-GPU bench line is also evidence that the two collectives of the path ran.
+# ---------------------------------------------------------------------------------------------------------------------
+def collective_selftest(device: torch.device) -> dict:
+    """Exercises exactly the collectives the path uses: (1) broadcast_weights of a packed arena with a known checksum,
+    (2) all_gather_windows with UNEQUAL chunks (world + 1 windows: rank 0 owns two, every other rank one), (3) a MAX
+    all-reduce as bench.py's timing uses.  Returns {"ranks", "backend", "ok", ...}; raises on a mismatch."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"ranks": 1, "backend": None, "ok": True}
+    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = dist.get_backend()
+    # (1) weight broadcast: a 3-tensor arena built on rank 0 only
+    pw = None
+    if rank == 0:
+        from .packing import Packer
+
+        pk = Packer(torch.bfloat16)
+        g = torch.Generator().manual_seed(99)
+        pk.T("a.w", torch.randn(130, 64, generator=g))
+        pk.F("a.b", torch.randn(130, generator=g))
+        pk.T("c.w", torch.randn(256, 32, generator=g), pad_rows=False)
+        pw = PackedWeights.from_packer(pk, device, {"patch_kp": 1216})
+    pw = broadcast_weights(pw, device)
+    chk = int(pw.arena.to(torch.int64).sum().item())
+    chks = [None] * world
+    dist.all_gather_object(chks, (chk, int(pw.arena.numel()), sorted(pw.t.keys())))
+    if any(c != chks[0] for c in chks):
+        raise RuntimeError(f"weight broadcast mismatch across ranks: {chks}")
+    # (2) unequal window chunks
+    nwin = world + 1
+    s0, e0 = window_chunks(nwin, world)[rank]
+    local = {w: {"x": torch.full((2, 3), float(w), device=device), "y": torch.arange(4, device=device, dtype=torch.float32) + 10 * w}
+             for w in range(s0, e0)}
+    allw = all_gather_windows(local, nwin, rank, world)
+    for w in range(nwin):
+        if float(allw[w]["x"].mean()) != float(w) or float(allw[w]["y"][0]) != 10.0 * w:
+            raise RuntimeError(f"all_gather_windows returned the wrong block for window {w} on rank {rank}")
+    # (3) MAX all-reduce
+    t = torch.tensor([float(rank)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t.item()) != world - 1:
+        raise RuntimeError("all_reduce(MAX) wrong")
+    return {"ranks": world, "backend": backend, "ok": True, "arena_checksum": chk, "windows_gathered": nwin}

@@ -90,3 +90,33 @@ def test_window_chunks_cover():
     for n, w in ((31, 8), (3, 8), (16, 4), (1, 2)):
         ch = window_chunks(n, w)
         assert ch[0][0] == 0 and ch[-1][1] == n and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+
+
+def _worker_selftest(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from l4p_amd.parallel import collective_selftest, init_distributed
+
+    init_distributed("gloo")
+    q.put((rank, collective_selftest(torch.device("cpu"))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_selftest_world3():
+    """parallel.collective_selftest — what bench.py runs on the live backend before an N > 1 measurement (and reports as
+    rccl_ranks / rccl_selftest) — on gloo with 3 ranks: weight broadcast checksum, all-gather of 4 windows in chunks of
+    2 + 1 + 1, MAX all-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_selftest, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(3)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1]["ok"] and r[1]["ranks"] == 3 and r[1]["backend"] == "gloo" and r[1]["windows_gathered"] == 4 for r in res)
+    assert len({r[1]["arena_checksum"] for r in res}) == 1

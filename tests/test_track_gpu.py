@@ -186,3 +186,23 @@ def test_single_window_entry_vs_reference_golden(dev, mini, precision):
         assert torch.equal(out[k], again[k]), k
     # unmasked: frames before the query time carry estimates, not the -10 / 0 fill of the sliding tracker
     assert float(out["track_2d_vis_est_bn1t"].min()) > -9.0
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_native_window_call_equals_python_composition(dev, mini, precision, monkeypatch):
+    """l4p_track_window_forward (one C++ call per clip and window, csrc/api_trackwin.hip) issues the same kernels in the same
+    order as sparse_heads._window (kernel by kernel from Python, L4P_TRACK_PYTHON=1): bit-identical outputs over a 3-window
+    recursion (shared first-window keys, per-track keys + memory tokens afterwards) and for 2 clips on their own streams."""
+    cfg, sd = mini
+    model = build(cfg, sd, precision)
+    b1 = make_batch(32, 7)
+    batch = {k: (torch.cat([v, v.flip(-1) if k == "rgb_b3thw" else v], dim=0) if torch.is_tensor(v) else v) for k, v in b1.items()}
+    keys = ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]
+    with torch.no_grad():
+        monkeypatch.delenv("L4P_TRACK_PYTHON", raising=False)
+        a = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+        monkeypatch.setenv("L4P_TRACK_PYTHON", "1")
+        b = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+    torch.cuda.synchronize()
+    for k in keys:
+        assert a[k].shape[0] == 2 and torch.equal(a[k], b[k]), k
