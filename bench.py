@@ -9,6 +9,10 @@ synthetic 16x224x224 clips already resident in HBM.  One process per GPU, clips 
 collective in the step (weak scaling: per-GPU batch fixed); the only collective is the one-off RCCL
 broadcast of the packed weight arena before the timed region.  Rank 0 prints ONE JSON line.
 
+--workload demo: the generic-video case of the reference's demo (demo/demo.py:84-100,38-40): one decoded 480x854 video per
+GPU -> clip preparation -> 64 frames = 7 windows, tasks depth + flow + dyn_mask + track_2d, 625 grid queries (spacing 0.04)
+tracked in chunks of max_queries = 128, windows batched four at a time through encoder and decoders (row f4 of SURVEY.md 8).
+
 Workloads (BASELINE.json configs): c3 = all heads, bf16, batch 4 clips per GPU (DEFAULT: BASELINE.json's metric is
 "frames/sec (all heads)", configs[2] is its single-GPU configuration and configs[3] the same work data-parallel over 8
 GPUs); c2 = depth head only, bf16, batch 1 (configs[1]).
@@ -256,12 +260,91 @@ def bench_prep(args, rank, world, device, lib):
     print(json.dumps(res))
 
 
+DEMO_TASKS = ["depth", "flow_2d_backward", "dyn_mask", "track_2d"]  # demo.py:82,99
+
+
+def bench_demo(args, rank, world, device, lib, selftest):
+    """--workload demo: large-N tracking at the demo's scale (625 queries over 7 windows, chunks of 128) next to the dense
+    heads of a 64-frame clip; one video per GPU per step (weak scaling)."""
+    from l4p_amd.data import prepare_clip
+    from tests.golden_utils import synthetic_video
+
+    cfg = ModelCfg.full()
+    model, _, sd = build_workload(list(DEMO_TASKS), 1, 64, device, rank)
+    net = model.l4p_model
+    net.task_heads["track_2d"].max_queries = 128   # demo.py:38-40
+    net.window_batch = 4                           # as demo/demo.py of this repository
+    T_out = 64
+    host = synthetic_video(1 + rank, 50, 480, 854)
+    clip = prepare_clip(torch.from_numpy(host).to(device), (T_out, 224, 224), (224, 224), spacing=0.04)
+    data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in clip.items()}
+    nq = int(data["track_2d_pointquerries_bn3"].shape[1])
+    nwin = (T_out - 16) // 8 + 1
+
+    def step():
+        with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
+            return model.forward(data, DEMO_TASKS)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    os.environ["L4P_TRACK_STREAMS"] = "0"
+    lib.l4p_prof_reset()
+    lib.l4p_prof_enable(1)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    lib.l4p_prof_enable(0)
+    if rank != 0:
+        return
+    prof = read_prof(lib)
+    fl = algorithmic_flops(cfg, DEMO_TASKS, nq, n_windows=nwin)  # per-window average
+    classes = {}
+    for name, (ms, n) in prof.items():
+        if n:
+            ent = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": n / args.steps, "avg_launch_us": round(ms / n * 1e3, 3)}
+            if fl.get(name, 0) > 0:
+                ent["tflops"] = round(fl[name] * nwin / (ms / args.steps * 1e-3) / 1e12, 2)
+            classes[name] = ent
+    dom = max((k for k in ("gemm", "conv3d", "attention") if k in classes), key=lambda k: classes[k]["ms_per_step"])
+    res = {
+        "metric": "frames/sec (depth + flow + motion-seg + 2D/3D tracks), 64-frame 224x224 clip, 625 track queries",
+        "value": round(world * T_out * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded 480x854 video, name-seeded random weights)",
+        "rccl_ranks": selftest["ranks"] if selftest.get("backend") == "nccl" else (1 if world == 1 else 0),
+        "config": {"workload": f"demo generic video (demo/demo.py:84-100): 1 clip of {T_out} frames = {nwin} windows per GPU, tasks "
+                               f"{'+'.join(DEMO_TASKS)}, {nq} grid queries in chunks of 128, windows batched 4 at a time",
+                   "queries": nq, "windows": nwin, "tasks": DEMO_TASKS},
+        "roofline": {"kernel": {"gemm": "gemm8p_kernel<0> / gemm_kernel<bf16,MODE0>", "conv3d": "gemm8p_kernel<1> / gemm_kernel<bf16,MODE1>",
+                                "attention": "attn_kernel<bf16,96,64>"}[dom], "bound": "mfma", "achieved": classes[dom]["tflops"],
+                     "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(classes[dom]["tflops"] / (PEAK_BF16_MFMA / 1e12), 4),
+                     "traffic": None, "method": "algorithmic FLOPs / HIP-event-bracketed kernel time, second pass of the same K steps",
+                     "algorithmic_flops_per_step": fl[dom] * nwin},
+        "kernel_classes": classes,
+    }
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5", "prep"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5", "prep", "demo"])
     ap.add_argument("--frames", type=int, default=256, help="c5: length of the long video")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default: 1 for c2; c3: 4 on one GPU = configs[2], "
                                                          "8 per GPU on N > 1 GPUs = configs[3]: batch 64 over 8 GPUs)")
@@ -284,6 +367,8 @@ def main():
     selftest = collective_selftest(device) if world > 1 else {"ranks": 1, "backend": None, "ok": True}
     if args.workload == "prep":
         return bench_prep(args, rank, world, device, lib)
+    if args.workload == "demo":
+        return bench_demo(args, rank, world, device, lib, selftest)
 
     cfg = ModelCfg.full()
     tasks = ["depth"] if args.workload == "c2" else list(ALL_TASKS)

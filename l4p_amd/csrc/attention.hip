@@ -390,7 +390,12 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
             });
             __builtin_amdgcn_s_setprio(0);
             if (HAS_NEXT) {
-                mx = fmaxf(mxn, __shfl_xor(mxn, 32));
+                {
+                    // lanes l and l + 32 hold the two key halves of one query: v_permlane32_swap exchanges them without the
+                    // LDS round trip (and the lgkmcnt(0) wait) of ds_bpermute: [0] = (own | lower), [1] = (upper | own)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxn), __float_as_uint(mxn), false, false);
+                    mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                }
 #ifndef ATTN_DBG_NOBARRIER
                 __syncthreads();
 #endif

@@ -358,12 +358,18 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
 // contiguous range of tiles (the caller's XCD remap) and position n of the walk is the m-tile
 //   (b, band, t, i):  i fastest inside a band of BT tiles (a few image rows), then t, then the next band
 // so the rows of planes t-1 / t / t+1 that a band needs are still in L2 when the walk moves to t+1.
+#ifdef GEMM_PROBE_VARIANTS
+__device__ int g_conv_bt_override = 0;  // (tools/probes: band size experiments)
+#endif
 __device__ __forceinline__ int conv_tile_walk(const GemmParams& p, int n, int BM, int es) {
     const int P = p.Ho * p.Wo;  // output voxels per (b, t) plane
     if (P % BM) return n;
     const int TP = P / BM;
     const long long tile_bytes = (long long)BM * p.sh * p.sw * p.Cin * es;
     int bt = (int)((2ll << 20) / 3 / (tile_bytes > 0 ? tile_bytes : 1));
+#ifdef GEMM_PROBE_VARIANTS
+    if (g_conv_bt_override > 0) bt = g_conv_bt_override;
+#endif
     if (bt > TP) bt = TP;
     if (bt < 1) bt = 1;
     while (TP % bt) --bt;  // largest divisor of TP that keeps three planes of a band within ~2 MB
@@ -528,6 +534,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     // LDS-DMA staging: one global_load_lds per 16-byte chunk; destination = wave-uniform base + lane*16
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    // conv position of the LDS-DMA stream (see issue_tile); starts at this workgroup's first k-tile (split-K: not 0)
+    int cp_kt = 0, cp_tap = 0, cp_ci0 = 0;
+    long long cp_off = 0;
+    if (MODE == 1) {
+        const int nsp = p.splitk > 1 ? p.splitk : 1;
+        cp_kt = (int)((long long)nk * ksplit / nsp);
+        cp_tap = cp_kt / kpc;
+        cp_ci0 = (cp_kt - cp_tap * kpc) * BK;
+        const int tp = cp_tap < 27 ? cp_tap : 26;
+        cp_off = (((long long)(tp / 9 - 1) * p.Hi + ((tp / 3) % 3 - 1)) * p.Wi + (tp % 3 - 1)) * p.Cin;
+    }
     auto issue_tile = [&](int kt, int buf) {
         const char* zero = (const char*)g_zero_chunk;
         if (MODE == 0) {
@@ -543,10 +560,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ws + buf * BN * 128 + (wave_u * 64 + i * NT) * 16), 16, 0, 0);
             }
         } else {
-            const int tap = kt / kpc;
-            const int ci0 = (kt - tap * kpc) * BK;
-            const int dt = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
-            const long long toff = (((long long)dt * p.Hi + dh) * p.Wi + dw) * p.Cin + ci0;
+            // (tap, channel slice) of k-tile kt, carried as counters: tiles are issued in k order, one further per call
+            while (cp_kt < kt) {
+                ++cp_kt;
+                cp_ci0 += BK;
+                if (cp_ci0 == p.Cin) {
+                    cp_ci0 = 0;
+                    ++cp_tap;
+                    const int tp = cp_tap < 27 ? cp_tap : 26;
+                    cp_off = (((long long)(tp / 9 - 1) * p.Hi + ((tp / 3) % 3 - 1)) * p.Wi + (tp % 3 - 1)) * p.Cin;
+                }
+            }
+            const int tap = cp_tap;
+            const long long toff = cp_off + cp_ci0;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const bool ok = (a_mask[i] >> tap) & 1u;

@@ -106,16 +106,40 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     const int kpc = (MODE == 1) ? (p.Cin / BK) : 1;
     const char* zero = (const char*)g_zero_chunk;
 
+    // Conv (MODE 1): k-tile kt is (tap kt / kpc, channel slice kt % kpc).  Both A streams (h = 0, 1) are staged in
+    // k-tile order, one k-tile further at every call, so (tap, channel offset, tap address offset) are carried as wave-uniform
+    // counters instead of being re-derived from kt with an integer division and 64-bit multiplies at every call (that
+    // arithmetic sat in the staging segment of every phase: ~40 instructions per call).
+    struct ConvPos {
+        int kt, tap, ci0;
+        long long off;  // byte offset of (tap, ci0) relative to the lane's centre voxel
+    } cpos[2];
+    auto conv_tap_off = [&](int tap) {
+        const int dt = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+        return ((((long long)dt * p.Hi + dh) * p.Wi + dw) * p.Cin) * 2;
+    };
+    if (MODE == 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) cpos[h] = ConvPos{0, 0, 0, conv_tap_off(0)};
+    }
     auto stage_a = [&](int h, int kt, int buf) {
         long long off;
         int tap = 0;
         if (MODE == 0) {
             off = (long long)kt * (BK * 2);
         } else {
-            tap = kt / kpc;
-            const int ci0 = (kt - tap * kpc) * BK;
-            const int dt = tap / 9 - 1, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
-            off = ((((long long)dt * p.Hi + dh) * p.Wi + dw) * p.Cin + ci0) * 2;
+            ConvPos& c = cpos[h];
+            while (c.kt < kt) {  // (one step per call in the main loop; the prologue's first calls start at 0)
+                ++c.kt;
+                c.ci0 += BK;
+                if (c.ci0 == p.Cin) {
+                    c.ci0 = 0;
+                    ++c.tap;
+                    c.off = conv_tap_off(c.tap < 27 ? c.tap : 26);
+                }
+            }
+            tap = c.tap;
+            off = c.off + (long long)c.ci0 * 2;
         }
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {

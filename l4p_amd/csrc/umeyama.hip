@@ -24,27 +24,81 @@ __device__ __forceinline__ unsigned hash_u32(unsigned x) {  // PCG-style integer
 #define QSEL_BINS 2048
 __device__ __forceinline__ unsigned qsel_key(float v) { return __float_as_uint(fmaxf(v, 0.f)); }
 
+// Depth values crowd into a handful of exponent bins, so the histogram is built per workgroup in LDS first (same-key lanes
+// of a wave are merged with a ballot before they touch the bin: one LDS atomic per distinct key of the wave for the first
+// few keys) and only the non-empty bins reach the global counters: 400 k global atomics on ~4 addresses cost 0.2 ms a pass.
 template <int SHIFT, int BITS, unsigned PMASK>
-__global__ void qsel_hist_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ ws) {
+__global__ __launch_bounds__(256) void qsel_hist_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ ws) {
+    __shared__ unsigned h[1 << BITS];
+    for (int i = threadIdx.x; i < (1 << BITS); i += 256) h[i] = 0;
+    __syncthreads();
     const unsigned prefix = ws[0];
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned k = qsel_key(x[i]);
-        if ((k & PMASK) == prefix) atomicAdd(&ws[4 + ((k >> SHIFT) & ((1u << BITS) - 1))], 1u);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i0 = blockIdx.x * (long long)blockDim.x; i0 < n; i0 += stride) {  // (wave-uniform trip count)
+        const long long i = i0 + threadIdx.x;
+        const unsigned k = i < n ? qsel_key(x[i]) : 0u;
+        bool todo = i < n && (k & PMASK) == prefix;
+        const unsigned bin = (k >> SHIFT) & ((1u << BITS) - 1);
+#pragma unroll 1
+        for (int round = 0; round < 4; ++round) {
+            const unsigned long long act = __ballot(todo);
+            if (!act) break;
+            const int leader = __ffsll((long long)act) - 1;
+            const unsigned lb = (unsigned)__shfl((int)bin, leader);
+            const bool mine = todo && bin == lb;
+            const unsigned long long grp = __ballot(mine);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[lb], (unsigned)__popcll(grp));
+            todo = todo && !mine;
+        }
+        if (todo) atomicAdd(&h[bin], 1u);  // many distinct keys in the wave: no contention to speak of
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (1 << BITS); i += 256)
+        if (h[i]) atomicAdd(&ws[4 + i], h[i]);
 }
+// one workgroup: the bin that holds the wanted rank, by a block-wide prefix sum over the bins (a single thread walking 2048
+// global counters one dependent load at a time cost 0.4 ms a pass), then the bins are cleared for the next pass
 template <int SHIFT, int BITS, bool LAST>
-__global__ void qsel_pick_kernel(unsigned* __restrict__ ws) {
-    if (threadIdx.x != 0) return;
-    unsigned rank = ws[1], b = 0;
-    for (; b < (1u << BITS) - 1; ++b) {
-        const unsigned c = ws[4 + b];
-        if (rank < c) break;
-        rank -= c;
+__global__ __launch_bounds__(256) void qsel_pick_kernel(unsigned* __restrict__ ws) {
+    constexpr int PER = (1 << BITS) / 256;
+    __shared__ unsigned scan[256];
+    const int tid = threadIdx.x;
+    unsigned c[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        c[j] = ws[4 + tid * PER + j];
+        sum += c[j];
     }
-    ws[0] |= b << SHIFT;
-    ws[1] = rank;
-    if (LAST) ws[2] = ws[4 + b];
-    for (unsigned i = 0; i < QSEL_BINS; ++i) ws[4 + i] = 0;
+    scan[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan
+        const unsigned v = tid >= o ? scan[tid - o] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const unsigned rank = ws[1], excl = scan[tid] - sum;
+    __syncthreads();  // (everyone has read ws[1] before the owner rewrites it)
+    if (sum > 0 && rank >= excl && rank < excl + sum) {
+        unsigned r = rank - excl;
+        int b = 0;
+#pragma unroll
+        for (int j = 0; j < PER - 1; ++j)
+            if (b == j && r >= c[j]) {
+                r -= c[j];
+                b = j + 1;
+            }
+        ws[0] |= (unsigned)(tid * PER + b) << SHIFT;
+        ws[1] = r;
+        if (LAST) {
+            unsigned cb = c[0];
+#pragma unroll
+            for (int j = 1; j < PER; ++j) cb = b == j ? c[j] : cb;
+            ws[2] = cb;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) ws[4 + tid * PER + j] = 0;
 }
 __global__ void qsel_next_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ ws) {
     const unsigned v = ws[0];
@@ -372,13 +426,13 @@ int l4p_quantile(l4p_stream s_, const float* x, long long n, float q, unsigned* 
     // (init is tiny and lives on the host stack: three 4-byte memsets keep the call free of host -> device copies)
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ws + 1), (int)init[1], 1, s));
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ws + 3), (int)init[3], 1, s));
-    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    const int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
     hipLaunchKernelGGL((qsel_hist_kernel<21, 11, 0u>), dim3(grid), dim3(256), 0, s, x, n, ws);
-    hipLaunchKernelGGL((qsel_pick_kernel<21, 11, false>), dim3(1), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL((qsel_pick_kernel<21, 11, false>), dim3(1), dim3(256), 0, s, ws);
     hipLaunchKernelGGL((qsel_hist_kernel<10, 11, 0xFFE00000u>), dim3(grid), dim3(256), 0, s, x, n, ws);
-    hipLaunchKernelGGL((qsel_pick_kernel<10, 11, false>), dim3(1), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL((qsel_pick_kernel<10, 11, false>), dim3(1), dim3(256), 0, s, ws);
     hipLaunchKernelGGL((qsel_hist_kernel<0, 10, 0xFFFFFC00u>), dim3(grid), dim3(256), 0, s, x, n, ws);
-    hipLaunchKernelGGL((qsel_pick_kernel<0, 10, true>), dim3(1), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL((qsel_pick_kernel<0, 10, true>), dim3(1), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(qsel_next_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
     hipLaunchKernelGGL(qsel_finish_kernel, dim3(1), dim3(64), 0, s, ws, pos - lo_f, out);
     HIP_TRY(hipGetLastError());

@@ -1,5 +1,5 @@
 """Per-shape kernel time table for one bench workload (event profiler, l4p_prof_detail).
-usage: python tools/prof_detail.py [c2|c3|prep|demo] [steps]   (demo: 64 frames, 625 queries, depth+flow+mask+tracks)"""
+usage: python tools/prof_detail.py [c2|c3|c5|prep|demo] [steps]   (demo: 64 frames, 625 queries, depth+flow+mask+tracks)"""
 import ctypes as C
 import os
 import sys
@@ -47,6 +47,16 @@ def main():
             torch.cuda.synchronize()
             print(f"demo forward: {(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr)
             return out
+    elif wl == "c5":  # one 256-frame video, all heads, one rank (bench.py --workload c5)
+        from l4p_amd.parallel import forward_windows_sharded
+
+        tasks = list(bench.ALL_TASKS)
+        model, data, _ = bench.build_workload(tasks, 1, 64, dev, frames=256)
+        model.l4p_model.always_use_windowed_version = True
+
+        def run():
+            with torch.no_grad():
+                return forward_windows_sharded(model.l4p_model, data, tasks, 0, 1, group=4)
     else:
         tasks = ["depth"] if wl == "c2" else list(bench.ALL_TASKS)
         B = 1 if wl == "c2" else 4
