@@ -7,6 +7,8 @@ and binds it into libl4p_hip.so.
 """
 from __future__ import annotations
 
+import os
+
 from collections import OrderedDict
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -210,6 +212,18 @@ class L4P_VideoMAE(torch.nn.Module):
         whose heavy work already ran (possibly on another GPU)."""
         out: Dict[str, Any] = {"enc_features_bpc_2dlist": feats2d}
         joint_possible = "depth" in tasks and "camray" in tasks
+        trk = self.task_heads["track_2d"] if "track_2d" in tasks else None
+        if trk is not None and hasattr(trk, "join_streams"):
+            # its per-clip streams run beside the dense heads and are joined below (L4P_TRACK_DEFER=0: join at once, A/B aid)
+            trk.defer_join = len(tasks) > 1 and os.environ.get("L4P_TRACK_DEFER", "1") != "0"
+        try:
+            return self._stitch_windows(out, feats2d, data, tasks, time_strides, joint_possible)
+        finally:
+            if trk is not None and hasattr(trk, "join_streams"):
+                trk.join_streams()
+                trk.defer_join = False
+
+    def _stitch_windows(self, out, feats2d, data, tasks, time_strides, joint_possible):
         if self.joint_alignment and joint_possible:
             from .task_heads.dense_heads import joint_windowed_estimation
 

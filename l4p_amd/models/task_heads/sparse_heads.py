@@ -379,13 +379,28 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                     self._ws_slot = b + 1  # concurrent clips: one native workspace each
                     run_clip(b)
             self._ws_slot = 0
-            for b in range(B):
-                main.wait_stream(pool[b])
+            if getattr(self, "defer_join", False):
+                # the caller (L4P_VideoMAE.stitch_windows) runs the dense heads on the main stream meanwhile and joins the
+                # clip streams before it returns: the tracker's ~130 tiny dependent launches per clip fill the gaps of the
+                # decoders' large kernels instead of serialising in front of them
+                self._pending = (main, pool[:B])
+            else:
+                for b in range(B):
+                    main.wait_stream(pool[b])
         else:
             for b in range(B):
                 run_clip(b)
         return {f"{self.task_name}_traj_est_bn2t": traj_all, f"{self.task_name}_vis_est_bn1t": vis_all,
                 f"{self.task_name}_depth_est_bn1t": dep_all}
+
+    def join_streams(self) -> None:
+        """Make the stream that launched the tracker wait for the clip streams (no-op when nothing is pending)."""
+        pend = getattr(self, "_pending", None)
+        if pend is not None:
+            main, pool = pend
+            for st in pool:
+                main.wait_stream(st)
+            self._pending = None
 
     def forward(self, enc_features_bpc_list, track_2d_pointquerries_bn3: torch.Tensor, track_2d_pointlabels_bn: torch.Tensor,
                 track_2d_promptfeatures_bnc: Optional[torch.Tensor] = None,

@@ -206,3 +206,26 @@ def test_native_window_call_equals_python_composition(dev, mini, precision, monk
     torch.cuda.synchronize()
     for k in keys:
         assert a[k].shape[0] == 2 and torch.equal(a[k], b[k]), k
+
+
+def test_tracker_streams_beside_dense_heads_equal_serial(dev, mini, monkeypatch):
+    """B > 1 with dense heads in the task list: the clips' trackers keep running on their own streams WHILE the dense decoders
+    run on the main stream (the join is deferred to the end of L4P_VideoMAE.stitch_windows).  Every output must equal the
+    fully serial order bit for bit, and repeated forwards must agree (no buffer is recycled under a running stream)."""
+    cfg, sd = mini
+    model = build(cfg, sd, "bf16")
+    b1 = make_batch(16, 6)
+    batch = {k: (torch.cat([v, v.flip(-1) if k == "rgb_b3thw" else v, v.flip(-2) if k == "rgb_b3thw" else v], dim=0)
+                 if torch.is_tensor(v) else v) for k, v in b1.items()}
+    tasks = ["track_2d", "depth", "flow_2d_backward", "camray"]
+    keys = ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t", "depth_est_b1thw",
+            "flow_2d_backward_est_b2thw", "traj3d_est_b16t"]
+    with torch.no_grad():
+        monkeypatch.setenv("L4P_TRACK_STREAMS", "1")
+        runs = [model.forward({k: v.clone() for k, v in batch.items()}, tasks) for _ in range(3)]
+        monkeypatch.setenv("L4P_TRACK_STREAMS", "0")
+        serial = model.forward({k: v.clone() for k, v in batch.items()}, tasks)
+    torch.cuda.synchronize()
+    for k in keys:
+        for r in runs:
+            assert torch.equal(r[k], serial[k]), k
