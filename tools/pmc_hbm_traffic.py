@@ -3,7 +3,7 @@
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out/fetch -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out/write -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof
-  python tools/pmc_hbm_traffic.py out/fetch out/write profiles/r01_c3_hbm_traffic
+  python tools/pmc_hbm_traffic.py out/fetch out/write profiles/r02_c3_hbm_traffic
 
 Units (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE count kilobytes... on gfx950 FETCH_SIZE
 under-reports by 2x (checked in-run on a kernel whose input size is known).  Kernel classes as in csrc/prof.hpp."""
@@ -60,7 +60,7 @@ def main():
             cls[c][1] += rd * n
             cls[c][2] += wt * n
     with open(out + ".md", "w") as f:
-        f.write("# HBM traffic per launch (PMC), r01 c3, final tree\n\n")
+        f.write(f"# HBM traffic per launch (PMC), {os.path.basename(out)}, final tree\n\n")
         f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) of `python bench.py --steps 1 "
                 "--warmup 1 --no-cpu-baseline --no-prof` (c3, 2 steps); FETCH_SIZE doubled per the gfx950 correction of "
                 "MI355X_MICROARCH.md, WRITE_SIZE as reported.\n\n| kernel | launches | HBM read MB/launch | HBM write MB/launch |\n|---|---|---|---|\n")
