@@ -342,7 +342,11 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
                     bf16x8 o;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
+#ifdef GEMM_DBG_NOSTORE  // (tools/probes: epilogue arithmetic without the output traffic)
+                    asm volatile("" ::"v"(o), "v"(op));
+#else
                     *(bf16x8*)op = o;
+#endif
                 } else {
                     *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
                     *(f32x4*)((float*)op + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
@@ -379,6 +383,150 @@ __device__ __forceinline__ int conv_tile_walk(const GemmParams& p, int n, int BM
     r /= p.To;
     const int band = r % (TP / bt), b = r / (TP / bt);
     return (b * p.To + t) * TP + band * bt + i;
+}
+
+// Lean epilogue for the plain dense family (L4P_EPI_DENSE, no row maps, no broadcast residual): what the large GEMMs and
+// convs of the 8-phase kernel mostly run.  The generic row body above decides every flavour (scatter forms, row maps,
+// residual kinds, activations) at run time inside the row loop - ~600 issued instructions per row with SGPR spills,
+// measured at 9 us per 256 x 256 tile for a bias + bf16 store (27 of fc1's 157 us at batch 4).  Here activation and
+// residual kind are template parameters, the loop body is a few dozen instructions, and the residual of row i + 1 is
+// requested before row i is finished (one exposed round trip per tile instead of one per row).
+// RES: 0 none, 1 float (p.res1 [+ p.res2]), 2 T.
+template <typename T, int TM, int TN, int ACT, int RES>
+__device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0, int li,
+                                                    int kg) {
+    constexpr int ES = sizeof(T);
+    constexpr int NV = 4 * TN, NG = NV / 8;
+    const int nb = n_wave0 + NV * kg;
+    bool gok[NG];
+    float bv[NV];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        gok[g] = nb + 8 * g < p.N;  // N % 8 == 0
+        const bool ok = p.bias && gok[g];
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 b0 = ok ? *(const f32x4*)(p.bias + nb + 8 * g) : z, b1 = ok ? *(const f32x4*)(p.bias + nb + 8 * g + 4) : z;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bv[8 * g + q] = b0[q];
+            bv[8 * g + 4 + q] = b1[q];
+        }
+    }
+    const bool two = RES != 0 && p.res2 != nullptr;
+    // residual registers of one row: float: NV values per residual; T: NV / 2 dwords per residual
+    f32x4 rf[RES == 1 ? 2 * NG : 1][2];
+    u32x4 rt[RES == 2 ? NG : 1][2];
+    auto load_res = [&](int m) {
+        const long long roff = (long long)m * p.ldr + nb;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (!gok[g]) continue;
+            if (RES == 1) {
+                rf[2 * g][0] = *(const f32x4*)((const float*)p.res1 + roff + 8 * g);
+                rf[2 * g + 1][0] = *(const f32x4*)((const float*)p.res1 + roff + 8 * g + 4);
+                if (two) {
+                    rf[2 * g][1] = *(const f32x4*)((const float*)p.res2 + roff + 8 * g);
+                    rf[2 * g + 1][1] = *(const f32x4*)((const float*)p.res2 + roff + 8 * g + 4);
+                }
+            } else if (RES == 2) {
+                rt[g][0] = *(const u32x4*)((const T*)p.res1 + roff + 8 * g);
+                if (two) rt[g][1] = *(const u32x4*)((const T*)p.res2 + roff + 8 * g);
+            }
+        }
+    };
+    int m_next = m_wave0 + li;
+    if (RES != 0 && m_next < p.M) load_res(m_next);
+    // fully unrolled over the TM rows: the body is lean enough for that (~40 instructions a row), and a rolled loop makes
+    // hipcc index the accumulator rows through scratch memory (one round trip per row: measured slower than the generic body)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float v[NV];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
+        const int m = m_wave0 + i * 16 + li;
+        if (m >= p.M) continue;  // (rows only run out at the bottom of the matrix: nothing after this row either)
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            float x = v[c] + bv[c];
+            if (ACT == ACT_GELU)
+                x = gelu_for<T>(x);
+            else if (ACT == ACT_RELU)
+                x = fmaxf(x, 0.f);
+            v[c] = x;
+        }
+        if (RES == 1) {
+#pragma unroll
+            for (int g = 0; g < 2 * NG; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[4 * g + q] += two ? rf[g][0][q] + rf[g][1][q] : rf[g][0][q];
+        } else if (RES == 2) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (ES == 2) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, rt[g][0]), b = __builtin_bit_cast(bf16x8, rt[g][1]);
+                        v[8 * g + q] += two ? (float)a[q] + (float)b[q] : (float)a[q];
+                    }
+                }
+        }
+        // the next row's residual is requested now: its values are copies in registers, so an in-place update of THIS row
+        // (out aliasing res1) cannot reach them, and rows never overlap
+        if (RES != 0 && i + 1 < TM && m + 16 < p.M) load_res(m + 16);
+        const long long off = (long long)m * p.ldc + nb;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (!gok[g]) continue;
+            const float* vv = v + 8 * g;
+            if (p.out_f32) {
+                float* op = p.out_f32 + off + 8 * g;
+                *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+                *(f32x4*)(op + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
+            }
+            if (ES == 2) {
+                if (p.out_relu_T) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)fmaxf(vv[q], 0.f);
+                    *(bf16x8*)((T*)p.out_relu_T + off + 8 * g) = o;
+                }
+                if (p.out_T) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
+#ifdef GEMM_DBG_NOSTORE
+                    asm volatile("" ::"v"(o));
+#else
+                    *(bf16x8*)((T*)p.out_T + off + 8 * g) = o;
+#endif
+                }
+            }
+        }
+    }
+}
+
+// run-time selection of the specialisation (wave-uniform); false = not a plain dense epilogue, use the generic one
+template <typename T, int TM, int TN>
+__device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0,
+                                                             int li, int kg) {
+    static_assert(sizeof(T) == 2, "bf16 kernels only");
+    if (p.epi != EPI_DENSE || p.c_gr > 0 || p.res_mod > 0 || (p.res1 && p.ldr != p.ldc && false)) return false;
+    const int res = !p.res1 ? 0 : (p.res_f32 ? 1 : 2);
+#define L4P_EPI_CASE(A, R)                                                                    \
+    if (p.act == A && res == R) {                                                             \
+        gemm_epilogue_dense<T, TM, TN, A, R>(p, acc, m_wave0, n_wave0, li, kg);               \
+        return true;                                                                          \
+    }
+    L4P_EPI_CASE(ACT_NONE, 0)
+    L4P_EPI_CASE(ACT_GELU, 0)
+    L4P_EPI_CASE(ACT_RELU, 0)
+    L4P_EPI_CASE(ACT_NONE, 1)
+    L4P_EPI_CASE(ACT_NONE, 2)
+    L4P_EPI_CASE(ACT_RELU, 2)
+#undef L4P_EPI_CASE
+    return false;
 }
 
 // GLDS = true: tiles are staged with global_load_lds (LDS-DMA, no VGPR round trip, no ds_write); the LDS image is

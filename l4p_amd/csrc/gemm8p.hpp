@@ -23,6 +23,9 @@
 #pragma once
 #include "gemm.hpp"
 
+#ifdef GEMM_PROBE_VARIANTS
+__device__ int g_tile_gm = 0;
+#endif
 template <int MODE, int WR, int WC>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
@@ -50,9 +53,34 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = ntiles >> 3, r = ntiles & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    int mt = tile / ntn;
+    // Linear order of the tiles: column BANDS of <= 8 tile columns, inside a band m-major with the band's columns fastest.
+    // The ~32 tiles an XCD runs at a time are consecutive in this order, i.e. a block of ~(32 / band width) tile rows x the
+    // band: they share that many A panels and <= 8 W panels, all walking k together, so each panel k-tile is fetched into the
+    // XCD's L2 once for the whole block.  (Plain row-major order made a round touch every W panel of a wide N: 2 + 24 panels
+    // for the MLP's first linear instead of 4 + 8; PMC: 2.4x the operand bytes fetched.)
+    int mt, nt_;
+    {
+        const int nb = (ntn + 7) >> 3, bw = (ntn + nb - 1) / nb, full = (nb - 1) * ntm * bw;
+#ifdef GEMM_PROBE_VARIANTS
+        const bool banded = g_tile_gm >= 0;
+#else
+        const bool banded = true;
+#endif
+        if (!banded || nb == 1) {
+            mt = tile / ntn;
+            nt_ = tile % ntn;
+        } else if (tile < full) {
+            const int band = tile / (ntm * bw), rem = tile - band * (ntm * bw);
+            mt = rem / bw;
+            nt_ = band * bw + rem % bw;
+        } else {
+            const int w = ntn - (nb - 1) * bw, rem = tile - full;  // last band: the remaining w columns
+            mt = rem / w;
+            nt_ = (nb - 1) * bw + rem % w;
+        }
+    }
     if (MODE == 1) mt = conv_tile_walk(p, mt, BM, 2);
-    const int m0 = mt * BM, n0 = (tile % ntn) * BN;
+    const int m0 = mt * BM, n0 = nt_ * BN;
 
     // ---- staging sources (one 16-byte chunk per lane per pass) ----
     const int srow = tid >> 3, slot = tid & 7;
@@ -269,9 +297,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
+#ifdef GEMM_DBG_ONLY_FAST  // (probe: the kernel with nothing but the lean bias + store epilogue)
+    gemm_epilogue_dense<T, TM, TN, ACT_NONE, 0>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
+    return;
+#endif
     if (p.epi == EPI_MASKDOT)
         gemm_epilogue_maskdot<T, TM, TN>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
-    else
+    else if (!gemm_epilogue_dense_dispatch<T, TM, TN>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg))
         gemm_epilogue<T, TM, TN, true>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
 #endif
 }

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <vector>
+#include <cstdlib>
 bool g_prof_on = false;
 void prof_begin(int, hipStream_t, const char*) {}
 void prof_end(int, hipStream_t) {}
@@ -16,10 +17,12 @@ void l4p_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprin
 #define GEMM_FN launch_gemm_bf16
 #include "../../l4p_amd/csrc/gemm_launch.inc"
 int main(int argc, char** argv) {
+    { const int gm = getenv("TILE_GM") ? atoi(getenv("TILE_GM")) : 0; hipMemcpyToSymbol(HIP_SYMBOL(g_tile_gm), &gm, sizeof(int)); }
     struct Shape { int M, N, K; const char* name; } shapes[] = {{2048, 4608, 1408, "qkv"}, {2048, 1408, 1408, "proj"},
         {2048, 6144, 1408, "fc1"}, {2048, 1408, 6144, "fc2"}, {8192, 6144, 1408, "fc1_b4"}, {8192, 1408, 6144, "fc2_b4"},
         {131072, 704, 1408, "trk_kv"}, {131072, 2816, 1408, "trk_up0"}, {32768, 6144, 1408, "fc1_b16"}, {8192, 4608, 1408, "qkv_b4"}, {8192, 1408, 1408, "proj_b4"}, {131072, 1408, 704, "trk_i2t"}, {1048576, 704, 352, "trk_up1"}, {262144, 256, 256, "dpt_1x1"}, {16384, 6144, 1408, "fc1_b8"}, {16384, 1408, 6144, "fc2_b8"}, {16384, 4608, 1408, "qkv_b8"}, {16384, 1408, 1408, "proj_b8"}};
     for (auto& s : shapes) {
+        if (getenv("SHAPE") && strcmp(getenv("SHAPE"), s.name)) continue;
         const size_t na = (size_t)s.M * s.K, nw = (size_t)(s.N + 255) / 256 * 256 * s.K, nc = (size_t)s.M * s.N;
         std::vector<unsigned short> h(na > nw ? na : nw);
         for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3C00 + (unsigned short)(((i * 2654435761u) >> 20) & 0x3FF) + ((i & 1) << 15);
