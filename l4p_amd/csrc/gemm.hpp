@@ -507,12 +507,77 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
     }
 }
 
+// Lean form of the L4P_EPI_QKV epilogue (bf16): what a lane's two 8-column groups are (q / k / v, head, dim) does not
+// depend on the row, so it is decided once; a row costs one division (m -> batch, token), the bias, the q scale and its stores.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_qkv(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0, int li, int kg) {
+    static_assert(sizeof(T) == 2, "bf16 kernels only");
+    constexpr int NV = 4 * TN, NG = NV / 8, KVB = 64;
+    const int nb = n_wave0 + NV * kg, HD = p.H * p.Dp;
+    int kind[NG];          // 0 q, 1 k, 2 v, -1 out of range
+    long long cbase[NG];   // column part of the element offset
+    int kflip[NG];
+    float bv[NV], qs[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int n = nb + 8 * g;
+        kind[g] = n >= p.N ? -1 : (n < HD ? 0 : (n < 2 * HD ? 1 : 2));
+        qs[g] = (kind[g] == 0 && p.q_scale != 0.f) ? p.q_scale : 1.f;
+        kflip[g] = 0;
+        cbase[g] = n;
+        if (kind[g] == 1) {  // K tile order: 8-element groups [b][h][kv block][k-step][key][half ^ ((key >> 3) & 1)]
+            const int nk = n - HD, h = nk / p.Dp, d0 = nk - h * p.Dp;
+            kflip[g] = (d0 >> 3) & 1;
+            cbase[g] = ((long long)h * (p.S / KVB) * (p.Dp / 16) + (d0 >> 4)) * KVB;  // + (b*H*(S/KVB) + kb)*(Dp/16)*KVB + key
+        } else if (kind[g] == 2) {  // V^T: vt[((b*H + h)*Dp + d)*S + s]
+            const int nv = n - 2 * HD, h = nv / p.Dp, d = nv - h * p.Dp;
+            cbase[g] = ((long long)h * p.Dp + d) * p.S;
+        }
+        const bool ok = p.bias && kind[g] >= 0;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 b0 = ok ? *(const f32x4*)(p.bias + n) : z, b1 = ok ? *(const f32x4*)(p.bias + n + 4) : z;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bv[8 * g + q] = b0[q];
+            bv[8 * g + 4 + q] = b1[q];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m_wave0 + i * 16 + li;
+        if (m >= p.M) continue;
+        const int b = m / p.S, s_ = m - b * p.S;
+        const int kb = s_ / KVB, key = s_ - kb * KVB;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (kind[g] < 0) continue;
+            bf16x8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = (bf16_t)((acc[i][2 * g + q / 4][q % 4] + bv[8 * g + q]) * qs[g]);
+            if (kind[g] == 0) {
+                *(bf16x8*)((T*)p.out_T + (long long)m * p.ldc + cbase[g]) = o;
+            } else if (kind[g] == 1) {
+                const long long g8 = (cbase[g] + ((long long)b * p.H * (p.S / KVB) + kb) * (p.Dp / 16) * KVB + key) * 2 + (kflip[g] ^ ((key >> 3) & 1));
+                *(bf16x8*)((T*)p.k_tiled + g8 * 8) = o;
+            } else {
+                T* vp = (T*)p.vt + (long long)b * p.H * p.Dp * p.S + cbase[g] + s_;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vp[(long long)q * p.S] = o[q];
+            }
+        }
+    }
+}
+
 // run-time selection of the specialisation (wave-uniform); false = not a plain dense epilogue, use the generic one
 template <typename T, int TM, int TN>
 __device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0,
                                                              int li, int kg) {
     static_assert(sizeof(T) == 2, "bf16 kernels only");
-    if (p.epi != EPI_DENSE || p.c_gr > 0 || p.res_mod > 0 || (p.res1 && p.ldr != p.ldc && false)) return false;
+    if (p.epi == EPI_QKV && !p.res1 && p.act == ACT_NONE && p.c_gr == 0) {
+        gemm_epilogue_qkv<T, TM, TN>(p, acc, m_wave0, n_wave0, li, kg);
+        return true;
+    }
+    if (p.epi != EPI_DENSE || p.c_gr > 0 || p.res_mod > 0) return false;
     const int res = !p.res1 ? 0 : (p.res_f32 ? 1 : 2);
 #define L4P_EPI_CASE(A, R)                                                                    \
     if (p.act == A && res == R) {                                                             \
