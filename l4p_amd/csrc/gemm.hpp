@@ -947,6 +947,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         gemm_epilogue_maskdot<T, TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), li, kg);
         return;
     }
+    if constexpr (ES == 2) {  // plain dense / QKV epilogues: the lean specialisations
+        if (gemm_epilogue_dense_dispatch<T, TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), li, kg)) return;
+    }
     gemm_epilogue<T, TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), li, kg);
 }
 
