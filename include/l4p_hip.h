@@ -129,6 +129,9 @@ typedef struct l4p_gemm_desc {
      * head_dim^-0.5 * log2(e) so that the scores leave the attention MFMA in the exp2 domain (see l4p_attention).
      * 0 is treated as 1. */
     float q_scale;
+    /* tuning aid, normally 0.  bit 0: use the generic run-time-dispatched epilogue even where a lean specialisation exists
+     * (set by the launcher when L4P_EPI_GENERIC=1: in-run A/B of the two forms). */
+    int tuning;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);

@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
         ("k_tiled", C.c_void_p),
         ("splitk", C.c_int), ("partial", C.c_void_p),
         ("hyper", C.c_void_p), ("hyper_rows", C.c_int),
-        ("q_scale", C.c_float),
+        ("q_scale", C.c_float), ("tuning", C.c_int),
     ]
 
 

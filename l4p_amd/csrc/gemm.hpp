@@ -568,13 +568,76 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmParams& p, f32x4 (&a
     }
 }
 
+// Lean form of the L4P_EPI_CONVT epilogue (ConvTranspose3d with kernel == stride, bf16 output, bias, no activation):
+// the tap / output-channel part of the scatter offset is per column group, the voxel part per row.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_convt(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0, int li, int kg) {
+    static_assert(sizeof(T) == 2, "bf16 kernels only");
+    constexpr int NV = 4 * TN, NG = NV / 8;
+    const int nb = n_wave0 + NV * kg;
+    bool gok[NG];
+    long long coff[NG];
+    float bv[NV];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int n = nb + 8 * g;
+        gok[g] = n < p.N;
+        const int tap = n / p.Cout, co = n - tap * p.Cout;
+        const int dw = tap % p.kw, dh = (tap / p.kw) % p.kh, dt = tap / (p.kw * p.kh);
+        coff[g] = (((long long)dt * (p.Hi * p.kh) + dh) * (p.Wi * p.kw) + dw) * p.Cout + co;
+        const bool ok = p.bias && gok[g];
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 b0 = ok ? *(const f32x4*)(p.bias + n) : z, b1 = ok ? *(const f32x4*)(p.bias + n + 4) : z;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bv[8 * g + q] = b0[q];
+            bv[8 * g + 4 + q] = b1[q];
+        }
+    }
+    const bool pow2 = ((p.Wi & (p.Wi - 1)) | (p.Hi & (p.Hi - 1)) | (p.Ti & (p.Ti - 1))) == 0;
+    const int sw = __builtin_ctz(p.Wi), sh = __builtin_ctz(p.Hi), st = __builtin_ctz(p.Ti);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m_wave0 + i * 16 + li;
+        if (m >= p.M) continue;
+        int wi, hi, ti, b;
+        if (pow2) {
+            wi = m & (p.Wi - 1);
+            hi = (m >> sw) & (p.Hi - 1);
+            ti = (m >> (sw + sh)) & (p.Ti - 1);
+            b = m >> (sw + sh + st);
+        } else {
+            wi = m % p.Wi;
+            int r = m / p.Wi;
+            hi = r % p.Hi;
+            r /= p.Hi;
+            ti = r % p.Ti;
+            b = r / p.Ti;
+        }
+        const long long rowoff = ((((long long)b * p.Ti + ti) * p.kt * (p.Hi * p.kh) + hi * p.kh) * (p.Wi * p.kw) + wi * p.kw) * p.Cout;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (!gok[g]) continue;
+            bf16x8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = (bf16_t)(acc[i][2 * g + q / 4][q % 4] + bv[8 * g + q]);
+            *(bf16x8*)((T*)p.out_T + rowoff + coff[g]) = o;
+        }
+    }
+}
+
 // run-time selection of the specialisation (wave-uniform); false = not a plain dense epilogue, use the generic one
 template <typename T, int TM, int TN>
 __device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0,
                                                              int li, int kg) {
     static_assert(sizeof(T) == 2, "bf16 kernels only");
+    if (p.tuning & 1) return false;
     if (p.epi == EPI_QKV && !p.res1 && p.act == ACT_NONE && p.c_gr == 0) {
         gemm_epilogue_qkv<T, TM, TN>(p, acc, m_wave0, n_wave0, li, kg);
+        return true;
+    }
+    if (p.epi == EPI_CONVT && !p.res1 && p.act == ACT_NONE && p.out_T && !p.out_f32 && !p.out_relu_T) {
+        gemm_epilogue_convt<T, TM, TN>(p, acc, m_wave0, n_wave0, li, kg);
         return true;
     }
     if (p.epi != EPI_DENSE || p.c_gr > 0 || p.res_mod > 0) return false;
