@@ -17,7 +17,8 @@ EPI_DENSE, EPI_QKV, EPI_CONVT, EPI_MASKDOT = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libl4p_hip.so")
+# L4P_HIP_LIB: another build of the same library (tuning aid: A/B of two builds inside one GPU call)
+LIB_PATH = os.environ.get("L4P_HIP_LIB") or os.path.join(_HERE, "lib", "libl4p_hip.so")
 
 
 class GemmDesc(C.Structure):

@@ -67,20 +67,15 @@ __device__ __forceinline__ void gemm_epilogue_maskdot(const GemmParams& p, f32x4
     }
     int hq = -1;
     const bool writer = NV == 16 ? (kg & 1) == 0 : kg == 0;
-#pragma nounroll
+    // fully unrolled over the rows (static accumulator indexing; rolled with a row switch it measured 8 % slower: 1123 vs 1032 us
+    // on the c3 shape)
+#pragma unroll
     for (int i = 0; i < TM; ++i) {
         float v[NV];
-#define L4P_ACC_ROW(I)                                                                                   \
-    case I:                                                                                              \
-        if (I < TM) {                                                                                    \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[I < TM ? I : 0][j][r]; \
-        }                                                                                                \
-        break;
-        switch (i) {
-            L4P_ACC_ROW(0) L4P_ACC_ROW(1) L4P_ACC_ROW(2) L4P_ACC_ROW(3) L4P_ACC_ROW(4) L4P_ACC_ROW(5) L4P_ACC_ROW(6) L4P_ACC_ROW(7)
-        }
-#undef L4P_ACC_ROW
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
         const int m = m_wave0 + i * 16 + li;
         const bool ok = m < p.M;
         const int qn = (ok ? m : p.M - 1) / p.hyper_rows;
