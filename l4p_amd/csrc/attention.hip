@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         const int cur = it & 1;
 #ifndef ATTN_DBG_NOLOAD  // (tools/probes/attn_variants.hip: compute-only timing)
+#ifdef ATTN_DMA_IN_SLOTS_ALL  // (probe)
+        constexpr bool DMA_IN_SLOTS = HS;
+#else
         constexpr bool DMA_IN_SLOTS = HS && SPLIT > 1;  // measured: +4 % for the KV-split (batch 1) form, -2 % otherwise
+#endif
         if (!DMA_IN_SLOTS) {
             if (it + 2 < nit) issue_k((it + 2) * SPLIT + grp, cur);  // K_{it} (ring slot cur) was consumed last iteration
             if (HAS_NEXT) issue_v((it + 1) * SPLIT + grp, cur ^ 1);  // V_{it-1} (slot cur^1) was consumed last iteration

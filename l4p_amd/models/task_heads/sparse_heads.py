@@ -320,6 +320,11 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         B = track_2d_pointquerries_bn3.shape[0]
         N = track_2d_pointquerries_bn3.shape[1]
         T = int(time_strides[-1]) + ws
+        if N == 0:  # no queries: the reference's buffers with an empty query axis (sparse_heads.py:233-239), no kernel to launch
+            z = dict(dtype=torch.float32, device=dev)
+            return {f"{self.task_name}_traj_est_bn2t": torch.zeros(B, 0, 2, T, **z),
+                    f"{self.task_name}_vis_est_bn1t": torch.full((B, 0, 1, T), -10.0, **z),
+                    f"{self.task_name}_depth_est_bn1t": torch.zeros(B, 0, 1, T, **z)}
         P, Cc = cfg.tokens, cfg.dim
         f32 = dict(dtype=torch.float32, device=dev)
         traj_all = torch.zeros(B, N, 2, T, **f32)

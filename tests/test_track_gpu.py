@@ -229,3 +229,23 @@ def test_tracker_streams_beside_dense_heads_equal_serial(dev, mini, monkeypatch)
     for k in keys:
         for r in runs:
             assert torch.equal(r[k], serial[k]), k
+
+
+def test_edge_cases_no_queries_and_one_query(dev, mini):
+    """Empty and minimal query sets: N = 0 returns the reference's initial buffers with an empty query axis (no launch with an
+    empty grid), N = 1 runs (no shared-key shortcut: one track) and equals row 0 of a larger run to float rounding."""
+    cfg, sd = mini
+    model = build(cfg, sd, "32-true")
+    b = make_batch(32, 5)
+    empty = {k: (v[:, :0].clone() if k.startswith("track_2d") else v.clone()) for k, v in b.items()}
+    with torch.no_grad():
+        o0 = model.forward(empty, ["track_2d", "depth"])
+        one = {k: (v[:, :1].clone() if k.startswith("track_2d") else v.clone()) for k, v in b.items()}
+        o1 = model.forward(one, ["track_2d"])
+        o5 = model.forward({k: v.clone() for k, v in b.items()}, ["track_2d"])
+    torch.cuda.synchronize()
+    assert tuple(o0["track_2d_traj_est_bn2t"].shape) == (1, 0, 2, 32) and tuple(o0["track_2d_vis_est_bn1t"].shape) == (1, 0, 1, 32)
+    assert tuple(o0["depth_est_b1thw"].shape) == (1, 1, 32, 224, 224)
+    for k in ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"):
+        a, r = o1[k][:, 0].float().cpu(), o5[k][:, 0].float().cpu()
+        assert (a - r).abs().max() <= 1e-4 * r.abs().max() + 1e-6, k
