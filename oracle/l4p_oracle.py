@@ -175,6 +175,18 @@ def lstsq_affine_apply(pred: Tensor, sol: Tensor) -> Tensor:
     return safe_inverse(sol[:, 0].reshape(shp) * safe_inverse(pred) + sol[:, 1].reshape(shp))
 
 
+def linear_mean_solve(pred: Tensor, target: Tensor) -> Tensor:
+    """LinearAligner(pre_post_fn='inverse', method='mean').solve (aligner.py:91-109): mean of 1/target over (1/pred + 1e-8)."""
+    a = safe_inverse(pred).reshape(pred.shape[0], -1)
+    b = safe_inverse(target).reshape(target.shape[0], -1)
+    return torch.mean(b / (a + 1e-8), dim=1)
+
+
+def linear_mean_apply(pred: Tensor, scale: Tensor) -> Tensor:
+    """LinearAligner.apply (aligner.py:111-118)."""
+    return safe_inverse(scale.reshape((scale.shape[0],) + (1,) * (pred.ndim - 1)) * safe_inverse(pred))
+
+
 def plucker_to_point_direction(rays_b6thw: Tensor) -> Tuple[Tensor, Tensor]:
     """geometry_utils.py:308-328."""
     d = rays_b6thw[:, :3]
@@ -451,6 +463,7 @@ class OracleModel:
         self.max_queries = max_queries
         self.seam = seam  # how the multi-window joint alignment draws its samples (oracle/joint_oracle.py)
         self.always_use_windowed_version = True  # configs/model.yaml:19; False: a 16-frame clip takes forward_single_window
+        self.depth_align_type = "affine"  # configs/model.yaml (default of VideoMAEDepthDPTHead); "linear": LinearAligner mean
         self.seam_log: list = []
         # actpost / fusion scale factors: dense_heads.py:30-31 and :269-271
         self._actpost = lambda t: ((1, 0, 0), (1, 0, 0), (0, 0, 0), (-1, -1, -1)) if t == "camray" else ((1, 2, 2), (1, 1, 1), (0, 0, 0), (-1, -1, -1))
@@ -492,8 +505,11 @@ class OracleModel:
                 buf = torch.zeros(*shp)
             if wi > 0 and task == "depth":
                 ov = int(strides[wi - 1]) + ws - st
-                sol = lstsq_affine_solve(out[:, :, :ov], buf[:, :, st:st + ov])
-                out = lstsq_affine_apply(out, sol)
+                if self.depth_align_type == "linear":  # VideoMAEDepthDPTHead(align_type="linear"), dense_heads.py:158,166
+                    out = linear_mean_apply(out, linear_mean_solve(out[:, :, :ov], buf[:, :, st:st + ov]))
+                else:
+                    sol = lstsq_affine_solve(out[:, :, :ov], buf[:, :, st:st + ov])
+                    out = lstsq_affine_apply(out, sol)
             if task == "flow_2d_backward" and wi > 0:
                 buf[:, :, st + 1:st + ws] = out[:, :, 1:]
             else:

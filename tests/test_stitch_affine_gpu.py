@@ -128,3 +128,26 @@ def test_linear_aligner_mean_ratio(dev):
         LinearAligner(method="median")
     with pytest.raises(ValueError):
         LinearAligner(method="mode")
+
+
+def test_depth_stitch_with_linear_aligner(dev):
+    """VideoMAEDepthDPTHead(align_type="linear") (dense_heads.py:146-170): the 3-window depth stitch with the scale-only
+    LinearAligner(method="mean") against the oracle's restatement of aligner.py:91-118, and it must differ from the affine one."""
+    from l4p_amd.models.aligner import LinearAligner
+    from oracle.l4p_oracle import OracleModel
+
+    cfg = ModelCfg.mini()
+    sd = seeded_state_dict(cfg)
+    model = build(cfg, sd, "32-true")
+    batch = make_batch(32, 2)
+    with torch.no_grad():
+        affine = model.forward({k: v.clone() for k, v in batch.items()}, ["depth"])["depth_est_b1thw"].float().cpu()
+        model.l4p_model.task_heads["depth"].overlap_aligner_type = LinearAligner
+        y = model.forward({k: v.clone() for k, v in batch.items()}, ["depth"])["depth_est_b1thw"].float().cpu()
+        om = OracleModel(sd, cfg)
+        om.depth_align_type = "linear"
+        ref = om.forward(batch, ["depth"])["depth_est_b1thw"]
+    torch.cuda.synchronize()
+    assert (y - ref).abs().max() <= 1e-3 * ref.abs().max(), float((y - ref).abs().max() / ref.abs().max())
+    assert (y - affine).abs().max() > 1e-4 * ref.abs().max()  # a different aligner: later windows differ
+    assert torch.equal(y[:, :, :8], affine[:, :, :8])          # the first window is never re-aligned

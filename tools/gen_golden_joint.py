@@ -79,6 +79,27 @@ def main():
         report[f"apply_{k}_rel_err"] = e
         assert e <= 1e-6, (k, e)
 
+    # LinearAligner(pre_post_fn="inverse", method="mean") (aligner.py:69-118) and LstSqAffineAligner("inverse") (:29-66)
+    from oracle import l4p_oracle as lo
+
+    pr = torch.rand(2, 1, 8, 24, 24, generator=g) * 3 + 0.3
+    tg = pr * 1.3 + 0.05 * torch.randn(pr.shape, generator=g)
+    pr[0, 0, 0, 0, :4] = 0.0   # invalid depths: safe_inverse -> 0 on both sides
+    tg[1, 0, 1, 2, :3] = -1.0
+    la = ref_al.LinearAligner(pre_post_fn="inverse", method="mean")
+    la.solve(pr, tg, None, None)
+    e = rel_err(lo.linear_mean_solve(pr, tg), la.sol)
+    report["linear_aligner_solve_rel_err"] = e
+    assert e <= 1e-6, e
+    e = rel_err(lo.linear_mean_apply(pr, lo.linear_mean_solve(pr, tg)), la.apply(pr))
+    report["linear_aligner_apply_rel_err"] = e
+    assert e <= 1e-6, e
+    aa = ref_al.LstSqAffineAligner(pre_post_fn="inverse")
+    aa.solve(pr, tg, None, None)
+    e = rel_err(lo.lstsq_affine_apply(pr, lo.lstsq_affine_solve(pr, tg)), aa.apply(pr))
+    report["affine_aligner_apply_rel_err"] = e
+    assert e <= 1e-5, e
+
     # ---- 2. the 3-window flow through the reference ---------------------------------------------------------------
     cfg = ModelCfg.mini()
     sd = seeded_state_dict(cfg)
