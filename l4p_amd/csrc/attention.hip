@@ -491,6 +491,32 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     }
     const float inv = 1.0f / l_tot;
     T* op = out + ((long long)b * S + q_row) * ((long long)H * DH) + (long long)h * DH;
+#ifndef ATTN_NO_WIDE_STORE
+    if constexpr (ES == 2) {
+        // The row is split across the half-waves in 4-column pieces (lane: columns 8k + 4hi .. + 3 of every 8-column group
+        // k).  One v_permlane32_swap per dword of a group PAIR (k, k+1) hands the upper half's group-k piece down and the
+        // lower half's group-(k+1) piece up: lanes 0-31 then hold columns 8k .. 8k+7, lanes 32-63 columns 8k+8 .. 8k+15 ->
+        // one 16-byte store per pair instead of two 8-byte ones (the store tail is bound by the number of store
+        // instructions, not by bytes).
+        constexpr int NG = DH / 8;
+        u32x2 pk[NG];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[k >> 2][4 * (k & 3) + e] * inv);
+            pk[k] = __builtin_bit_cast(u32x2, v);
+        }
+#pragma unroll
+        for (int k = 0; k + 1 < NG; k += 2) {
+            const auto x = __builtin_amdgcn_permlane32_swap(pk[k][0], pk[k + 1][0], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(pk[k][1], pk[k + 1][1], false, false);
+            *(u32x4*)(op + 8 * k + 8 * hi) = (u32x4){x[0], y[0], x[1], y[1]};
+        }
+        if constexpr (NG & 1) *(u32x2*)(op + 8 * (NG - 1) + 4 * hi) = pk[NG - 1];
+        return;
+    }
+#endif
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
