@@ -387,6 +387,14 @@ __device__ __forceinline__ int conv_tile_walk(const GemmParams& p, int n, int BM
 // residual kind are template parameters, the loop body is a few dozen instructions, and the residual of row i + 1 is
 // requested before row i is finished (one exposed round trip per tile instead of one per row).
 // RES: 0 none, 1 float (p.res1 [+ p.res2]), 2 T.
+template <int I, int N, class F>
+__device__ __forceinline__ void epi_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        epi_static_for<I + 1, N>(f);
+    }
+}
+
 template <typename T, int TM, int TN, int ACT, int RES>
 __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0, int li,
                                                     int kg) {
@@ -407,41 +415,49 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
             bv[8 * g + 4 + q] = b1[q];
         }
     }
-    const bool two = RES != 0 && p.res2 != nullptr;
-    // residual registers of one row: float: NV values per residual; T: NV / 2 dwords per residual
-    f32x4 rf[RES == 1 ? 2 * NG : 1][2];
-    u32x4 rt[RES == 2 ? NG : 1][2];
-    auto load_res = [&](int m) {
+    const bool two = RES == 2 && p.res2 != nullptr;  // (a second residual only exists in the engine dtype: the DPT fusion convs)
+    // Residual registers: a ring of RD rows (float: NV values per residual and row; T: NV / 2 dwords).  The rows of a lane are
+    // 16 apart, every row is its own HBM round trip, and nothing else runs on the CU while its workgroup is in the epilogue: with
+    // one row of look-ahead the 8 rows of a wave were 8 dependent round trips (the tall tracker GEMM with a float residual
+    // in + out spent more time here than in its main loop).  RD rows are requested before the first one is needed.
+#ifndef GEMM_EPI_RES_DEPTH
+#define GEMM_EPI_RES_DEPTH 4
+#endif
+    constexpr int RD = RES == 0 ? 1 : RES == 2 ? 2 : (GEMM_EPI_RES_DEPTH < TM ? GEMM_EPI_RES_DEPTH : TM);
+    f32x4 rf[RD][RES == 1 ? 2 * NG : 1][1];
+    u32x4 rt[RD][RES == 2 ? NG : 1][2];
+    auto load_res = [&](int m, auto slot_) {
+        constexpr int sl = decltype(slot_)::value;
         const long long roff = (long long)m * p.ldr + nb;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (!gok[g]) continue;
             if (RES == 1) {
-                rf[2 * g][0] = *(const f32x4*)((const float*)p.res1 + roff + 8 * g);
-                rf[2 * g + 1][0] = *(const f32x4*)((const float*)p.res1 + roff + 8 * g + 4);
-                if (two) {
-                    rf[2 * g][1] = *(const f32x4*)((const float*)p.res2 + roff + 8 * g);
-                    rf[2 * g + 1][1] = *(const f32x4*)((const float*)p.res2 + roff + 8 * g + 4);
-                }
+                rf[sl][2 * g][0] = *(const f32x4*)((const float*)p.res1 + roff + 8 * g);
+                rf[sl][2 * g + 1][0] = *(const f32x4*)((const float*)p.res1 + roff + 8 * g + 4);
             } else if (RES == 2) {
-                rt[g][0] = *(const u32x4*)((const T*)p.res1 + roff + 8 * g);
-                if (two) rt[g][1] = *(const u32x4*)((const T*)p.res2 + roff + 8 * g);
+                rt[sl][g][0] = *(const u32x4*)((const T*)p.res1 + roff + 8 * g);
+                if (two) rt[sl][g][1] = *(const u32x4*)((const T*)p.res2 + roff + 8 * g);
             }
         }
     };
-    int m_next = m_wave0 + li;
-    if (RES != 0 && m_next < p.M) load_res(m_next);
+    if (RES != 0) {
+        epi_static_for<0, RD>([&](auto d_) {
+            constexpr int d = decltype(d_)::value;
+            if (m_wave0 + d * 16 + li < p.M) load_res(m_wave0 + d * 16 + li, d_);
+        });
+    }
     // fully unrolled over the TM rows: the body is lean enough for that (~40 instructions a row), and a rolled loop makes
     // hipcc index the accumulator rows through scratch memory (one round trip per row: measured slower than the generic body)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    epi_static_for<0, TM>([&](auto i_) {
+        constexpr int i = decltype(i_)::value, sl = i % RD;
         float v[NV];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
         const int m = m_wave0 + i * 16 + li;
-        if (m >= p.M) continue;  // (rows only run out at the bottom of the matrix: nothing after this row either)
+        if (m >= p.M) return;  // (rows only run out at the bottom of the matrix: nothing after this row either)
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
             float x = v[c] + bv[c];
@@ -455,21 +471,23 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
 #pragma unroll
             for (int g = 0; g < 2 * NG; ++g)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[4 * g + q] += two ? rf[g][0][q] + rf[g][1][q] : rf[g][0][q];
+                for (int q = 0; q < 4; ++q) v[4 * g + q] += rf[sl][g][0][q];
         } else if (RES == 2) {
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (ES == 2) {
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, rt[g][0]), b = __builtin_bit_cast(bf16x8, rt[g][1]);
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, rt[sl][g][0]), b = __builtin_bit_cast(bf16x8, rt[sl][g][1]);
                         v[8 * g + q] += two ? (float)a[q] + (float)b[q] : (float)a[q];
                     }
                 }
         }
-        // the next row's residual is requested now: its values are copies in registers, so an in-place update of THIS row
-        // (out aliasing res1) cannot reach them, and rows never overlap
-        if (RES != 0 && i + 1 < TM && m + 16 < p.M) load_res(m + 16);
+        // row i + RD's residual is requested now, into the slot this row has just released: its values are copies in
+        // registers, so an in-place update of THIS row (out aliasing res1) cannot reach them, and rows never overlap
+        if constexpr (RES != 0 && i + RD < TM) {
+            if (m + 16 * RD < p.M) load_res(m + 16 * RD, std::integral_constant<int, sl>{});
+        }
         const long long off = (long long)m * p.ldc + nb;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -499,7 +517,7 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
                 }
             }
         }
-    }
+    });
 }
 
 // Lean form of the L4P_EPI_QKV epilogue (bf16): what a lane's two 8-column groups are (q / k / v, head, dim) does not
@@ -637,6 +655,7 @@ __device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p
     }
     if (p.epi != EPI_DENSE || p.c_gr > 0 || p.res_mod > 0) return false;
     const int res = !p.res1 ? 0 : (p.res_f32 ? 1 : 2);
+    if (res == 1 && p.res2) return false;  // (two float residuals: no caller; the generic body handles it)
 #define L4P_EPI_CASE(A, R)                                                                    \
     if (p.act == A && res == R) {                                                             \
         gemm_epilogue_dense<T, TM, TN, A, R>(p, acc, m_wave0, n_wave0, li, kg);               \
