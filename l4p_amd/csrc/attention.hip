@@ -542,11 +542,8 @@ static int launch_attn_t(const void* q, const void* kt, const void* vt, void* ou
     constexpr int DP = 96;
     const size_t lds = SPLIT * 2 * (size_t)(DP / 16 * KVB * 2 * 8 * sizeof(T) + DP * 128);
     auto kern = attn_kernel<T, DP, KVB, DH, SPLIT, HS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    HIP_TRY(lds_attr_once(attr_done, kern, (int)lds));
     // scale == 0 (L4P_ATTN_PRESCALED): q already carries head_dim^-0.5 * log2(e); the kernels then multiply by exactly 1
     const float c_scale = scale > 0.f ? scale * 1.4426950408889634f : 1.0f;
     ProfScope prof(PROF_ATTENTION, stream);

@@ -100,6 +100,22 @@ __device__ __forceinline__ float wave_max(float v) {
 
 #include "prof.hpp"
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, DEVICE): the attribute is a property of
+// the function on one device, and a host may drive several devices, from several threads (the mask is atomic; a lost race
+// only repeats an idempotent call)
+#include <atomic>
+template <class K>
+static inline hipError_t lds_attr_once(std::atomic<unsigned long long>& done, K kern, int lds) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 // host-side error plumbing (defined in api.hip)
 void l4p_set_error(const char* fmt, ...);
 #define HIP_TRY(expr)                                                                  \
