@@ -8,13 +8,21 @@
 // ds_read_b128 and half the fragment waits per FLOP of attention.hip's 32-row form (whose ablation put 19 % of its time on
 // the fragment reads).  With no second wave on the SIMD to overlap with, the overlap is inside the wave: the vector work
 // of a block (exp2 / bf16 packing of P_j, row maximum of S_{j+1}) is sliced behind the 48 MFMAs of the block.
-// EXPERIMENT, not part of libl4p_hip.so (round 2): correct (it passed tests/test_kernels_gpu.py's attention cases when hooked
-// into launch_attention for >= 256 workgroups) but SLOWER than the 32-row kernel it was meant to replace: 114.1 vs 108.5 us at
-// batch 4 and 201.7 vs 193.1 us at batch 8 (tools/attn_time.py, random data).  Compiled with -amdgpu-mfma-vgpr-form=1 the
-// 224 accumulator registers fill the architected VGPRs and hipcc parks the Q fragments in AGPRs, re-reading them with
-// v_accvgpr_read before every use (56 copies per 48-MFMA block: 5.3 issue slots per MFMA gap where one wave per SIMD can hide
-// ~5); without the flag it spills.  The way forward is the one the CDNA4 guide describes for this structure: O^T owned by
-// AGPR-form MFMAs written as inline asm, which this file does not do.
+// EXPERIMENT, not part of libl4p_hip.so (round 2; to try it: copy into l4p_amd/csrc/, declare launch_attention64 in attention.hip
+// and call it from launch_attention for bf16, S % 256 == 0 and >= 256 workgroups).  Correct (tests/test_kernels_gpu.py's
+// attention cases pass through it) and NOT faster than the 32-row kernel: 108.6-109.3 vs 106.5-108.5 us at batch 4, 198.5 vs
+// 193.5 us at batch 8 (tools/attn_time.py, random data, same call), for every read-ahead depth from 3 to 14.  Its first form
+// used the MFMA builtins: hipcc parked Q in AGPRs and copied it back before every use (56 v_accvgpr_* per 48-MFMA block, 114 us).
+// This form has no copies in the steady-state block (48 MFMA, 24 ds_read_b128, 64 v_exp, 32 v_cvt_pk, 38 v_max, nothing else) and
+// half the fragment reads per FLOP of the 32-row kernel - so the number of fragment reads is not what bounds either kernel.
+// Register plan (one wave per SIMD: 256 architected VGPRs + 256 AGPRs): the output accumulators O^T (96) and the Q fragments
+// (48) live in AGPRs for the whole kernel - every MFMA is written as inline asm so that its operand classes are chosen here
+// (PV: AGPR accumulator; QK^T: Q read as an AGPR B operand), which hipcc's builtins do not allow (round 2's builtin form of this
+// kernel parked Q in AGPRs and copied it back before every use: 56 v_accvgpr_* per 48-MFMA block, 5 % slower than the 32-row
+// kernel).  VGPRs hold the two score sets (128), P (32), the fragment read-ahead and addresses.
+// Hazards hipcc cannot see through inline asm are kept by construction: a score tile is read by VALU no sooner than two MFMAs
+// after its last MFMA (8-pass MFMA: 11 wait states); O^T / Q are touched by VALU only on the rare rescale path and in the
+// epilogue, behind explicit s_nop padding that is tied to the registers by asm operands.
 #include <cstdlib>
 #include <type_traits>
 
@@ -30,6 +38,18 @@ __device__ __forceinline__ void static_for64(F&& f) {
         f(std::integral_constant<int, I>{});
         static_for64<I + 1, N>(f);
     }
+}
+
+// MFMAs with explicit operand classes.  S^T tile: VGPR accumulator, K fragment in VGPRs, Q fragment in AGPRs.
+__device__ __forceinline__ void mfma_s_first(f32x16& d, const u32x4& k, const u32x4& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void mfma_s(f32x16& d, const u32x4& k, const u32x4& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+}
+// O^T tile: AGPR accumulator, V^T and P fragments in VGPRs
+__device__ __forceinline__ void mfma_o(f32x16& d, const u32x4& v, const u32x4& pfrag) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(v), "v"(pfrag));
 }
 
 template <int DH>
@@ -72,20 +92,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int b = unit / H, h = unit % H;
     const int q_row0 = qb * 256 + wave * 64 + lq;  // + 32 * qt
 
-    frag_t qf[QT][NKS];
+    u32x4 qf[QT][NKS];  // (only ever an "a" operand: lives in AGPRs)
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const T* qp = q + ((long long)b * S + q_row0 + 32 * qt) * ((long long)H * DP) + (long long)h * DP;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) *(u32x4*)&qf[qt][ks] = *(const u32x4*)(qp + ks * 16 + hi * 8);
-    }
-    if (c_scale != 1.0f) {  // (not pre-scaled: fold scale * log2 e here, a second bf16 rounding of q)
+        for (int ks = 0; ks < NKS; ++ks) {
+            frag_t f = *(const frag_t*)(qp + ks * 16 + hi * 8);
+            if (c_scale != 1.0f) {  // (not pre-scaled: fold scale * log2 e here, a second bf16 rounding of q)
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[qt][ks][e] = (bf16_t)((float)qf[qt][ks][e] * c_scale);
+                for (int e = 0; e < 8; ++e) f[e] = (bf16_t)((float)f[e] * c_scale);
+            }
+            qf[qt][ks] = __builtin_bit_cast(u32x4, f);
+        }
     }
 
     // ---- LDS-DMA sources (as attention.hip) ----
@@ -151,16 +170,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int t = 0; t < NST; ++t) {
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_a[qt][t][r] = 0.f;
-#pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            const frag_t kf = *(const frag_t*)(Ks + ks * (KVB * 2 * 16) + koff[t]);
+            const u32x4 kf = *(const u32x4*)(Ks + ks * (KVB * 2 * 16) + koff[t]);
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) s_a[qt][t] = mma32(kf, qf[qt][ks], s_a[qt][t]);
+            for (int qt = 0; qt < QT; ++qt) {
+                if (ks == 0)
+                    mfma_s_first(s_a[qt][t], kf, qf[qt][ks]);
+                else
+                    mfma_s(s_a[qt][t], kf, qf[qt][ks]);
+            }
         }
     }
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s_a[0][0]), "+v"(s_a[0][1]), "+v"(s_a[1][0]), "+v"(s_a[1][1]));  // MFMA -> VALU read
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float m = s_a[qt][0][0];
@@ -179,6 +200,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (HAS_NEXT) issue_v(it + 1, cur ^ 1);      // V_{it-1} (slot cur^1) was consumed last iteration
         // ---- deferred maximum: the rare side path (see attention.hip) ----
         if (it == 0 || __any(fmaxf(mx[0], mx[1]) > RESCALE_THR)) {
+            // (the previous block's last PV MFMAs may still be writing O^T: 8 passes + 3 wait states before VALU reads it)
+            asm volatile("s_nop 7\n\ts_nop 7"
+                         : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]));
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const float want = m_run[qt] + (it == 0 ? mx[qt] : fmaxf(mx[qt], 0.f));
@@ -193,18 +217,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
                 }
                 m_run[qt] = m_new;
-                if (hi == HI_P) {
-                    qf[qt][KS_P][0] = -m_hi;
-                    qf[qt][KS_P][1] = -m_lo;
+                if (hi == HI_P) {  // dims DH, DH+1 = the two bf16 halves of -m: dword 0 of the chunk
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                    const bf16x2 mm = {-m_hi, -m_lo};
+                    qf[qt][KS_P][0] = __builtin_bit_cast(unsigned, mm);
                 }
 #pragma unroll
                 for (int t = 0; t < NST; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s_cur[qt][t][r] -= delta;
             }
+            // (VALU wrote O^T / Q / the scores: keep the first MFMAs that read them a few wait states away)
+            asm volatile("s_nop 4"
+                         : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(qf[0][KS_P]),
+                           "+a"(qf[1][KS_P]));
         }
         // ---- hand-scheduled block body: 24 fragment reads (12 K, 12 V^T), each feeding QT MFMAs ----
-        constexpr int PRE = 6;
+#ifndef ATTN64_PRE
+#define ATTN64_PRE 6
+#endif
+        constexpr int PRE = ATTN64_PRE;  // fragment reads in flight ahead of the MFMA pair that consumes them
         constexpr int NR = HAS_NEXT ? 24 : 12, R0 = HAS_NEXT ? 0 : 12;
         const unsigned lds_k = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Ks;
         const unsigned lds_v = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Vs;
@@ -240,7 +272,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 exp_pair(std::integral_constant<int, 1>{}, p_);
             });
         }
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         static_for64<0, NR>([&](auto m_) {
             constexpr int m = decltype(m_)::value, r = R0 + m;
             constexpr int issued = (PRE + m < NR) ? PRE + m : NR;
@@ -250,11 +281,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             static_for64<0, QT>([&](auto qt_) {
                 constexpr int qt = decltype(qt_)::value;
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (r < 12) {
-                    s_nxt[qt][r % NST] = mma32(__builtin_bit_cast(frag_t, fr[r]), qf[qt][r / NST], r < NST ? zero16 : s_nxt[qt][r % NST]);
+                if constexpr (r < NST) {
+                    mfma_s_first(s_nxt[qt][r % NST], fr[r], qf[qt][r / NST]);
+                } else if constexpr (r < 12) {
+                    mfma_s(s_nxt[qt][r % NST], fr[r], qf[qt][r / NST]);
                 } else {
                     constexpr int i = r - 12;
-                    o[qt][i % NDT] = mma32(__builtin_bit_cast(frag_t, fr[r]), pf[qt][(i / NDT) >> 1][(i / NDT) & 1], o[qt][i % NDT]);
+                    mfma_o(o[qt][i % NDT], fr[r], __builtin_bit_cast(u32x4, pf[qt][(i / NDT) >> 1][(i / NDT) & 1]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (qt == 0 && PRE + m < NR) rd(std::integral_constant<int, PRE + m>{});
@@ -290,6 +323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     // ---- normalise and store: lane owns query q_row0 + 32 qt, d = 32*dt + (r&3) + 8*(r>>2) + 4*hi ----
+    asm volatile("s_nop 7\n\ts_nop 7" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]));
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float l_tot = o[qt][DT_L][R_L];
