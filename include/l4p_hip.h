@@ -264,6 +264,12 @@ int l4p_track_keys_init(l4p_stream stream, int dtype, const float* enc, const fl
 int l4p_fill_rows(l4p_stream stream, float* out, const float* v, long long rows, int C, long long group_rows,
                   long long group_stride, long long group_off);
 
+/* Copies the `bytes` bytes at base + off to the same offset of the following n - 1 groups (group g starts at base + g * stride;
+ * all multiples of 16).  Later tracker windows (sparse_heads.py:406-448): the second temporal half of every track's keys is
+ * encoder feature + the same learned mask token, so what layer 0 derives from it (rows [P/2, P) of t2i.k, t2i.v, i2t.q) is
+ * computed for track 0 and copied to the other tracks' rows. */
+int l4p_broadcast_block(l4p_stream stream, void* base, long long off, long long bytes, long long stride, int n);
+
 /* Attention of sam/transformer.py:223-245 after the projections. kind 0: 6 prompt tokens among themselves
  * (q,k,v,out [N][6][D]); kind 1: tokens -> image (q [N][6][D], k,v [N][P][D], out [N][6][D]);
  * kind 2: image -> tokens (q [N][P][D], k,v [N][6][D], out [N][P][D]);
@@ -350,7 +356,10 @@ int l4p_dpt_forward(l4p_engine* e, l4p_stream stream, const char* task, const l4
  * the next window, memory tokens (need_history), up-scaling fused with the mask product, fused up-sample + soft-argmax.
  * enc_last float [P][C] (enc_features[-1] of the clip); hist float [N][P][C] per-query history tokens (read; rewritten in
  * place for the next window when need_history) — or, with hist_uniform (every track still has the same history rows: the
- * first window / the plain single-window forward), only its first P rows are read; q_off float [N][3] (t, x, y) relative
+ * first window / the plain single-window forward), only its first P rows are read; hist_uniform == 2: rows [P/2, P) of every
+ * track's history are identical (the state need_history leaves behind: the learned mask token), so the layer-0 projections
+ * of those rows are computed once and copied (l4p_broadcast_block) — same values, half the key-side projection work of
+ * layer 0; q_off float [N][3] (t, x, y) relative
  * to the window; labels, plabel float [N]; pfeat float [N][C].  Outputs: traj float [N][2][T], vis, depth float [N][T],
  * new_pfeat float [N][C].  Weights "trk.*" must have been bound with l4p_bind_weight. */
 typedef struct l4p_track_cfg {

@@ -14,6 +14,7 @@ int launch_track_keys_init(int dtype, const float* enc, const float* hist, const
                            void* kP, int N, int P, int C, hipStream_t stream);
 int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
                      long long group_off, hipStream_t stream);
+int launch_broadcast_block(void* base, long long off, long long bytes, long long stride, int n, hipStream_t stream);
 int launch_small_attn(int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P, int D,
                       int heads, hipStream_t stream);
 int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, int w, int cpt, hipStream_t stream);
@@ -52,6 +53,9 @@ int l4p_track_keys_init(l4p_stream s, int dtype, const float* enc, const float* 
 int l4p_fill_rows(l4p_stream s, float* out, const float* v, long long rows, int C, long long group_rows,
                   long long group_stride, long long group_off) {
     return launch_fill_rows(out, v, rows, C, group_rows, group_stride, group_off, (hipStream_t)s);
+}
+int l4p_broadcast_block(l4p_stream s, void* base, long long off, long long bytes, long long stride, int n) {
+    return launch_broadcast_block(base, off, bytes, stride, n, (hipStream_t)s);
 }
 int l4p_small_attn(l4p_stream s, int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P,
                    int D, int heads) {

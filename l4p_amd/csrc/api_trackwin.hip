@@ -26,6 +26,7 @@ int launch_track_keys_init(int dtype, const float* enc, const float* hist, const
                            void* kP, int N, int P, int C, hipStream_t stream);
 int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
                      long long group_off, hipStream_t stream);
+int launch_broadcast_block(void* base, long long off, long long bytes, long long stride, int n, hipStream_t stream);
 int launch_small_attn(int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P, int D,
                       int heads, hipStream_t stream);
 int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, int w, int cpt, hipStream_t stream);
@@ -136,6 +137,21 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
     const int P = g.tokens, Cc = g.dim, Dh = Cc / 2;
     const int T = g.T, H = g.H, W = g.W;
     const long long NP = (long long)N * P;
+    // hist_uniform == 2: rows [P/2, P) of every track's keys are the same until the first image -> token update
+    const bool half_shared = hist_uniform == 2 && N > 1 && P % 2 == 0;
+    if (hist_uniform == 2) hist_uniform = 0;
+    // projection of per-track keys x [N*P][Cc] whose second temporal half is common to all tracks: the first halves of all
+    // tracks (row-mapped GEMM over N * P/2 rows), track 0's second half, and a copy of that block to the other tracks
+    auto proj_half_shared = [&](const void* x, const std::string& wk, int n) -> void* {
+        void* o = c.T(NP, n);
+        const int half = P / 2;
+        const int m1[3] = {half, P, 0}, m2[3] = {half, P, half};
+        c.gemm(x, (long long)N * half, Cc, Cc, wk, n, true, ACT_NONE, nullptr, 0, nullptr, o, n, m1, m1);
+        c.gemm(x, half, Cc, Cc, wk, n, true, ACT_NONE, nullptr, 0, nullptr, o, n, m2, m2);
+        if (!c.rc && !c.dry)
+            c.rc = launch_broadcast_block(o, (long long)half * n * c.es, (long long)half * n * c.es, (long long)P * n * c.es, N, c.st);
+        return o;
+    };
     // ---- prompt tokens (prompt_encoder.py:78-121,196-203; mask_decoder.py:107-113) ----
     float* tok32 = c.f32(6ll * N, Cc);
     void* tokT = c.T(6ll * N, Cc);
@@ -199,8 +215,9 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         size_t mark = c.ws.off;
         {
             void* tq = c.proj(qP, 6ll * N, Cc, lo + "t2i.q", Dh);
-            void* tk = c.proj(curP, (long long)Nk * P, Cc, lo + "t2i.k", Dh);
-            void* tv = c.proj(curT, (long long)Nk * P, Cc, lo + "t2i.v", Dh);
+            const bool hs = half_shared && l == 0;
+            void* tk = hs ? proj_half_shared(curP, lo + "t2i.k", Dh) : c.proj(curP, (long long)Nk * P, Cc, lo + "t2i.k", Dh);
+            void* tv = hs ? proj_half_shared(curT, lo + "t2i.v", Dh) : c.proj(curT, (long long)Nk * P, Cc, lo + "t2i.v", Dh);
             void* ta = c.T(6ll * N, Dh);
             c.attn(shared ? 3 : 1, tq, tk, tv, ta, N, P, Dh, g.sam_heads);
             c.gemm(ta, 6ll * N, Dh, Dh, lo + "t2i.out", Cc, true, ACT_NONE, q32, 0, x32, nullptr, Cc);
@@ -218,7 +235,8 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         // --- image -> tokens (transformer.py:180-185): keys are updated in place ---
         mark = c.ws.off;
         {
-            void* iq = c.proj(curP, (long long)Nk * P, Cc, lo + "i2t.q", Dh);
+            void* iq = half_shared && l == 0 ? proj_half_shared(curP, lo + "i2t.q", Dh)
+                                             : c.proj(curP, (long long)Nk * P, Cc, lo + "i2t.q", Dh);
             void* ik = c.proj(qP, 6ll * N, Cc, lo + "i2t.k", Dh);
             void* iv = c.proj(qT, 6ll * N, Cc, lo + "i2t.v", Dh);
             void* ia = c.T(NP, Dh);

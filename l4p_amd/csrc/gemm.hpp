@@ -426,9 +426,11 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
     constexpr int RD = RES == 0 ? 1 : RES == 2 ? 2 : (GEMM_EPI_RES_DEPTH < TM ? GEMM_EPI_RES_DEPTH : TM);
     f32x4 rf[RD][RES == 1 ? 2 * NG : 1][1];
     u32x4 rt[RD][RES == 2 ? NG : 1][2];
+    // optional row map of the output and the residual (l4p_gemm_desc.c_*): logical row m lives at physical row crow(m)
+    auto crow = [&](int m) -> long long { return p.c_gr > 0 ? (long long)(m / p.c_gr) * p.c_gs + p.c_go + (m % p.c_gr) : m; };
     auto load_res = [&](int m, auto slot_) {
         constexpr int sl = decltype(slot_)::value;
-        const long long roff = (long long)m * p.ldr + nb;
+        const long long roff = crow(m) * p.ldr + nb;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (!gok[g]) continue;
@@ -488,7 +490,7 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
         if constexpr (RES != 0 && i + RD < TM) {
             if (m + 16 * RD < p.M) load_res(m + 16 * RD, std::integral_constant<int, sl>{});
         }
-        const long long off = (long long)m * p.ldc + nb;
+        const long long off = crow(m) * p.ldc + nb;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (!gok[g]) continue;
@@ -653,7 +655,7 @@ __device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p
         gemm_epilogue_convt<T, TM, TN>(p, acc, m_wave0, n_wave0, li, kg);
         return true;
     }
-    if (p.epi != EPI_DENSE || p.c_gr > 0 || p.res_mod > 0) return false;
+    if (p.epi != EPI_DENSE || p.res_mod > 0) return false;
     const int res = !p.res1 ? 0 : (p.res_f32 ? 1 : 2);
     if (res == 1 && p.res2) return false;  // (two float residuals: no caller; the generic body handles it)
 #define L4P_EPI_CASE(A, R)                                                                    \

@@ -678,6 +678,30 @@ int launch_track_keys_init(int dtype, const float* enc, const float* hist, const
     return 0;
 }
 
+// Copies the block of `bytes` bytes at base + off to the same offset of the next n - 1 groups (group g at base + g * stride):
+// the later-window form of the tracker shares what only depends on the second temporal half of the keys, which is the same
+// for every track of a clip (encoder feature + the learned mask token), by computing it for track 0 and copying it
+__global__ void broadcast_block_kernel(char* __restrict__ base, long long off, long long chunks, long long stride, int n) {
+    const long long total = chunks * (n - 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long g = i / chunks + 1, c = i - (g - 1) * chunks;
+        const u32x4 v = *(const u32x4*)(base + off + c * 16);
+        __builtin_nontemporal_store(v, (u32x4*)(base + g * stride + off + c * 16));
+    }
+}
+int launch_broadcast_block(void* base, long long off, long long bytes, long long stride, int n, hipStream_t stream) {
+    if ((bytes | off | stride) % 16 || ((size_t)base & 15)) {
+        l4p_set_error("broadcast_block: offsets / sizes must be multiples of 16 bytes");
+        return L4P_E_INVALID;
+    }
+    if (n <= 1 || bytes == 0) return 0;
+    ProfScope prof(PROF_TRACK, stream, "broadcast_block");
+    hipLaunchKernelGGL(broadcast_block_kernel, dim3(GRID1D(bytes / 16 * (n - 1), 16384)), dim3(256), 0, stream, (char*)base, off,
+                       bytes / 16, stride, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
                      long long group_off, hipStream_t stream) {
     ProfScope prof(PROF_TRACK, stream, "fill_rows");

@@ -102,16 +102,17 @@ class Engine:
         return out_f, out_T
 
     def track_window(self, tcfg: "_lib.TrackCfg", enc_last: torch.Tensor, hist: torch.Tensor, q_off: torch.Tensor,
-                     labels: torch.Tensor, pfeat: torch.Tensor, plabel: torch.Tensor, need_history: bool, hist_uniform: bool,
+                     labels: torch.Tensor, pfeat: torch.Tensor, plabel: torch.Tensor, need_history: bool, hist_uniform: int,
                      slot: int = 0):
         """One tracker window of one clip as ONE native call (l4p_track_window_forward).  ``slot`` selects the workspace:
         clips whose trackers run concurrently on different HIP streams must not share one."""
         N, Cc = q_off.shape[0], self.cfg.dim
         T = tcfg.T
-        key = (slot, N, 1 if hist_uniform else 0)
+        hu = int(hist_uniform)  # 0 per-track history, 1 uniform (first window), 2 second temporal half uniform (later windows)
+        key = (slot, N, hu)
         ws = self._trk_ws.get(key)
         if ws is None:
-            need = int(self.lib.l4p_track_window_workspace_bytes(self.handle, C.byref(tcfg), N, 1 if hist_uniform else 0))
+            need = int(self.lib.l4p_track_window_workspace_bytes(self.handle, C.byref(tcfg), N, hu))
             if need == 0:
                 raise _lib.L4PHipError("l4p_track_window_workspace_bytes: " + self.lib.l4p_last_error().decode())
             for k in [k for k in self._trk_ws if k[0] == slot]:  # one workspace per slot: drop the one of another shape
@@ -126,6 +127,6 @@ class Engine:
         _lib.check(self.lib.l4p_track_window_forward(
             self.handle, torch.cuda.current_stream().cuda_stream, C.byref(tcfg), enc_last.data_ptr(), hist.data_ptr(),
             q_off.data_ptr(), labels.data_ptr(), pfeat.data_ptr(), plabel.data_ptr(), N, 1 if need_history else 0,
-            1 if hist_uniform else 0, ws.data_ptr(), ws.numel(), traj.data_ptr(), vis.data_ptr(), dep.data_ptr(),
+            hu, ws.data_ptr(), ws.numel(), traj.data_ptr(), vis.data_ptr(), dep.data_ptr(),
             new_pfeat.data_ptr()), "l4p_track_window_forward")
         return traj, vis, dep, new_pfeat

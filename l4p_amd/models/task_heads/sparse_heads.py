@@ -118,7 +118,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def _window(self, enc_last: torch.Tensor, hist: torch.Tensor, q_off: torch.Tensor, labels: torch.Tensor,
-                pfeat: torch.Tensor, plabel: torch.Tensor, need_history: bool, hist_uniform: bool = False):
+                pfeat: torch.Tensor, plabel: torch.Tensor, need_history: bool, hist_uniform: int = 0):
         """forward / forward_single_batch (sparse_heads.py:497-667) for N queries of one clip.
         enc_last: float [P,C]; hist: float [N,P,C]; returns window traj [N,2,T], vis [N,T], depth [N,T],
         new prompt features [N,C]; updates ``hist`` in place when ``need_history``.
@@ -154,6 +154,23 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         _lib.check(lib.l4p_cast(_stream(), dt, _p(tok32), _p(tokT), tok32.numel()), "l4p_cast")
 
         pos = self._w("dense_pe")
+        # hist_uniform == 2: rows [P/2, P) of every track's keys coincide until the first image -> token update
+        half_shared = hist_uniform == 2 and N > 1 and P % 2 == 0
+        if hist_uniform == 2:
+            hist_uniform = 0
+
+        def proj_half_shared(x: torch.Tensor, key: str, n: int) -> torch.Tensor:
+            """Projection of per-track keys [N*P, C] whose second temporal half is common to all tracks: the first halves of
+            all tracks (row-mapped GEMM), track 0's second half, and a copy of that block to the other tracks."""
+            half = P // 2
+            o = torch.empty((N * P, n), dtype=x.dtype, device=x.device)
+            w, b = self._w(key + ".w"), self._w(key + ".b")
+            _gemm(x, N * half, Cc, Cc, w, n, bias=b, out_T=o, a_map=(half, P, 0), c_map=(half, P, 0))
+            _gemm(x, half, Cc, Cc, w, n, bias=b, out_T=o, a_map=(half, P, half), c_map=(half, P, half))
+            es = o.element_size()
+            _lib.check(lib.l4p_broadcast_block(_stream(), _p(o), half * n * es, half * n * es, P * n * es, N), "l4p_broadcast_block")
+            return o
+
         Nk = 1 if hist_uniform else N  # distinct key sets before the first image -> token update
         k32 = torch.empty((Nk * P, Cc), **f32)
         kT = torch.empty((Nk * P, Cc), dtype=td, device=dev)
@@ -176,8 +193,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             q32, qT, qP = self._ln(x32, lo + "norm1", tok32, 6 * N, out32=torch.empty_like(x32))
             # --- tokens -> image (transformer.py:168-173) ---
             tq = self._proj(qP, lo + "t2i.q", Dh)
-            tk = self._proj(kP, lo + "t2i.k", Dh)
-            tv = self._proj(kT, lo + "t2i.v", Dh)
+            hs = half_shared and l == 0
+            tk = proj_half_shared(kP, lo + "t2i.k", Dh) if hs else self._proj(kP, lo + "t2i.k", Dh)
+            tv = proj_half_shared(kT, lo + "t2i.v", Dh) if hs else self._proj(kT, lo + "t2i.v", Dh)
             ta = self._attn(3 if shared else 1, tq, tk, tv, N, P, Dh)
             del tk, tv
             _gemm(ta, 6 * N, Dh, Dh, self._w(lo + "t2i.out.w"), Cc, bias=self._w(lo + "t2i.out.b"), res1=q32, out_f32=x32)
@@ -188,7 +206,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                   out_f32=x32)
             q32, qT, qP = self._ln(x32, lo + "norm3", tok32, 6 * N, out32=torch.empty_like(x32))
             # --- image -> tokens (transformer.py:180-185): keys are updated in place ---
-            iq = self._proj(kP, lo + "i2t.q", Dh)
+            iq = proj_half_shared(kP, lo + "i2t.q", Dh) if hs else self._proj(kP, lo + "i2t.q", Dh)
             ik = self._proj(qP, lo + "i2t.k", Dh)
             iv = self._proj(qT, lo + "i2t.v", Dh)
             ia = torch.empty((N * P, Dh), dtype=td, device=dev)
@@ -362,8 +380,12 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                                        "valid_t": valid_t.clone()})
                 enc_last = enc_features_bpc_2dlist[wi].f32(-1)[b].contiguous()
                 # first window: the history of every track is the learned mask token (filled above) -> shared keys
+                # later windows: the second temporal half of every track's history is the mask token again (written by the
+                # previous window's memory update) -> what layer 0 derives from those rows is computed once (L4P_TRACK_HALF_SHARE=0:
+                # every track on its own, the A/B and equality check)
+                hu = 1 if wi == 0 else (2 if os.environ.get("L4P_TRACK_HALF_SHARE", "1") != "0" else 0)
                 w_traj, w_vis, w_dep, new_pfeat = self._window(enc_last, hist, q_off, labels, pfeat, plabel, not last,
-                                                               hist_uniform=(wi == 0))
+                                                               hist_uniform=hu)
                 _lib.check(lib.l4p_track_commit(_stream(), _p(w_traj), _p(w_vis), _p(w_dep), _p(valid_t), _p(valid_n),
                                                 traj_b.data_ptr(), vis_b.data_ptr(), dep_b.data_ptr(), T, start, ws, nxt,
                                                 1 if last else 0, _p(cur_q), _p(plabel), _p(new_pfeat), _p(pfeat), _p(best),

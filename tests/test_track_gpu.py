@@ -189,6 +189,31 @@ def test_single_window_entry_vs_reference_golden(dev, mini, precision):
 
 
 @pytest.mark.parametrize("precision", ["32-true", "bf16"])
+@pytest.mark.parametrize("python_path", [False, True])
+def test_later_window_shared_half_equals_per_track_path(dev, mini, precision, python_path, monkeypatch):
+    """Later windows: the second temporal half of every track's keys is encoder feature + the same mask
+    token, so layer 0's t2i.k / t2i.v / i2t.q rows of that half are computed for track 0 and copied (hist_uniform = 2).
+    Against every track projecting all of its rows (L4P_TRACK_HALF_SHARE=0): identical rows in, identical rows out - bit for
+    bit over a 4-window recursion, through the native window call and through the Python composition."""
+    cfg, sd = mini
+    model = build(cfg, sd, precision)
+    batch = make_batch(40, 9)
+    keys = ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]
+    if python_path:
+        monkeypatch.setenv("L4P_TRACK_PYTHON", "1")
+    else:
+        monkeypatch.delenv("L4P_TRACK_PYTHON", raising=False)
+    with torch.no_grad():
+        monkeypatch.delenv("L4P_TRACK_HALF_SHARE", raising=False)
+        a = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+        monkeypatch.setenv("L4P_TRACK_HALF_SHARE", "0")
+        b = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+    torch.cuda.synchronize()
+    for k in keys:
+        assert a[k].shape[-1] == 40 and torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
 def test_native_window_call_equals_python_composition(dev, mini, precision, monkeypatch):
     """l4p_track_window_forward (one C++ call per clip and window, csrc/api_trackwin.hip) issues the same kernels in the same
     order as sparse_heads._window (kernel by kernel from Python, L4P_TRACK_PYTHON=1): bit-identical outputs over a 3-window
