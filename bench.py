@@ -97,7 +97,8 @@ def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int, n_windows: int = 1):
     #    memory tokens only, and only its second temporal half survives (sparse_heads.py:406-448): the last (or only)
     #    window needs none of it, every other window half of it;
     #  * in a first window every track starts from the same keys, so the first layer's three image-side projections
-    #    (t2i.k, t2i.v, i2t.q: 2*S*D*(D/2) each) are one computation per clip, not one per track.
+    #    (t2i.k, t2i.v, i2t.q: 2*S*D*(D/2) each) are one computation per clip, not one per track; in later windows the
+    #    second temporal half of the keys is still common to all tracks: half of those projections is one computation.
     if "track_2d" in tasks and n_queries > 0:
         hist_full = 2.0 * S * D * D
         per_qw = TRACK_FLOPS_PER_QUERY_WINDOW - hist_full
@@ -105,6 +106,7 @@ def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int, n_windows: int = 1):
         total = n_windows * per_qw * n_queries                       # every window, every query
         total += (n_windows - 1) * 0.5 * hist_full * n_queries       # memory tokens for the windows that have a successor
         total -= shared * (n_queries - 1)                            # first window: shared image-side projections
+        total -= (n_windows - 1) * 0.5 * shared * (n_queries - 1)    # later windows: their track-independent temporal half
         gemm += total / n_windows
     return {"gemm": gemm, "conv3d": conv, "attention": attn}
 
