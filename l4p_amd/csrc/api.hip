@@ -8,6 +8,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "engine.hpp"
 
 static thread_local char g_err[512] = "";
@@ -131,10 +133,18 @@ struct EncWs {
 };
 // fc2 (K = mlp_hidden = 6144: 96 k-tiles in a row) at batch 1 gives each CU one latency-bound chain of k-tiles; two K slices
 // double the workgroups in flight (69 -> ~50 us including the reduction pass).  Not worth it once M fills the chip.
+// With enough k-tiles per slice the slices go to the 8-phase kernel instead: as many slices of the 256x256 tiles as fill the
+// chip about once (batch 1: 48 tiles x 4 = 192 workgroups), the form gemm_launch.inc routes to that kernel.
 static int enc_fc2_splitk(const l4p_engine* e, size_t M) {
     const l4p_encoder_cfg& c = e->enc;
     const size_t tiles = ((M + 127) / 128) * (((size_t)c.dim + 63) / 64);
-    return (e->dtype == L4P_BF16 && tiles < 512 && c.mlp_hidden >= 4096) ? 2 : 1;
+    if (!(e->dtype == L4P_BF16 && tiles < 512 && c.mlp_hidden >= 4096)) return 1;
+    static const int env8 = getenv("L4P_FC2_SPLITK8") ? atoi(getenv("L4P_FC2_SPLITK8")) : -1;  // (A/B aid: 0 = the 2-slice form, n = n slices)
+    const bool no8 = env8 == 0;
+    const size_t t8 = ((M + 255) / 256) * (((size_t)c.dim + 255) / 256);
+    const int sk8 = env8 > 1 ? env8 : (t8 > 0 ? (int)(200 / t8) : 0);  // (48 tiles: 4 slices 72.0 us, 5 slices 73.4, 3 slices 77.7; 2 slices of 128x128 tiles 76.1)
+    if (!no8 && c.dim > 128 && sk8 >= 2 && sk8 <= 8 && t8 * sk8 >= 144 && c.mlp_hidden / sk8 >= 512) return sk8;
+    return 2;
 }
 static EncWs enc_layout(const l4p_engine* e, int B, char* base) {
     const l4p_encoder_cfg& c = e->enc;

@@ -48,9 +48,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     // ---- workgroup -> tile: XCD x gets a contiguous range of tiles (workgroup b runs on XCD b % 8), n fastest, so the
     //      tiles that share an A row panel / the W panels stay inside one L2 ----
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, ntiles = ntn * ntm;
+    // split-K (few tiles, long K: the batch-1 MLP-out projection): slice ksplit of a tile contracts k-tiles [kt0, kt0 + nk) and
+    // leaves a float partial that splitk_finish_kernel sums (fixed order) and finishes, as in gemm_kernel
+    const int nsplit = p.splitk > 1 ? p.splitk : 1;
+    const int ksplit = nsplit > 1 ? (int)blockIdx.x / ntiles : 0;
+    const int bid = (int)blockIdx.x - ksplit * ntiles;
     int tile;
     {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = bid & 7, idx = bid >> 3, q = ntiles >> 3, r = ntiles & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     // Linear order of the tiles: column BANDS of <= 8 tile columns, inside a band m-major with the band's columns fastest.
@@ -130,7 +135,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
             w_src[i][h] = (const char*)((const T*)p.W + (long long)n * p.ldw + cs_w * 8);
         }
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * ksplit / nsplit), nk = (int)((long long)nk_all * (ksplit + 1) / nsplit) - kt0;
     const int kpc = (MODE == 1) ? (p.Cin / BK) : 1;
     const char* zero = (const char*)g_zero_chunk;
 
@@ -154,10 +160,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         long long off;
         int tap = 0;
         if (MODE == 0) {
-            off = (long long)kt * (BK * 2);
+            off = (long long)(kt0 + kt) * (BK * 2);
         } else {
             ConvPos& c = cpos[h];
-            while (c.kt < kt) {  // (one step per call in the main loop; the prologue's first calls start at 0)
+            while (c.kt < kt0 + kt) {  // (one step per call in the main loop; the prologue's first calls start at 0)
                 ++c.kt;
                 c.ci0 += BK;
                 if (c.ci0 == p.Cin) {
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         for (int i = 0; i < A_PASS; ++i) {
             bool ok;
             if (MODE == 0)
-                ok = kt * BK + cs_a * 8 < p.K;
+                ok = kt < nk && (kt0 + kt) * BK + cs_a * 8 < p.K;
             else
                 ok = kt < nk && ((a_mask[i][h] >> tap) & 1u);
             const char* src = ok ? a_src[i][h] + off : zero;
@@ -182,10 +188,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         }
     };
     auto stage_w = [&](int h, int kt, int buf) {
-        const bool ok = kt * BK + cs_w * 8 < p.K;
+        const bool ok = kt < nk && (kt0 + kt) * BK + cs_w * 8 < p.K;
 #pragma unroll
         for (int i = 0; i < W_PASS; ++i) {
-            const char* src = ok ? w_src[i][h] + (long long)kt * (BK * 2) : zero;
+            const char* src = ok ? w_src[i][h] + (long long)(kt0 + kt) * (BK * 2) : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src,
                                              (lptr_t)(smem + buf * BUF + 2 * A_HALF + h * W_HALF + (i * 512 + wave * 64) * 16), 16, 0, 0);
         }
@@ -291,6 +297,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with the trailing barrier of the delayed group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (only zero-chunk dummies are still in flight)
 
+    if (nsplit > 1) {  // raw float partial [ksplit][M][N]; bias / activation / residuals / conversion: splitk_finish_kernel
+        const int nb2 = n0 + wc * 64 + 4 * TN * kg;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + li;
+            if (m >= p.M) continue;
+            float* pp = p.partial + ((long long)ksplit * p.M + m) * p.N + nb2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (nb2 + 4 * j < p.N) *(f32x4*)(pp + 4 * j) = acc[i][j];
+        }
+        return;
+    }
 #ifdef GEMM_DBG_NOEPI  // (tools/probes/gemm_variants.hip: main-loop-only timing)
 #pragma unroll
     for (int i = 0; i < TM; ++i)

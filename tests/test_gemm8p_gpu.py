@@ -89,6 +89,41 @@ def test_gemm8p_gelu_and_f32_residual_inplace(dev):
     check(x, h.float().cpu() @ w2_ref.t() + b2 + res, MODE, False)
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(2048, 1408, 6144, 5),   # the batch-1 MLP-out projection: 48 tiles x 5 slices, 19.2 k-tiles each
+                                        (2304, 1416, 4104, 4)])  # ragged M / N / K (64.1 k-tiles: slices of 16, 16, 16, 17)
+def test_gemm8p_splitk_f32_residual_inplace(dev, M, N, K, sk):
+    """Split-K on the 8-phase kernel: slices of the 256x256 tiles leave float partials, splitk_finish_kernel sums them in
+    slice order and applies bias + the float residual in place (the encoder's fc2 at batch 1, api.hip:enc_fc2_splitk)."""
+    a, a_ref = as_mode(rnd((M, K), 26), MODE)
+    w, w_ref = as_mode(rnd((N, K), 27, K ** -0.5), MODE)
+    bias = rnd((N,), 28)
+    res = rnd((M, N), 29, 3.0)
+    x = res.clone().cuda()
+    wp = ops.pad_rows(w, 256)
+    partial = torch.empty((sk, M, N), dtype=torch.float32, device="cuda")
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = a.data_ptr(), K, wp.data_ptr(), K
+    d.M, d.N, d.K = M, N, K
+    d.bias = bias.cuda().data_ptr()
+    bias_dev = bias.cuda()
+    d.bias = bias_dev.data_ptr()
+    d.res1, d.res_f32, d.ldr = x.data_ptr(), 1, N
+    d.out_f32, d.ldc = x.data_ptr(), N
+    d.epi = EPI_DENSE
+    d.splitk, d.partial = sk, partial.data_ptr()
+    with prof_tags() as p:
+        _lib.check(_lib.load().l4p_gemm(torch.cuda.current_stream().cuda_stream, MODE, C.byref(d)), "l4p_gemm")
+    tags = [ln[1] for ln in p.lines if ln[0] == "gemm"]
+    assert tags and all(f" 8p sk{sk} " in t for t in tags), tags
+    check(x, a_ref @ w_ref.t() + bias + res, MODE, False)
+    # run-to-run bit-reproducible (fixed summation order of the slices)
+    x2 = res.clone().cuda()
+    d.res1 = d.out_f32 = x2.data_ptr()
+    _lib.check(_lib.load().l4p_gemm(torch.cuda.current_stream().cuda_stream, MODE, C.byref(d)), "l4p_gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(x, x2)
+
+
 def test_gemm8p_two_residuals_T(dev):
     """DPT skip connections: two residuals stored in the engine dtype + ReLU."""
     M, N, K = 65536, 256, 256
