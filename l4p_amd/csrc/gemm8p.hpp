@@ -26,7 +26,9 @@
 #ifdef GEMM_PROBE_VARIANTS
 __device__ int g_tile_gm = 0;
 #endif
-template <int MODE, int WR, int WC>
+// SPLITK is a compile-time form: the k-range arithmetic it adds to the staging segments of every phase cost the plain kernel
+// 1.7 % of the c3 step when it was a run-time condition
+template <int MODE, int WR, int WC, bool SPLITK = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
     typedef bf16_t T;
@@ -50,9 +52,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM, ntiles = ntn * ntm;
     // split-K (few tiles, long K: the batch-1 MLP-out projection): slice ksplit of a tile contracts k-tiles [kt0, kt0 + nk) and
     // leaves a float partial that splitk_finish_kernel sums (fixed order) and finishes, as in gemm_kernel
-    const int nsplit = p.splitk > 1 ? p.splitk : 1;
-    const int ksplit = nsplit > 1 ? (int)blockIdx.x / ntiles : 0;
-    const int bid = (int)blockIdx.x - ksplit * ntiles;
+    const int nsplit = SPLITK ? p.splitk : 1;
+    const int ksplit = SPLITK ? (int)blockIdx.x / ntiles : 0;
+    const int bid = SPLITK ? (int)blockIdx.x - ksplit * ntiles : (int)blockIdx.x;
     int tile;
     {
         const int xcd = bid & 7, idx = bid >> 3, q = ntiles >> 3, r = ntiles & 7;
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         }
 
     const int nk_all = (p.K + BK - 1) / BK;
-    const int kt0 = (int)((long long)nk_all * ksplit / nsplit), nk = (int)((long long)nk_all * (ksplit + 1) / nsplit) - kt0;
+    const int kt0 = SPLITK ? (int)((long long)nk_all * ksplit / nsplit) : 0;
+    const int nk = SPLITK ? (int)((long long)nk_all * (ksplit + 1) / nsplit) - kt0 : nk_all;
     const int kpc = (MODE == 1) ? (p.Cin / BK) : 1;
     const char* zero = (const char*)g_zero_chunk;
 
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         for (int i = 0; i < A_PASS; ++i) {
             bool ok;
             if (MODE == 0)
-                ok = kt < nk && (kt0 + kt) * BK + cs_a * 8 < p.K;
+                ok = (!SPLITK || kt < nk) && (kt0 + kt) * BK + cs_a * 8 < p.K;
             else
                 ok = kt < nk && ((a_mask[i][h] >> tap) & 1u);
             const char* src = ok ? a_src[i][h] + off : zero;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         }
     };
     auto stage_w = [&](int h, int kt, int buf) {
-        const bool ok = kt < nk && (kt0 + kt) * BK + cs_w * 8 < p.K;
+        const bool ok = (!SPLITK || kt < nk) && (kt0 + kt) * BK + cs_w * 8 < p.K;
 #pragma unroll
         for (int i = 0; i < W_PASS; ++i) {
             const char* src = ok ? w_src[i][h] + (long long)(kt0 + kt) * (BK * 2) : zero;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with the trailing barrier of the delayed group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (only zero-chunk dummies are still in flight)
 
-    if (nsplit > 1) {  // raw float partial [ksplit][M][N]; bias / activation / residuals / conversion: splitk_finish_kernel
+    if constexpr (SPLITK) {  // raw float partial [ksplit][M][N]; bias / activation / residuals / conversion: splitk_finish_kernel
         const int nb2 = n0 + wc * 64 + 4 * TN * kg;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
