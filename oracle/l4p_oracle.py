@@ -12,9 +12,10 @@ product path (l4p_amd/*) never does and fails loudly when the HIP library is mis
 Parity status: encoder, DPT heads, LstSq window stitching, tracker (incl. multi-window memory /
 re-seeding), rays->camera with given intrinsics and the multi-window joint depth + camera flow
 (oracle/joint_oracle.py: point maps, q98 threshold, similarity apply, stitching) are pinned by golden
-vectors.  The RANDOM DRAWS of the two third-party RANSAC steps of the reference (cv2.findHomography /
-RQDecomp3x3, skimage.measure.ransac — unpinned versions, not installed here) are "parity unpinned":
-see DESIGN.md.
+vectors, and so is the K-estimation flow of the shipped default (use_intrinsics=false) AROUND its two cv2
+calls (tools/gen_golden_intrinsics.py: the reference run with deterministic stand-ins in its cv2 stub).
+The RANDOM DRAWS of the two third-party RANSAC steps of the reference (cv2.findHomography, skimage.measure.
+ransac — unpinned versions, not installed here) are "parity unpinned": see DESIGN.md section 7.
 """
 from __future__ import annotations
 
@@ -234,6 +235,107 @@ def rays_to_cameras(rays_b6thw: Tensor, Kn_b44t: Tensor) -> Tensor:
     tr = -torch.matmul(E[:, :3, :3].permute(0, 3, 1, 2), centers[..., None]).squeeze(3)
     E[:, :3, -1] = tr.permute(0, 2, 1)
     return E
+
+
+# ---- K estimation (shipped default: use_intrinsics=false, fixed_intrinsics=true) ------------------------------------
+# The reference estimates K from the first frame's ray map with cv2.findHomography(RANSAC) + cv2.RQDecomp3x3
+# (geometry_utils.py:436-448; opencv-python unpinned in env/requirements.txt, not installed here: the RANSAC draw cannot be
+# pinned).  Everything AROUND those two calls is restated here with the two calls injectable, and pinned against the imported
+# reference with the same stand-ins installed in its cv2 stub (tools/gen_golden_intrinsics.py).
+def dlt_homography(src_n2: np.ndarray, dst_n2: np.ndarray, method=None, reproj_threshold=None):
+    """Deterministic stand-in for cv2.findHomography(src, dst, cv2.RANSAC, thr): Hartley-normalised DLT over ALL
+    correspondences in float64 (no consensus step).  Returns (H 3x3 float64 with H[2,2] = 1, None) like cv2."""
+    src, dst = np.asarray(src_n2, np.float64), np.asarray(dst_n2, np.float64)
+
+    def norm(p):
+        c = p.mean(0)
+        s = np.sqrt(2.0) / max(np.sqrt(((p - c) ** 2).sum(1)).mean(), 1e-12)
+        T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+        return (p - c) * s, T
+
+    a, Ta = norm(src)
+    b, Tb = norm(dst)
+    n = a.shape[0]
+    A = np.zeros((2 * n, 9))
+    A[0::2, 0:2], A[0::2, 2] = a, 1.0
+    A[0::2, 6:8], A[0::2, 8] = -b[:, :1] * a, -b[:, 0]
+    A[1::2, 3:5], A[1::2, 5] = a, 1.0
+    A[1::2, 6:8], A[1::2, 8] = -b[:, 1:2] * a, -b[:, 1]
+    _, _, Vt = np.linalg.svd(A, full_matrices=False)
+    Hn = Vt[-1].reshape(3, 3)
+    H = np.linalg.inv(Tb) @ Hn @ Ta
+    return H / H[2, 2], None
+
+
+def rq3(H: np.ndarray):
+    """Deterministic stand-in for cv2.RQDecomp3x3(H): H = K R with K upper triangular (positive diagonal) and R orthogonal.
+    Returns a tuple indexed like cv2's: [1] = K, [2] = R."""
+    H = np.asarray(H, np.float64)
+    P = np.eye(3)[::-1]
+    q, r = np.linalg.qr((P @ H).T)
+    K, R = P @ r.T @ P, P @ q.T
+    S = np.diag(np.sign(np.diag(K)) + (np.diag(K) == 0))
+    K, R = K @ S, S @ R
+    return None, K, R
+
+
+def optimal_rotation_intrinsics(rays_origin: Tensor, rays_target: Tensor, find_h=dlt_homography, rq=rq3,
+                                z_threshold: float = 1e-4, reproj_threshold: float = 0.2):
+    """compute_optimal_rotation_intrinsics geometry_utils.py:409-456 with the two cv2 calls injected."""
+    z_mask = torch.logical_and(torch.abs(rays_target) > z_threshold, torch.abs(rays_origin) > z_threshold)[:, 2]
+    rt, ro = rays_target[z_mask], rays_origin[z_mask]
+    ro = ro[:, :2] / ro[:, -1:]
+    rt = rt[:, :2] / rt[:, -1:]
+    A, _ = find_h(ro.numpy(), rt.numpy(), None, reproj_threshold)
+    A = torch.from_numpy(np.asarray(A)).float()
+    if torch.linalg.det(A) < 0:
+        A = -A
+    Hm = torch.linalg.inv(A.float())  # H = K @ R
+    out = rq(Hm.numpy())
+    K = np.asarray(out[1])
+    K = K / K[2, 2]
+    return torch.from_numpy(np.asarray(out[2])).float(), torch.from_numpy(K).float(), Hm
+
+
+def rays_to_cameras_fixed_intrinsics(rays_b6thw: Tensor, output_size: Tuple[int, int], find_h=dlt_homography, rq=rq3,
+                                     k_override=None) -> Tuple[Tensor, Tensor]:
+    """rays_to_cameras_and_fixed_per_frame_intrinsics geometry_utils.py:493-579 (ctr_only=False): K from the FIRST frame's
+    rays on the ray grid (identity-intrinsics rays -> predicted directions), repeated over the window; rotations by Kabsch
+    against rays of that K; translation from the ray intersection; K rescaled to ``output_size``.  ``k_override(b)``
+    supplies the 3x3 ray-grid K instead of estimating it (closed form on a supplied estimate: how the engine's own
+    estimator is tied to everything downstream of it).  Returns (cam_T_world [B,4,4,T], K [B,4,4,T] in output pixels)."""
+    B, _, T, h, w = rays_b6thw.shape
+    rays = rays_b6thw.float()
+    origins, directions = plucker_to_point_direction(rays)
+    o = origins.permute(0, 2, 3, 4, 1).reshape(-1, h * w, 3)
+    d = directions.permute(0, 2, 3, 4, 1).reshape(-1, h * w, 3)
+    centers = intersect_skew_lines(o, d).reshape(B, T, 3)
+    j, i = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    pix = torch.stack([i.expand(B, -1, -1), j.expand(B, -1, -1), torch.ones_like(i).expand(B, -1, -1)], dim=-1)
+    E = torch.zeros(B, 4, 4, T)
+    E[:, 3, 3] = 1.0
+    Kest = torch.zeros_like(E)
+    Kest[:, 3, 3] = 1.0
+    Kest[:, 2, 2] = 1.0
+    eye = torch.eye(3)[None, :, :, None].repeat(B, 1, 1, T)
+    rd = torch.einsum("btmn,bhwn->bthwm", torch.inverse(eye.permute(0, 3, 1, 2)), pix)
+    rd = rd / rd.norm(dim=-1, keepdim=True)
+    for b in range(B):
+        if k_override is not None:
+            K = k_override(b).float()
+        else:
+            _, K, _ = optimal_rotation_intrinsics(rd[b, 0].reshape(-1, 3).float(), directions[b, :, 0].reshape(3, -1).T.float(),
+                                                  find_h, rq, reproj_threshold=0.2)
+        Kest[b, :3, :3, :] = K[:, :, None].repeat(1, 1, T)
+    rd = torch.einsum("btmn,bhwn->bthwm", torch.inverse(Kest[:, :3, :3].permute(0, 3, 1, 2)), pix)
+    rd = rd / rd.norm(dim=-1, keepdim=True)
+    for b in range(B):
+        for t in range(T):
+            E[b, :3, :3, t] = kabsch_rotation(rd[b, t].reshape(-1, 3), directions[b, :, t].reshape(3, -1).T)
+    tr = -torch.matmul(E[:, :3, :3].permute(0, 3, 1, 2), centers[..., None]).squeeze(3)
+    E[:, :3, -1] = tr.permute(0, 2, 1)
+    Ho, Wo = output_size
+    return E, denormalize_intrinsics(normalize_intrinsics(Kest, h, w), Ho, Wo)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -465,12 +567,16 @@ class OracleModel:
         self.always_use_windowed_version = True  # configs/model.yaml:19; False: a 16-frame clip takes forward_single_window
         self.depth_align_type = "affine"  # configs/model.yaml (default of VideoMAEDepthDPTHead); "linear": LinearAligner mean
         self.seam_log: list = []
+        # use_intrinsics=False (the shipped default): the two third-party calls of the K estimation (stand-ins pinned against
+        # the reference, tools/gen_golden_intrinsics.py), or a supplied ray-grid K per batch item instead of an estimate
+        self.find_h, self.rq, self.k_override = dlt_homography, rq3, None
+        self.first_window_K: Optional[Tensor] = None
         # actpost / fusion scale factors: dense_heads.py:30-31 and :269-271
         self._actpost = lambda t: ((1, 0, 0), (1, 0, 0), (0, 0, 0), (-1, -1, -1)) if t == "camray" else ((1, 2, 2), (1, 1, 1), (0, 0, 0), (-1, -1, -1))
         self._fusion = lambda t: ((1, 1, 1), (1, 1, 1), (2, 1, 1), (2, 2, 2)) if t == "camray" else ((1, 2, 2), (1, 2, 2), (2, 2, 2), (2, 2, 2))
 
     # ---- dense heads: dense_heads.py:66-74,172-182,208-217,292-352 -------------------------------
-    def dense_single(self, task: str, feats: Sequence[Tensor], intrinsics_b44t: Optional[Tensor]) -> Dict[str, Tensor]:
+    def dense_single(self, task: str, feats: Sequence[Tensor], intrinsics_b44t: Optional[Tensor], win_id: int = 0) -> Dict[str, Tensor]:
         cfg = self.cfg
         osz = (16, 16, 16) if task == "camray" else None
         raw = dpt_forward(self.sd, task, feats, cfg, self._actpost(task), self._fusion(task), osz)
@@ -481,12 +587,26 @@ class OracleModel:
         if task == "dyn_mask":
             return {"dyn_mask_est_b1thw": raw}
         if task == "camray":
-            if not self.use_intrinsics:
-                raise NotImplementedError("K estimation uses cv2 RANSAC in the reference: parity unpinned")
             T, H, W = cfg.frames, cfg.img, cfg.img
-            E = rays_to_cameras(raw.float(), normalize_intrinsics(intrinsics_b44t, H, W).float())
+            Kest = None
+            if self.use_intrinsics:
+                E = rays_to_cameras(raw.float(), normalize_intrinsics(intrinsics_b44t, H, W).float())
+            else:
+                # VideoMAETraj3DDPTHead.forward with use_intrinsics=False, fixed_intrinsics=True (dense_heads.py:303-334):
+                # K is estimated on the first window and reported for every later one, whose rotations use the INPUT K
+                if win_id == 0:
+                    self.first_window_K = None
+                if self.first_window_K is None:
+                    E, Kest = rays_to_cameras_fixed_intrinsics(raw.float(), (H, W), self.find_h, self.rq, self.k_override)
+                    self.first_window_K = Kest.clone()
+                else:
+                    E = rays_to_cameras(raw.float(), normalize_intrinsics(intrinsics_b44t, H, W).float())
+                    Kest = self.first_window_K.clone()
             pose = torch.linalg.inv(E.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
-            return {"traj3d_est_b16t": pose.reshape(pose.shape[0], 16, T)}
+            out = {"traj3d_est_b16t": pose.reshape(pose.shape[0], 16, T)}
+            if Kest is not None:
+                out["traj3d_intrinsics_est_b16t"] = Kest.reshape(Kest.shape[0], 16, T)
+            return out
         raise KeyError(task)
 
     def dense_windowed(self, task: str, feats2d: Sequence[Sequence[Tensor]], strides: Sequence[int],
@@ -496,7 +616,7 @@ class OracleModel:
         T = int(strides[-1]) + ws
         buf, key = None, None
         for wi, st in enumerate(int(s) for s in strides):
-            o = self.dense_single(task, feats2d[wi], intrinsics_b44t[..., st:st + ws])
+            o = self.dense_single(task, feats2d[wi], intrinsics_b44t[..., st:st + ws], wi)
             key = next(k for k in o if "intrinsics" not in k)
             out = o[key]
             if buf is None:
@@ -529,9 +649,11 @@ class OracleModel:
             st = int(strides[win_id])
             K = intrinsics_b44t[..., st:st + ws]
             d = self.dense_single("depth", feats2d[win_id], K)["depth_est_b1thw"]
-            c = self.dense_single("camray", feats2d[win_id], K)["traj3d_est_b16t"]
+            co = self.dense_single("camray", feats2d[win_id], K, win_id)
+            c = co["traj3d_est_b16t"]
             # no estimated K when use_intrinsics: the input K is echoed (dense_heads.py:419-422)
-            return {"depth": d, "camray": c, "camray_intrinsics_est": K.clone().reshape(1, 16, ws)}
+            return {"depth": d, "camray": c,
+                    "camray_intrinsics_est": co.get("traj3d_intrinsics_est_b16t", K.clone().reshape(1, 16, ws))}
 
         self.seam_log = []
         est = jo.joint_windowed(heads, strides, ws, self.seam, self.seam_log)
