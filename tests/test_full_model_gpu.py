@@ -135,3 +135,32 @@ def test_batch4_bf16_equals_four_batch1_forwards_and_goldens(dev, full_sd):
     print("B=4 clip 0 vs goldens:", {k: f"{v:.2e}" for k, v in rep0.items()})
     bad = {k: v for k, v in rep0.items() if v > bf16_gate(k)}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_full_size_two_windows_vs_reference_goldens(dev, full_sd, precision):
+    """The windowed path (configs[4]) at the REAL geometry: 24 frames = 2 overlapping windows through the reference itself
+    (tools/gen_golden_full_windows.py -> tests/golden/full_T24_windows.npz): depth with the inverse-depth LstSq seam, backward
+    flow, motion mask, and 4 tracks carried across the seam (memory tokens, re-seeding).  f32 engine 1e-3 relative-to-max;
+    bf16 engine rel-L2 at the full-size gates of this file."""
+    tasks = ["depth", "flow_2d_backward", "dyn_mask", "track_2d"]
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "full_T24_windows.npz"))
+    m = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision=precision)
+    m.load_state_dict({"l4p_model." + k: v for k, v in full_sd.items()})
+    batch = make_batch(24, 4)
+    with torch.no_grad():
+        out = m.forward({k: v.clone() for k, v in batch.items()}, tasks)
+    torch.cuda.synchronize()
+    report = {}
+    for k in gold.files:
+        y = out[k].float().cpu().reshape(-1)
+        g = torch.from_numpy(gold[k]).reshape(-1)
+        s = y[sample_indices(y.numel())] if y.numel() > 4096 else y
+        assert s.shape == g.shape, (k, tuple(s.shape), tuple(g.shape))
+        report[k] = (float((s - g).abs().max() / g.abs().max()), float((s - g).norm() / g.norm()))
+    print(report)
+    for k, (emax, el2) in report.items():
+        if precision == "32-true":
+            assert emax <= 1e-3, (k, emax)
+        else:
+            assert el2 <= 3e-2, (k, el2)
