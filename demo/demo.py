@@ -52,7 +52,7 @@ def main():
         model = prepare_model(model_config_path=args.config, ckpt_path=args.ckpt, max_queries=args.max_queries,
                               precision=precision, accelerator=accelerator)
 
-    model.l4p_model.window_batch = 4  # windows of a long clip go through encoder + dense decoders four at a time
+    model.l4p_model.window_batch = 8  # windows of a long clip go through encoder + dense decoders eight at a time
     dataset = VideoDataset(video_paths=args.videos, crop_size=(args.frames, 224, 224), estimation_directions=[1],
                            track_2d_querry_sampling_spacing=args.spacing, frames=frames)
     loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False)
