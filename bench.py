@@ -11,7 +11,7 @@ broadcast of the packed weight arena before the timed region.  Rank 0 prints ONE
 
 --workload demo: the generic-video case of the reference's demo (demo/demo.py:84-100,38-40): one decoded 480x854 video per
 GPU -> clip preparation -> 64 frames = 7 windows, tasks depth + flow + dyn_mask + track_2d, 625 grid queries (spacing 0.04)
-tracked in chunks of max_queries = 128, windows batched four at a time through encoder and decoders (row f4 of SURVEY.md 8).
+tracked in chunks of max_queries = 128, all 7 windows batched through encoder and decoders (row f4 of SURVEY.md 8).
 
 Workloads (BASELINE.json configs): c3 = all heads, bf16, batch 4 clips per GPU (DEFAULT: BASELINE.json's metric is
 "frames/sec (all heads)", configs[2] is its single-GPU configuration and configs[3] the same work data-parallel over 8
@@ -187,12 +187,54 @@ def build_workload(tasks, B, nq, device, rank=0, frames=16, same_data=False, use
     K[0, 2] = K[1, 2] = 112.0
     batch = {"rgb_b3thw": rgb.to(device), "intrinsics_b44t": K[None, :, :, None].repeat(B, 1, 1, frames).to(device)}
     if "track_2d" in tasks:
-        q = torch.zeros(1, nq, 3)
-        for i in range(nq):
-            q[0, i] = torch.tensor([0.5, 14.0 + 28.0 * (i % 8) + 0.5, 14.0 + 28.0 * ((i // 8) % 8) + 0.5])
+        from tests.golden_utils import grid_queries
+
+        q = grid_queries(nq)
         batch["track_2d_pointquerries_bn3"] = q.repeat(B, 1, 1).to(device)  # every clip tracks its own nq queries
         batch["track_2d_pointlabels_bn"] = torch.ones(B, nq, device=device)
     return model, batch, sd
+
+
+def c5_phase_times(net, batch, tasks, rank, world, group):
+    """configs[4] once more, phase by phase with a device synchronisation between the phases (outside the timed region):
+    phase 1 = encoder + dense decoders of this rank's windows (sharded: all the FLOPs), exchange = the all-gather of the
+    decoded windows, phase 3 = stitching / seam alignment / pose chaining (REPLICATED on every rank) + the tracker recursion
+    over all windows on this rank's query shard.  Phase 3 is the Amdahl term of the only strong-scaling configuration; it is
+    measurable on one GPU, and so is what one of EIGHT ranks would run of it (dense stitch in full + the tracker on an
+    eighth of the queries).  All ranks execute this (the exchange is a collective); times are this rank's."""
+    from l4p_amd import parallel as par
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, (time.perf_counter() - t0) * 1e3
+
+    data = {k: (v.to(net.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    nwin = len(net.time_strides(data["rgb_b3thw"].shape[2]))
+    dense = [t for t in tasks if t != "track_2d"]
+    with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
+        local, p1 = timed(lambda: par.decode_local_windows(net, data, tasks, rank, world, group))
+        gathered, ex = timed(lambda: par.all_gather_windows(local, nwin, rank, world))
+        _, p3 = timed(lambda: par.stitch_gathered_windows(net, data, tasks, gathered, rank, world))
+        _, p3_dense = timed(lambda: par.stitch_gathered_windows(net, data, dense, gathered, rank, world))
+        res = {"phase1_ms": round(p1, 3), "exchange_ms": round(ex, 3), "phase3_ms": round(p3, 3), "phase3_dense_ms": round(p3_dense, 3)}
+        if "track_2d" in tasks:
+            _, trk = timed(lambda: par.stitch_gathered_windows(net, data, ["track_2d"], gathered, rank, world))
+            res["phase3_track_ms"] = round(trk, 3)
+            if world == 1:
+                _, trk8 = timed(lambda: par.stitch_gathered_windows(net, data, ["track_2d"], gathered, 0, 8))
+                res["phase3_track_ms_on_an_eighth_of_the_queries"] = round(trk8, 3)
+    if world == 1:
+        s_ = p3 / (p1 + p3)
+        # (a) everything in phase 3 taken as serial (stitch AND the whole tracker): 1 / (s + (1 - s) / 8)
+        res["implied_8gpu_speedup_ceiling"] = round(1.0 / (s_ + (1.0 - s_) / 8.0), 3)
+        # (b) as the path shards it: windows over 8 ranks, dense stitch replicated, tracker on an eighth of the queries
+        if "phase3_track_ms_on_an_eighth_of_the_queries" in res:
+            res["implied_8gpu_speedup_query_sharded_tracker"] = round(
+                (p1 + p3) / (p1 / 8.0 + p3_dense + res["phase3_track_ms_on_an_eighth_of_the_queries"]), 3)
+    return res
 
 
 def bench_prep(args, rank, world, device, lib):
@@ -329,7 +371,7 @@ def bench_demo(args, rank, world, device, lib, selftest):
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded 480x854 video, name-seeded random weights)",
         "rccl_ranks": selftest["ranks"] if selftest.get("backend") == "nccl" else (1 if world == 1 else 0),
         "config": {"workload": f"demo generic video (demo/demo.py:84-100): 1 clip of {T_out} frames = {nwin} windows per GPU, tasks "
-                               f"{'+'.join(DEMO_TASKS)}, {nq} grid queries in chunks of 128, windows batched 4 at a time",
+                               f"{'+'.join(DEMO_TASKS)}, {nq} grid queries in chunks of {net.task_heads['track_2d'].max_queries}, windows batched {net.window_batch} at a time",
                    "queries": nq, "windows": nwin, "tasks": DEMO_TASKS},
         "roofline": {"kernel": {"gemm": "gemm8p_kernel<0> / gemm_kernel<bf16,MODE0>", "conv3d": "gemm8p_kernel<1> / gemm_kernel<bf16,MODE1>",
                                 "attention": "attn_kernel<bf16,96,64>"}[dom], "bound": "mfma", "achieved": classes[dom]["tflops"],
@@ -422,6 +464,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    phases = c5_phase_times(model.l4p_model, batch, tasks, rank, world, args.group) if c5 else None
 
     if rank != 0:
         return
@@ -443,6 +486,8 @@ def main():
                    "parallelism": (f"windows sharded over {world} rank(s); one all-gather of the decoded windows, stitching replicated, track queries sharded" if c5
                                    else f"dp{world} (clips sharded, no collective in the step)")},
     }
+    if phases:
+        res.update(phases)
     if not args.no_prof:
         prof = read_prof(lib)
         nwin_total = (args.frames - 16) // 8 + 1 if c5 else 1

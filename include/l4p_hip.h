@@ -210,11 +210,18 @@ int l4p_rays_to_intrinsics(l4p_stream stream, const float* rays, float* out_K, f
  * validated against synthetic ground truth ("parity unpinned").
  * ---------------------------------------------------------------------------------------------- */
 
-/* EXACT q-quantile of n non-negative floats with torch.quantile's linear interpolation (aligner.py:187): radix select
- * of the order statistics floor(q (n-1)) and the next one on the float bit patterns, then ATen's lerp.
- * ws >= L4P_QUANTILE_WS_UINTS uints. */
+/* EXACT q-quantile of n finite floats (either sign) with torch.quantile's linear interpolation (aligner.py:187): radix
+ * select of the order statistics floor(q (n-1)) and the next one on an order-preserving integer image of the float bit
+ * patterns, then ATen's lerp.  ws >= L4P_QUANTILE_WS_UINTS uints. */
 #define L4P_QUANTILE_WS_UINTS 2052
 int l4p_quantile(l4p_stream stream, const float* x, long long n, float q, unsigned* ws, float* out);
+/* EXACT order statistic `rank` (0-based, ascending) of n finite floats; torch.median(x) = rank (n - 1) / 2. */
+int l4p_select_rank(l4p_stream stream, const float* x, long long n, long long rank, unsigned* ws, float* out);
+/* LinearAligner(method="median").solve (aligner.py:96-107): sol[0] = torch.median over f(target) / (f(pred) + 1e-8)
+ * (f = safe_inverse when `inverse`, misc.py:48-62; float arithmetic; the LOWER median as torch.median returns it),
+ * sol[1] = 0, so that l4p_affine_align_apply applies it.  ratios: n floats of scratch; ws >= L4P_QUANTILE_WS_UINTS uints. */
+int l4p_ratio_median_solve(l4p_stream stream, const float* pred, const float* target, long long n, int inverse,
+                           float* ratios, unsigned* ws, float* sol);
 
 /* world-space points of a hashed 1/ratio pixel subset of F frames: depth [F][H*W], K and P (world_T_cam)
  * [F][16] row-major 4x4  ->  out [F*(H*W/ratio)][3] */

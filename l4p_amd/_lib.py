@@ -103,6 +103,8 @@ SIGNATURES = {
     "l4p_rays_to_pose": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     "l4p_rays_to_intrinsics": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _F]),
     "l4p_quantile": (_I, [_VP, _VP, _LL, _F, _VP, _VP]),
+    "l4p_select_rank": (_I, [_VP, _VP, _LL, _LL, _VP, _VP]),
+    "l4p_ratio_median_solve": (_I, [_VP, _VP, _VP, _LL, _I, _VP, _VP, _VP]),
     "l4p_point_map_samples": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, C.c_uint]),
     "l4p_similarity_ransac": (_I, [_VP, _VP, _VP, _I, _VP, _F, _I, _I, C.c_uint, _VP, _VP]),
     "l4p_similarity_apply": (_I, [_VP, _VP, _VP, _I, _VP, _LL]),

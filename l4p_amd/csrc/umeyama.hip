@@ -22,7 +22,13 @@ __device__ __forceinline__ unsigned hash_u32(unsigned x) {  // PCG-style integer
 // last pass, [3] bits of min{x > x_(lo)}, [4 ..] 2048 histogram bins.
 // -------------------------------------------------------------------------------------------------
 #define QSEL_BINS 2048
-__device__ __forceinline__ unsigned qsel_key(float v) { return __float_as_uint(fmaxf(v, 0.f)); }
+// order-preserving map float -> unsigned for every finite value of either sign (negative: all bits flipped, non-negative:
+// sign bit set; -0.0 lands just below +0.0 and both map back to a zero), and its inverse
+__device__ __forceinline__ unsigned qsel_key(float v) {
+    const unsigned b = __float_as_uint(v);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float qsel_unkey(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
 
 // Depth values crowd into a handful of exponent bins, so the histogram is built per workgroup in LDS first (same-key lanes
 // of a wave are merged with a ballot before they touch the bin: one LDS atomic per distinct key of the wave for the first
@@ -115,9 +121,9 @@ __global__ void qsel_next_kernel(const float* __restrict__ x, long long n, unsig
 }
 __global__ void qsel_finish_kernel(const unsigned* __restrict__ ws, float weight, float* __restrict__ out) {
     if (threadIdx.x != 0) return;
-    const float a = __uint_as_float(ws[0]);
+    const float a = qsel_unkey(ws[0]);
     // rank lo sits at offset ws[1] inside the ws[2] copies of a: rank lo + 1 is another copy unless it was the last one
-    const float b = (ws[1] + 1 < ws[2] || ws[3] == 0xFFFFFFFFu) ? a : __uint_as_float(ws[3]);
+    const float b = (ws[1] + 1 < ws[2] || ws[3] == 0xFFFFFFFFu) ? a : qsel_unkey(ws[3]);
     // ATen lerp: the weight < 0.5 form and its mirror (aten/src/ATen/native/Lerp.h)
     const float d = b - a;
     out[0] = weight < 0.5f ? __builtin_fmaf(weight, d, a) : b - d * (1.f - weight);
@@ -409,7 +415,10 @@ __global__ void scale_by_device_scalar_kernel(float* __restrict__ x, long long n
 
 extern "C" {
 
-/* exact q-quantile (torch.quantile, linear interpolation) of n non-negative floats. ws: >= L4P_QUANTILE_WS_UINTS uints. */
+// order statistic `lo` (0-based) of x[0..n) and the next one, blended with `weight` (ATen's lerp); weight 0: the statistic itself
+static int qsel_launch(hipStream_t s, const float* x, long long n, unsigned lo, float weight, unsigned* ws, float* out);
+
+/* exact q-quantile (torch.quantile, linear interpolation) of n finite floats. ws: >= L4P_QUANTILE_WS_UINTS uints. */
 int l4p_quantile(l4p_stream s_, const float* x, long long n, float q, unsigned* ws, float* out) {
     hipStream_t s = (hipStream_t)s_;
     if (n < 1 || n > 0x7FFFFFFFll || !(q >= 0.f && q <= 1.f)) {
@@ -420,7 +429,46 @@ int l4p_quantile(l4p_stream s_, const float* x, long long n, float q, unsigned* 
     // torch.quantile computes the rank in the input dtype: pos = q * (n - 1) rounded to float
     const float pos = q * (float)(n - 1);
     const float lo_f = floorf(pos);
-    const unsigned lo = (unsigned)lo_f;
+    return qsel_launch(s, x, n, (unsigned)lo_f, pos - lo_f, ws, out);
+}
+
+/* the order statistic of rank `rank` (0-based, ascending) of n finite floats, exact.  torch.median(x) is rank (n - 1) / 2. */
+int l4p_select_rank(l4p_stream s_, const float* x, long long n, long long rank, unsigned* ws, float* out) {
+    hipStream_t s = (hipStream_t)s_;
+    if (n < 1 || n > 0x7FFFFFFFll || rank < 0 || rank >= n) {
+        l4p_set_error("l4p_select_rank: need 1 <= n < 2^31 and 0 <= rank < n (n=%lld rank=%lld)", n, rank);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_ELEMENTWISE, s, "l4p_select_rank");
+    return qsel_launch(s, x, n, (unsigned)rank, 0.f, ws, out);
+}
+
+// LinearAligner(method="median") (aligner.py:96-107): ratios f(target) / (f(pred) + 1e-8) in float, f = safe_inverse or identity
+__global__ void ratio_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, long long n, int inverse,
+                             float* __restrict__ r) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float p = pred[i], t = tgt[i];
+        const float af = inverse ? (p > 0.f ? 1.0f / p : 0.f) : p, bf = inverse ? (t > 0.f ? 1.0f / t : 0.f) : t;
+        r[i] = bf / (af + 1e-8f);
+    }
+}
+/* sol[0] = torch.median(ratios) = their order statistic (n - 1) / 2 (the LOWER median, as torch returns it), sol[1] = 0.
+ * ratios: n floats of scratch; ws >= L4P_QUANTILE_WS_UINTS uints. */
+int l4p_ratio_median_solve(l4p_stream s_, const float* pred, const float* target, long long n, int inverse, float* ratios,
+                           unsigned* ws, float* sol) {
+    hipStream_t s = (hipStream_t)s_;
+    if (n < 1 || n > 0x7FFFFFFFll) {
+        l4p_set_error("l4p_ratio_median_solve: need 1 <= n < 2^31 (n=%lld)", n);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_ELEMENTWISE, s, "ratio_median");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(ratio_kernel, dim3(grid), dim3(256), 0, s, pred, target, n, inverse & 1, ratios);
+    HIP_TRY(hipMemsetAsync(sol + 1, 0, sizeof(float), s));
+    return qsel_launch(s, ratios, n, (unsigned)((n - 1) / 2), 0.f, ws, sol);
+}
+
+static int qsel_launch(hipStream_t s, const float* x, long long n, unsigned lo, float weight, unsigned* ws, float* out) {
     unsigned init[4] = {0u, lo, 0u, 0xFFFFFFFFu};
     HIP_TRY(hipMemsetAsync(ws, 0, (4 + QSEL_BINS) * sizeof(unsigned), s));
     // (init is tiny and lives on the host stack: three 4-byte memsets keep the call free of host -> device copies)
@@ -434,7 +482,7 @@ int l4p_quantile(l4p_stream s_, const float* x, long long n, float q, unsigned* 
     hipLaunchKernelGGL((qsel_hist_kernel<0, 10, 0xFFFFFC00u>), dim3(grid), dim3(256), 0, s, x, n, ws);
     hipLaunchKernelGGL((qsel_pick_kernel<0, 10, true>), dim3(1), dim3(256), 0, s, ws);
     hipLaunchKernelGGL(qsel_next_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
-    hipLaunchKernelGGL(qsel_finish_kernel, dim3(1), dim3(64), 0, s, ws, pos - lo_f, out);
+    hipLaunchKernelGGL(qsel_finish_kernel, dim3(1), dim3(64), 0, s, ws, weight, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

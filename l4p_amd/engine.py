@@ -30,7 +30,8 @@ class Engine:
             if name.startswith("enc.") or name.startswith("dpt.") or name.startswith("trk."):
                 _lib.check(self.lib.l4p_bind_weight(self.handle, name.encode(), t.data_ptr(), t.numel()), "l4p_bind_weight")
         self._dpt_ws: Dict[Tuple[str, int], torch.Tensor] = {}
-        self._trk_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._trk_ws: Dict[int, torch.Tensor] = {}
+        self._trk_need: Dict[Tuple[int, int], int] = {}
         ec = EncoderCfg(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, head_dim=cfg.head_dim, mlp_hidden=cfg.mlp_hidden,
                         in_chans=cfg.in_chans, frames=cfg.frames, img_h=cfg.img, img_w=cfg.img, pt=cfg.patch[0],
                         ph=cfg.patch[1], pw=cfg.patch[2], patch_kp=int(weights.meta["patch_kp"]), ln_eps=cfg.ln_eps)
@@ -109,16 +110,25 @@ class Engine:
         N, Cc = q_off.shape[0], self.cfg.dim
         T = tcfg.T
         hu = int(hist_uniform)  # 0 per-track history, 1 uniform (first window), 2 second temporal half uniform (later windows)
-        key = (slot, N, hu)
-        ws = self._trk_ws.get(key)
-        if ws is None:
-            need = int(self.lib.l4p_track_window_workspace_bytes(self.handle, C.byref(tcfg), N, hu))
-            if need == 0:
-                raise _lib.L4PHipError("l4p_track_window_workspace_bytes: " + self.lib.l4p_last_error().decode())
-            for k in [k for k in self._trk_ws if k[0] == slot]:  # one workspace per slot: drop the one of another shape
-                del self._trk_ws[k]
+        # ONE workspace per slot, sized for the largest of the three history forms at the largest N seen (a clip's first
+        # window runs hu = 1, its later ones hu = 2, a last chunk has fewer queries: keyed by shape, every forward freed and
+        # re-allocated several hundred MB per clip); it only ever grows
+        need = self._trk_need.get((N, hu))
+        if need is None:
+            for h in (0, 1, 2):
+                nb = int(self.lib.l4p_track_window_workspace_bytes(self.handle, C.byref(tcfg), N, h))
+                if nb == 0:
+                    raise _lib.L4PHipError("l4p_track_window_workspace_bytes: " + self.lib.l4p_last_error().decode())
+                self._trk_need[(N, h)] = nb
+            need = max(self._trk_need[(N, h)] for h in (0, 1, 2))
+            for h in (0, 1, 2):
+                self._trk_need[(N, h)] = need
+        ws = self._trk_ws.get(slot)
+        if ws is None or ws.numel() < need:
+            ws = None
+            self._trk_ws.pop(slot, None)
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self._trk_ws[key] = ws
+            self._trk_ws[slot] = ws
         f32 = dict(dtype=torch.float32, device=self.device)
         traj = torch.empty((N, 2, T), **f32)
         vis = torch.empty((N, T), **f32)

@@ -34,6 +34,7 @@ def _mode(pre_post_fn: Optional[str]) -> int:
 
 AFFINE_SCRATCH_DOUBLES = 4096  # L4P_AFFINE_SCRATCH_DOUBLES (include/l4p_hip.h)
 ALIGN_INVERSE, ALIGN_RATIO_MEAN = 1, 2
+QUANTILE_WS_UINTS = 2052  # L4P_QUANTILE_WS_UINTS
 
 
 class LstSqAffineAligner(WindowOverlapAligner):
@@ -68,9 +69,9 @@ class LstSqAffineAligner(WindowOverlapAligner):
 
 
 class LinearAligner(LstSqAffineAligner):
-    """Scale-only aligner (aligner.py:69-118): scale = mean of f(target) / (f(pred) + 1e-8), shift = 0.  The same two
-    kernels as the affine aligner in their ratio-mean mode.  ``method="median"`` (a selection over 401k ratios) is not
-    built into the engine and is rejected here, at construction."""
+    """Scale-only aligner (aligner.py:69-118): scale = mean or median of f(target) / (f(pred) + 1e-8), shift = 0.
+    ``mean``: the affine aligner's two kernels in their ratio-mean mode.  ``median``: torch.median's LOWER median of the
+    ratios by exact radix selection (l4p_ratio_median_solve; csrc/umeyama.hip qsel_*)."""
 
     _mode_bits = ALIGN_RATIO_MEAN
 
@@ -78,9 +79,22 @@ class LinearAligner(LstSqAffineAligner):
         super().__init__(pre_post_fn)
         if method not in ["mean", "median"]:
             raise ValueError(f"Unknown method: {method}")
-        if method != "mean":
-            raise NotImplementedError("LinearAligner(method='median') is not built into the engine; use 'mean'")
         self.method = method
+
+    def solve(self, pred, target, intrinsics=None, img_info=None, pred_conf=None, target_conf=None):
+        if self.method == "mean":
+            return super().solve(pred, target, intrinsics, img_info)
+        assert pred.is_cuda and pred.dtype == torch.float32 and pred.shape == target.shape
+        lib = _lib.load()
+        bs = pred.shape[0]
+        self.sol = torch.empty(bs, 2, dtype=torch.float32, device=pred.device)
+        n = pred[0].numel()
+        ratios = torch.empty(n, dtype=torch.float32, device=pred.device)
+        ws = torch.empty(QUANTILE_WS_UINTS, dtype=torch.int32, device=pred.device)
+        for b in range(bs):
+            pb, tb = pred[b].contiguous(), target[b].contiguous()
+            _lib.check(lib.l4p_ratio_median_solve(_stream(), _p(pb), _p(tb), n, self.inverse, _p(ratios), _p(ws),
+                                                  self.sol[b].data_ptr()), "l4p_ratio_median_solve")
 
 
 class KabaschUmeyama3DAligner(WindowOverlapAligner):

@@ -79,6 +79,7 @@ class L4P_VideoMAE(torch.nn.Module):
         cam_emb_type: str = "add",
         model_cfg: Optional[ModelCfg] = None,
         precision: str = "bf16",
+        device: Optional[Any] = None,
     ) -> None:
         super().__init__()
         if cam_emb_placed_at_enc is not None:
@@ -99,7 +100,15 @@ class L4P_VideoMAE(torch.nn.Module):
         self.engine_dtype = _engine_dtype(precision)
         self.engine: Optional[Engine] = None
         self.weights: Optional[PackedWeights] = None
-        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        # Engine option: the GPU this model lives on ("cuda:3", 3, torch.device).  None = the current device AT THE TIME THE
+        # WEIGHTS ARRIVE (load_state_dict / set_weights), so a rank may build the model before torch.cuda.set_device(local_rank).
+        self._device_arg = None if device is None else torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if self._device_arg is not None and self._device_arg.type != "cuda":
+            raise _lib.L4PHipError(f"the L4P engine runs on an AMD GPU only (device={device!r})")
+        if self._device_arg is not None and self._device_arg.index is None:
+            self._device_arg = None  # plain "cuda": the current device, resolved late like None
+        self.device = self._device_arg or (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                                           else torch.device("cpu"))
         for key, head in self.task_heads.items():
             head._engine_task = key
             # the packed weight layout and the decoder geometry are keyed by the ModuleDict key (weights.actpost_of /
@@ -137,7 +146,7 @@ class L4P_VideoMAE(torch.nn.Module):
             raise _lib.L4PHipError("no AMD GPU visible: the L4P engine has no CPU path")
         # the device is resolved when the weights arrive, not at construction: a rank that builds the model before
         # torch.cuda.set_device(local_rank) must still end up on its own GPU
-        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.device = self._device_arg or torch.device("cuda", torch.cuda.current_device())
         self.set_weights(pack_state_dict(sd, self.cfg, torch.bfloat16 if self.engine_dtype == L4P_BF16 else torch.float32,
                                          self.device, tasks=list(self.task_heads.keys())))
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)

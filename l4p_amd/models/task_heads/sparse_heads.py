@@ -319,6 +319,10 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             sl = slice(i * self.max_queries, (i + 1) * self.max_queries)
             outs.append(self.forward_windowed_core(enc_features_bpc_2dlist, track_2d_pointquerries_bn3[:, sl],
                                                    track_2d_pointlabels_bn[:, sl], time_strides, **kwargs))
+        # The concatenation below reads every chunk's buffers on the launching stream: with a deferred join the clip streams
+        # may still be writing them (and the chunk buffers would go back to the allocator while in use).  Join here; the
+        # chunks of one clip already ran back to back on that clip's stream.
+        self.join_streams()
         return {k: torch.cat([o[k] for o in outs], dim=1) for k in outs[0]}
 
     def forward_windowed_core(self, enc_features_bpc_2dlist, track_2d_pointquerries_bn3: torch.Tensor,
@@ -376,8 +380,10 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 _lib.check(lib.l4p_track_prepare(_stream(), _p(cur_q), _p(orig_q), start, ws, _p(q_off), _p(labels),
                                                  _p(valid_t), _p(valid_n), N), "l4p_track_prepare")
                 if self.trace is not None:
-                    self.trace.append({"labels": labels.clone(), "queries": q_off.clone(), "prompt_labels": plabel.clone(),
-                                       "valid_t": valid_t.clone()})
+                    # (recorded on whatever stream the clip runs on: the clones are ordered behind track_prepare there, so
+                    # tracing does not change the schedule — the benchmarked stream configuration can be traced as it runs)
+                    self.trace.append({"clip": b, "window": wi, "labels": labels.clone(), "queries": q_off.clone(),
+                                       "prompt_labels": plabel.clone(), "valid_t": valid_t.clone()})
                 enc_last = enc_features_bpc_2dlist[wi].f32(-1)[b].contiguous()
                 # first window: the history of every track is the learned mask token (filled above) -> shared keys
                 # later windows: the second temporal half of every track's history is the mask token again (written by the
@@ -393,7 +399,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 if self.trace is not None and not last:
                     self.trace[-1]["best_vis_id"] = best.clone()
 
-        use_streams = B > 1 and dev.type == "cuda" and os.environ.get("L4P_TRACK_STREAMS", "1") != "0" and self.trace is None
+        use_streams = B > 1 and dev.type == "cuda" and os.environ.get("L4P_TRACK_STREAMS", "1") != "0"
         if use_streams:
             main = torch.cuda.current_stream()
             pool = getattr(self, "_clip_streams", None)

@@ -56,6 +56,10 @@ def prepare_model(model_config_path: str, ckpt_path: Optional[str], max_queries:
         raise ValueError("the MI355X engine only runs on the GPU (accelerator='gpu')")
     from ..packing import PackedWeights
 
+    if ckpt_path is None:
+        # (the reference's Optional[str] annotation notwithstanding, it has no weights-free mode either: torch.load(None) fails)
+        raise ValueError("prepare_model needs ckpt_path: the reference's Lightning checkpoint or a packed arena "
+                         "(tools/ckpt_to_arena.py); build_model(...) gives a model without weights")
     model = build_model(model_config_path, max_queries, precision, model_cfg=model_cfg)
     if PackedWeights.is_arena_file(ckpt_path):
         net = model.l4p_model

@@ -261,7 +261,7 @@ class PackedWeights:
         try:
             with open(path, "rb") as f:
                 return f.read(len(PackedWeights.MAGIC)) == PackedWeights.MAGIC
-        except OSError:
+        except (OSError, TypeError):
             return False
 
     @staticmethod

@@ -183,6 +183,14 @@ def linear_mean_solve(pred: Tensor, target: Tensor) -> Tensor:
     return torch.mean(b / (a + 1e-8), dim=1)
 
 
+def linear_median_solve(pred: Tensor, target: Tensor, inverse: bool = True) -> Tensor:
+    """LinearAligner(method='median').solve (aligner.py:91-109): torch.median (the LOWER median) of the float ratios."""
+    f = safe_inverse if inverse else (lambda x: x)
+    a = f(pred).reshape(pred.shape[0], -1)
+    b = f(target).reshape(target.shape[0], -1)
+    return torch.median(b / (a + 1e-8), dim=1).values
+
+
 def linear_mean_apply(pred: Tensor, scale: Tensor) -> Tensor:
     """LinearAligner.apply (aligner.py:111-118)."""
     return safe_inverse(scale.reshape((scale.shape[0],) + (1,) * (pred.ndim - 1)) * safe_inverse(pred))
@@ -295,6 +303,103 @@ def optimal_rotation_intrinsics(rays_origin: Tensor, rays_target: Tensor, find_h
     K = np.asarray(out[1])
     K = K / K[2, 2]
     return torch.from_numpy(np.asarray(out[2])).float(), torch.from_numpy(K).float(), Hm
+
+
+# ---- the ENGINE's deterministic K estimator (csrc/intrinsics.hip rays_to_intrinsics_kernel), restated --------------------------
+# It stands where cv2's RANSAC draw stands in the reference, so it has no reference result to be compared with; restating
+# its schedule here makes a GPU estimate reproducible on the CPU at any geometry (tests/test_full_model_gpu.py compares the
+# full-size model's estimate with it), exactly as joint_oracle.engine_ransac does for the seam similarity.
+def _engine_dlt(x: np.ndarray, y: np.ndarray, u: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """Hartley-normalised DLT of (x, y) -> (u, v) in float64: null vector of the 9x9 normal matrix, denormalised."""
+    n = x.shape[0]
+    mx, my, mu, mv = x.mean(), y.mean(), u.mean(), v.mean()
+    ds = np.sqrt((x - mx) ** 2 + (y - my) ** 2).sum()
+    dd = np.sqrt((u - mu) ** 2 + (v - mv) ** 2).sum()
+    ss = np.sqrt(2.0) * n / ds if ds > 0 else 1.0
+    sd = np.sqrt(2.0) * n / dd if dd > 0 else 1.0
+    xn, yn, un, vn = (x - mx) * ss, (y - my) * ss, (u - mu) * sd, (v - mv) * sd
+    z, o = np.zeros(n), np.ones(n)
+    r1 = np.stack([-xn, -yn, -o, z, z, z, un * xn, un * yn, un], axis=1)
+    r2 = np.stack([z, z, z, -xn, -yn, -o, vn * xn, vn * yn, vn], axis=1)
+    M = r1.T @ r1 + r2.T @ r2
+    _, V = np.linalg.eigh(M)
+    Hn = V[:, 0].reshape(3, 3)
+    Ts = np.array([[ss, 0, -ss * mx], [0, ss, -ss * my], [0, 0, 1.0]])
+    Tdi = np.array([[1 / sd, 0, mu], [0, 1 / sd, mv], [0, 0, 1.0]])
+    return Tdi @ Hn @ Ts
+
+
+def _engine_reproj(Hm: np.ndarray, x, y, u, v, dt) -> np.ndarray:
+    Hm = Hm.astype(dt)
+    x, y, u, v = x.astype(dt), y.astype(dt), u.astype(dt), v.astype(dt)
+    with np.errstate(all="ignore"):
+        pw = Hm[2, 0] * x + Hm[2, 1] * y + Hm[2, 2]
+        pu = (Hm[0, 0] * x + Hm[0, 1] * y + Hm[0, 2]) / pw
+        pv = (Hm[1, 0] * x + Hm[1, 1] * y + Hm[1, 2]) / pw
+        return np.sqrt((pu - u) ** 2 + (pv - v) ** 2)
+
+
+def engine_rays_to_intrinsics(dirs_n3: np.ndarray, h: int, w: int, H: int, W: int, thr: float = 0.2, b: int = 0,
+                              z_thr: float = 1e-4):
+    """rays_to_intrinsics_kernel for batch item ``b``: dirs_n3 = predicted ray directions of the first frame on the h x w ray
+    grid (row-major).  128 hashed minimal 4-point homographies (grid pixel -> direction xy / z) scored by consensus in float,
+    the best one's consensus set re-estimated by DLT until the set is stable (<= 8 rounds, kept when a new set would have < 8
+    members), H^-1 = K R by RQ with a positive diagonal, K rescaled from the ray grid to the H x W image.
+    Returns (K 4x4 float64 in output pixels, consensus size, rounds)."""
+    d = np.asarray(dirs_n3, np.float32).astype(np.float64)
+    nr = h * w
+    r = np.arange(nr)
+    x, y = (r % w).astype(np.float64), (r // w).astype(np.float64)
+    valid = np.abs(d[:, 2]) > z_thr
+    u = np.where(valid, d[:, 0] / np.where(valid, d[:, 2], 1.0), 0.0)
+    v = np.where(valid, d[:, 1] / np.where(valid, d[:, 2], 1.0), 0.0)
+    f32 = np.float32
+    xf, yf, uf, vf = x.astype(f32).astype(np.float64), y.astype(f32).astype(np.float64), u.astype(f32).astype(np.float64), v.astype(f32).astype(np.float64)
+    counts, Hts = np.zeros(128, np.int64), []
+    for t in range(128):
+        idx, ok = [], True
+        for k in range(4):
+            hsh = ((b * 131 + t) * 2654435761 + 40503 * k) & 0xFFFFFFFF
+            hsh ^= hsh >> 15
+            hsh = (hsh * 2246822519) & 0xFFFFFFFF
+            hsh ^= hsh >> 13
+            i = hsh % nr
+            ok = ok and bool(valid[i]) and i not in idx
+            idx.append(i)
+        if not ok:
+            Hts.append(np.zeros((3, 3)))
+            continue
+        idx = np.array(idx)
+        Ht = _engine_dlt(xf[idx], yf[idx], uf[idx], vf[idx])
+        Hts.append(Ht)
+        e = _engine_reproj(Ht, x, y, u, v, f32)
+        counts[t] = int((valid & (e < f32(thr))).sum())
+    bt = int(np.argmax(counts))  # first maximum, as the kernel's strict > scan
+    wgt = valid & (_engine_reproj(Hts[bt], x, y, u, v, f32) < f32(thr))
+    if counts[bt] < 8:
+        wgt = valid.copy()
+    Hs, iters = None, 0
+    for _ in range(8):
+        if int(wgt.sum()) < 4:
+            break
+        Hs = _engine_dlt(x[wgt], y[wgt], u[wgt], v[wgt])
+        nw = valid & (_engine_reproj(Hs, x, y, u, v, np.float64) < thr)
+        iters += 1
+        if np.array_equal(nw, wgt) or int(nw.sum()) < 8:
+            break
+        wgt = nw
+    A = Hs if np.linalg.det(Hs) >= 0 else -Hs
+    _, K, _ = rq3(np.linalg.inv(A))
+    K = K / K[2, 2]
+    K4 = np.eye(4)
+    K4[:3, :3] = K
+    K4[0, 2] += 0.5
+    K4[1, 2] += 0.5
+    K4[0, :] = K4[0, :] / w * W
+    K4[1, :] = K4[1, :] / h * H
+    K4[0, 2] -= 0.5
+    K4[1, 2] -= 0.5
+    return K4, int(wgt.sum()), iters
 
 
 def rays_to_cameras_fixed_intrinsics(rays_b6thw: Tensor, output_size: Tuple[int, int], find_h=dlt_homography, rq=rq3,

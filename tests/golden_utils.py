@@ -24,6 +24,14 @@ def make_batch(T: int, nq: int, seed: int = 1234):
     }
 
 
+def grid_queries(nq: int) -> torch.Tensor:
+    """The benchmark's track queries (bench.py): an 8x8 grid x, y in {14 + 28 i} + 0.5 at t = 0.5 -> [1,nq,3]."""
+    q = torch.zeros(1, nq, 3)
+    for i in range(nq):
+        q[0, i] = torch.tensor([0.5, 14.0 + 28.0 * (i % 8) + 0.5, 14.0 + 28.0 * ((i // 8) % 8) + 0.5])
+    return q
+
+
 def sample_indices(numel: int, n: int = 4096) -> torch.Tensor:
     if numel <= n:
         return torch.arange(numel)

@@ -1,5 +1,6 @@
 """bench.py's output contract on the GPU box: stdout is exactly ONE JSON line carrying the driver's keys, `roofline` and (at N=1)
-`cpu_baseline`; checked on a 1-step run of the default workload (c3) and of the clip-preparation workload."""
+`cpu_baseline`; checked on a 1-step run of the default workload (c3), of configs[4] at its full length (c5: one 256-frame
+video, 31 windows) and of the clip-preparation workload."""
 import json
 import os
 import subprocess
@@ -47,3 +48,16 @@ def test_prep_workload_line(dev):
     r = _run(["--workload", "prep", "--steps", "3", "--warmup", "1"])
     _check_common(r, 3, 1)
     assert r["roofline"]["bound"] == "hbm" and r["roofline"]["peak"] == 8000.0 and r["cpu_baseline"]["kind"] == "port"
+
+
+def test_c5_workload_line_at_full_length(dev):
+    """configs[4] on one GPU at its own length: 256 frames = 31 windows, all heads, on-GPU alignment.  Property checks at full
+    size: the line carries the replicated phase-3 time (stitch + alignment + tracker recursion: the Amdahl term of the only
+    strong-scaling configuration) and the ceiling it implies for 8 GPUs."""
+    r = _run(["--workload", "c5", "--steps", "1", "--warmup", "1"])
+    _check_common(r, 1, 1)
+    assert r["scaling"] == "strong" and "31 overlapping" in r["config"]["workload"]
+    assert abs(r["value"] - 256 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-2
+    assert 0 < r["phase3_ms"] < r["ms_per_step"] and 0 < r["phase1_ms"] < r["ms_per_step"]
+    s = r["phase3_ms"] / (r["phase1_ms"] + r["phase3_ms"])
+    assert abs(r["implied_8gpu_speedup_ceiling"] - 1.0 / (s + (1.0 - s) / 8.0)) < 0.05

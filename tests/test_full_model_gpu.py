@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 from l4p_amd.models.utils import build_model
 from l4p_amd.weights import ModelCfg, seeded_state_dict
-from tests.golden_utils import make_batch, sample_indices
+from tests.golden_utils import grid_queries, make_batch, sample_indices
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALL = ["flow_2d_backward", "track_2d", "depth", "dyn_mask", "camray"]
@@ -113,10 +113,9 @@ def test_batch4_bf16_equals_four_batch1_forwards_and_goldens(dev, full_sd):
             for k in OUT_KEYS:
                 report[(i, k)] = _rel_l2(out4[k][i], o1[k].float().cpu()[0])
             # integer / boolean tracker state of clip i: identical between the two batch sizes
-            t4 = trace4[i] if len(trace4) == 4 else None
-            if t4 is not None:
-                for name in ("labels", "prompt_labels", "valid_t"):
-                    assert torch.equal(t4[name].cpu(), head.trace[0][name].cpu()), (i, name)
+            assert len(trace4) == 4 and trace4[i]["clip"] == i and len(head.trace) == 1, (len(trace4), len(head.trace))
+            for name in ("labels", "prompt_labels", "valid_t"):
+                assert torch.equal(trace4[i][name].cpu(), head.trace[0][name].cpu()), (i, name)
     print("B=4 vs B=1 rel-L2:", {f"{i}:{k}": f"{v:.2e}" for (i, k), v in report.items()})
     # same arithmetic, different tile shapes / summation order: differences at bf16 rounding level, well inside the
     # bf16-vs-f32 drift gates
@@ -164,3 +163,188 @@ def test_full_size_two_windows_vs_reference_goldens(dev, full_sd, precision):
             assert emax <= 1e-3, (k, emax)
         else:
             assert el2 <= 3e-2, (k, el2)
+
+
+def _samples(y, g):
+    y = y.float().cpu().reshape(-1)
+    g = torch.from_numpy(np.asarray(g)).reshape(-1)
+    s = y[sample_indices(y.numel())] if y.numel() > 4096 else y
+    assert s.shape == g.shape, (tuple(s.shape), tuple(g.shape))
+    return s, g
+
+
+def test_benchmarked_configuration_itself(dev, full_sd):
+    """configs[2] EXACTLY as bench.py runs it: batch 4, 64 grid queries per clip (golden_utils.grid_queries), the SHIPPED camray
+    configuration (configs/model.yaml:44-45 use_intrinsics=false: K estimated from the first window's ray map), one tracker
+    stream per clip with the join deferred behind the dense decoders, the integer state traced WITHOUT touching the stream
+    schedule.  Checked:
+      * every clip against its own batch-1 forward (different kernels), integer / boolean tracker state identical;
+      * clip 0 (the golden clip) against the REFERENCE: dense outputs vs full_T16_all.npz, its 64 tracks vs full_T16_q64.npz
+        (tools/gen_golden_full_joint.py: the reference's tracker on the benchmark's query set);
+      * the K estimate of every clip against the oracle's restatement of the engine's estimator on the same ray map, and the
+        poses against the reference flow downstream of that estimate (oracle rays_to_cameras_fixed_intrinsics, k_override)."""
+    from oracle import l4p_oracle as lo
+
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "full_T16_all.npz"))
+    gq = np.load(os.path.join(ROOT, "tests", "golden", "full_T16_q64.npz"))
+    m = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision="bf16")
+    net = m.l4p_model
+    assert net.task_heads["camray"].use_intrinsics is False and net.task_heads["camray"].fixed_intrinsics is True  # as shipped
+    m.load_state_dict({"l4p_model." + k: v for k, v in full_sd.items()})
+    head = net.task_heads["track_2d"]
+    singles = []
+    for i in range(4):
+        b = make_batch(16, 1, seed=1234 + i)
+        b["track_2d_pointquerries_bn3"] = grid_queries(64)
+        b["track_2d_pointlabels_bn"] = torch.ones(1, 64)
+        singles.append(b)
+    b4 = {k: torch.cat([b[k] for b in singles], dim=0) for k in singles[0]}
+    keys = OUT_KEYS + ["traj3d_intrinsics_est_b16t"]
+    os.environ.pop("L4P_TRACK_STREAMS", None)
+    with torch.no_grad():
+        head.trace = []
+        out4 = m.forward({k: v.clone() for k, v in b4.items()}, ALL)
+        torch.cuda.synchronize()
+        trace4 = head.trace
+        assert [(t["clip"], t["window"]) for t in trace4] == [(i, 0) for i in range(4)]
+        assert len(getattr(head, "_clip_streams", [])) >= 4, "the clips' trackers did not run on their own streams"
+        out4 = {k: out4[k].float().cpu() for k in keys}
+        # the ray maps the forward decoded (deterministic: the same launches again)
+        data = {k: v.to(net.device) for k, v in b4.items()}
+        rays4 = net.task_heads["camray"]._decode(net.encode_features(data, ALL), (16, 224, 224)).float().cpu()
+        report = {}
+        for i, b in enumerate(singles):
+            head.trace = []
+            o1 = m.forward({k: v.clone() for k, v in b.items()}, ALL)
+            torch.cuda.synchronize()
+            for k in keys:
+                report[(i, k)] = _rel_l2(out4[k][i], o1[k].float().cpu()[0])
+            for name in ("labels", "prompt_labels", "valid_t"):
+                assert torch.equal(trace4[i][name].cpu(), head.trace[0][name].cpu()), (i, name)
+            assert torch.equal(trace4[i]["queries"][:, 0].cpu(), head.trace[0]["queries"][:, 0].cpu()), i
+        head.trace = None
+    print("bench config, B=4 vs B=1 rel-L2:", {f"{i}:{k}": f"{v:.2e}" for (i, k), v in report.items()})
+    # The K estimate is a consensus (best-of-128 + refit) estimate on a ray map that, with random weights, is not the image
+    # of any camera: the batch-4 and batch-1 ray maps differ by bf16 rounding and the estimate legitimately lands elsewhere
+    # (measured: rel-L2 ~1 between the two K).  Poses / K are therefore NOT tied to the batch-1 path; they are tied, for every
+    # clip, to the CPU restatement of the estimator on the very ray map the batch-4 forward decoded (below).
+    bad = {k: v for k, v in report.items() if not k[1].startswith("traj3d") and v > BF16_GATE_HEADS / 2}
+    assert not bad, bad
+    # ---- clip 0 against the reference ----
+    rep0 = {}
+    for k in ("depth_est_b1thw", "flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw"):
+        rep0[k] = _rel_l2(*_samples(out4[k][0], gold[k]))
+    for k in ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"):
+        assert tuple(out4[k][0].shape) == tuple(gq[k][0].shape), k
+        rep0[k] = _rel_l2(out4[k][0], torch.from_numpy(gq[k][0]))
+    print("bench config, clip 0 vs the reference:", {k: f"{v:.2e}" for k, v in rep0.items()})
+    bad = {k: v for k, v in rep0.items() if v > BF16_GATE_HEADS}
+    assert not bad, bad
+    # ---- K estimate and what follows from it, every clip ----
+    for i in range(4):
+        dirs = rays4[i, :3, 0].reshape(3, -1).T.numpy()
+        want, n_cons, iters = lo.engine_rays_to_intrinsics(dirs, 16, 16, 224, 224, thr=0.2, b=i)
+        K_pix = out4["traj3d_intrinsics_est_b16t"][i].reshape(4, 4, 16)
+        assert torch.equal(K_pix[..., 0], K_pix[..., 15])
+        got = K_pix[..., 0].double().numpy()
+        print(f"clip {i}: consensus {n_cons}/256 after {iters} rounds, fx {got[0, 0]:.2f} fy {got[1, 1]:.2f}")
+        assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max(), (i, got, want)
+        K_ray = lo.denormalize_intrinsics(lo.normalize_intrinsics(K_pix[None], 224, 224), 16, 16)[0, :3, :3, 0]
+        E, Kout = lo.rays_to_cameras_fixed_intrinsics(rays4[i:i + 1], (224, 224), k_override=lambda b: K_ray)
+        pose = torch.linalg.inv(E.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).reshape(16, 16)
+        y = out4["traj3d_est_b16t"][i]
+        assert (y - pose).abs().max() <= 1e-3 * pose.abs().max(), (i, float((y - pose).abs().max() / pose.abs().max()))
+        assert (Kout[0].reshape(16, 16) - out4["traj3d_intrinsics_est_b16t"][i]).abs().max() <= 1e-3 * Kout.abs().max()
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_depth_only_full_size_vs_reference_golden(dev, precision):
+    """configs[1] as bench.py --workload c2 builds it: a model with the depth head only, task list ["depth"], batch 1.  The
+    encoder stops after block 36 (the highest hook; the reference runs all 40 and discards them) and the batch-1 dispatch
+    (split-K MLP-out projection, KV-split attention) runs; the output must equal the reference's depth_est_b1thw."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "full_T16_all.npz"))
+    cfg = ModelCfg.full()
+    m = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision=precision)
+    net = m.l4p_model
+    net.task_heads = torch.nn.ModuleDict({"depth": net.task_heads["depth"]})
+    m.load_state_dict({"l4p_model." + k: v for k, v in seeded_state_dict(cfg, tasks=["depth"]).items()})
+    batch = make_batch(16, 8)
+    with torch.no_grad():
+        out = m.forward({k: v.clone() for k, v in batch.items()}, ["depth"])
+    torch.cuda.synchronize()
+    feats = out["enc_features_bpc_2dlist"][0]
+    with pytest.raises(KeyError):
+        feats.f32(cfg.depth)  # blocks 37..40 never ran
+    s, g = _samples(out["depth_est_b1thw"], gold["depth_est_b1thw"])
+    emax, el2 = float((s - g).abs().max() / g.abs().max()), float((s - g).norm() / g.norm())
+    print(precision, "depth-only vs reference:", f"max {emax:.2e} rel-L2 {el2:.2e}")
+    if precision == "32-true":
+        assert emax <= 1e-3, emax
+    else:
+        assert el2 <= BF16_GATE_HEADS, el2
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_full_size_four_windows_joint_vs_reference_goldens(dev, full_sd, precision):
+    """The path of dense_heads.py:360-492 at the REAL geometry over more than one seam: 40 frames = 4 windows = 3 seams, all
+    five tasks, 8 tracks (tools/gen_golden_full_joint.py -> tests/golden/full_T40_joint.npz).
+      * flow, motion mask, tracks: against the reference's outputs directly;
+      * depth / poses / K of frames 0..7 (first window, never re-aligned): against the reference directly;
+      * the jointly aligned depth / poses over all 40 frames: the reference's two random draws cannot be pinned, so the fixture
+        carries, next to the reference run with fixed stand-ins (which pins the oracle's flow over 3 seams at this geometry),
+        the oracle's flow with the ENGINE's deterministic draws ("engine.*") — the f32 engine must reproduce it to 1e-3;
+        the bf16 engine's joint stage is checked on its own per-window estimates (as tests/test_joint_gpu.py does at the mini
+        geometry: a best-of-100 estimator legitimately lands elsewhere for inputs that differ by the bf16 drift)."""
+    from oracle import joint_oracle as jo
+
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "full_T40_joint.npz"))
+    m = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision=precision)
+    m.l4p_model.task_heads["camray"].use_intrinsics = True
+    m.load_state_dict({"l4p_model." + k: v for k, v in full_sd.items()})
+    batch = make_batch(40, 8)
+    with torch.no_grad():
+        out = m.forward({k: v.clone() for k, v in batch.items()}, ALL)
+    torch.cuda.synchronize()
+    exact = precision == "32-true"
+    report = {}
+    for k in ("flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw", "track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t",
+              "track_2d_depth_est_bn1t"):
+        s, g = _samples(out[k], gold[k])
+        report[k] = (float((s - g).abs().max() / g.abs().max()), float((s - g).norm() / g.norm()))
+    joint_keys = ("depth_est_b1thw", "traj3d_est_b16t", "traj3d_intrinsics_est_b16t")
+    for k in joint_keys:
+        s, g = _samples(out[k], gold["engine." + k])
+        report["engine." + k] = (float((s - g).abs().max() / g.abs().max()), float((s - g).norm() / g.norm()))
+    print(precision, {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in report.items()})
+    for k, (emax, el2) in report.items():
+        if exact:
+            assert emax <= 1e-3, (k, emax)
+        elif not k.startswith("engine."):
+            assert el2 <= BF16_GATE_HEADS, (k, el2)
+    # frames 0..7 are written by window 0 only: independent of the draws -> the reference's own values (full tensors are not
+    # in the fixture; the sampled positions that fall into the first 8 frames are compared)
+    for k in joint_keys:
+        y = out[k].float().cpu()
+        idx = sample_indices(y.numel()) if y.numel() > 4096 else torch.arange(y.numel())
+        t_of = (idx // (224 * 224)) % 40 if k == "depth_est_b1thw" else idx % 40
+        sel = t_of < 8
+        s, g = y.reshape(-1)[idx][sel], torch.from_numpy(gold[k]).reshape(-1)[sel]
+        assert int(sel.sum()) > 10
+        e = float((s - g).abs().max() / g.abs().max()) if exact else float((s - g).norm() / g.norm())
+        assert e <= (1e-3 if exact else BF16_GATE_HEADS), ("first window", k, e)
+    if exact:
+        return
+    per_win = []
+    with torch.no_grad():
+        for st in (0, 8, 16, 24):
+            b = {k: (v[:, :, st:st + 16].clone() if k == "rgb_b3thw" else v[..., st:st + 16].clone() if k == "intrinsics_b44t" else v.clone())
+                 for k, v in batch.items()}
+            o = m.forward(b, ["depth", "camray"])
+            per_win.append({"depth": o["depth_est_b1thw"].float().cpu(), "camray": o["traj3d_est_b16t"].float().cpu(),
+                            "camray_intrinsics_est": o["traj3d_intrinsics_est_b16t"].float().cpu()})
+    torch.cuda.synchronize()
+    log = []
+    est = jo.joint_windowed(lambda w: {k: v.clone() for k, v in per_win[w].items()}, [0, 8, 16, 24], 16, "engine", log)
+    for key, ek in (("depth_est_b1thw", "depth"), ("traj3d_est_b16t", "camray"), ("traj3d_intrinsics_est_b16t", "camray_intrinsics_est")):
+        y, r = out[key].float().cpu(), est[ek]
+        assert (y - r).abs().max() <= 1e-3 * r.abs().max(), (key, float((y - r).abs().max() / r.abs().max()), log)

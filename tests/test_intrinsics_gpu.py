@@ -71,3 +71,32 @@ def test_intrinsics_and_pose_recovered(dev):
     K_est = intrinsics_from_rays(rays.cuda(), H, W)
     pose = poses_from_rays(rays.cuda(), K_est, H, W).cpu().view(1, 4, 4, T)
     assert (pose[0] - c2w).abs().max() <= 2e-3
+
+
+def test_kernel_equals_the_oracle_restatement_of_its_schedule(dev):
+    """rays_to_intrinsics_kernel == oracle.l4p_oracle.engine_rays_to_intrinsics (the CPU restatement of the ENGINE's
+    estimator: hashed minimal samples, float consensus scoring, iterated consensus DLT, RQ) on ray maps that are NOT a
+    clean camera — 10 % gross outliers and per-ray noise, two batch items (the hash depends on the item), both
+    thresholds — so that a GPU estimate on a real model's ray map is reproducible on the CPU (test_full_model_gpu.py)."""
+    import numpy as np
+
+    from oracle.l4p_oracle import engine_rays_to_intrinsics
+
+    H = W = 224
+    T = 4
+    K = torch.eye(4)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = 250.0, 263.0, 109.0, 121.0
+    c2w = torch.eye(4)[:, :, None].repeat(1, 1, T).clone()
+    g = torch.Generator().manual_seed(4)
+    rays = torch.cat([render_rays(K, c2w, H, W), render_rays(K * torch.tensor([1.2, 0.9, 1.0, 1.0]).view(4, 1), c2w, H, W)], dim=0)
+    bad = torch.rand(2, 1, T, 16, 16, generator=g) < 0.1
+    rays = torch.where(bad.expand_as(rays), rays + 2.0 * torch.randn(rays.shape, generator=g), rays)
+    rays = rays + 0.01 * torch.randn(rays.shape, generator=g)
+    for thr in (0.2, 0.02):
+        got = intrinsics_from_rays(rays.cuda(), H, W, reproj_threshold=thr).cpu()
+        for b in range(2):
+            dirs = rays[b, :3, 0].reshape(3, -1).T.numpy()
+            want, n, iters = engine_rays_to_intrinsics(dirs, 16, 16, H, W, thr=thr, b=b)
+            assert n >= 100 and iters >= 1, (n, iters)
+            k = got[b, :, :, 0].double().numpy()
+            assert np.abs(k - want).max() <= 1e-4 * np.abs(want).max(), (thr, b, k, want)

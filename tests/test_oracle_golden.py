@@ -178,3 +178,22 @@ def test_oracle_single_window_entry_matches_reference_golden(mini):
     assert sorted(out.keys()) == sorted(gold.files)
     for k in gold.files:
         _cmp(k, out[k], gold[k])
+
+
+def test_full_size_joint_and_q64_goldens_are_pinned():
+    """tests/golden/full_T40_joint.npz (4 windows / 3 seams, all tasks) and full_T16_q64.npz (the benchmark's 64 queries) come
+    from the imported reference at the full geometry (tools/gen_golden_full_joint.py); the oracle's agreement over the FULL
+    tensors was asserted when they were generated and is recorded — re-running 4 full-size windows on the CPU takes minutes."""
+    import json
+
+    rep = json.load(open(os.path.join(GOLD, "oracle_vs_reference_full_joint.json")))
+    errs = {k: v for k, v in rep.items() if k.endswith("_oracle_rel_err")}
+    assert len(errs) == 11 and max(errs.values()) <= 1e-4, errs
+    g = np.load(os.path.join(GOLD, "full_T40_joint.npz"))
+    for k in ("depth_est_b1thw", "traj3d_est_b16t", "engine.depth_est_b1thw", "engine.traj3d_est_b16t", "seam2_T", "engine.seam2_T"):
+        assert k in g.files, k
+    # (name-seeded random weights: neighbouring windows' depth / pose estimates are mutually inconsistent, so at the reference's
+    #  threshold of 1 % of the q98 depth only a handful of the 15051 sampled points agree — the seams are still well defined)
+    assert all(rep[f"T40_engine_seam{i}"]["inliers"] >= 1 and rep[f"T40_engine_seam{i}"]["n"] == 15051 for i in range(3)), rep
+    q = np.load(os.path.join(GOLD, "full_T16_q64.npz"))
+    assert q["track_2d_traj_est_bn2t"].shape == (1, 64, 2, 16)

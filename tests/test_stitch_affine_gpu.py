@@ -124,10 +124,59 @@ def test_linear_aligner_mean_ratio(dev):
         y = al.apply(pred.cuda()).cpu()
         ref = fn(ratios.float().view(2, 1, 1, 1, 1) * fn(pred))
         assert (y - ref).abs().max() <= 1e-5 * ref.abs().max()
-    with pytest.raises(NotImplementedError):
-        LinearAligner(method="median")
     with pytest.raises(ValueError):
         LinearAligner(method="mode")
+
+
+@pytest.mark.parametrize("n", [8 * 224 * 224, 8 * 32 * 32, 7, 2, 1])
+def test_linear_aligner_median_equals_torch_median(dev, n):
+    """LinearAligner(method="median") (aligner.py:106-107): torch.median = the LOWER median of the float ratios, selected
+    exactly (even and odd counts, duplicates at the selected rank, ratios of either sign in the identity mode, invalid depths
+    in the inverse mode), against the oracle's restatement (== the imported reference, tools/gen_golden_joint.py)."""
+    from oracle.l4p_oracle import linear_median_solve
+
+    g = torch.Generator().manual_seed(n)
+    pred = torch.rand(2, n, generator=g) + 0.5
+    target = pred * torch.tensor([1.7, 0.4]).view(2, 1) * (1 + 0.05 * torch.randn(pred.shape, generator=g))
+    if n > 100:
+        target[0, : n // 3] = pred[0, : n // 3] * 1.7   # a third of the ratios nearly coincide around the median
+        pred[1, 5:9] = 0.0                                # invalid depths: safe_inverse -> 0 -> ratio 0 / 1e-8
+        target[0, 11:14] = -1.0
+    for pre_post, tgt in (("inverse", target), ("identity", target - 1.2)):
+        al = LinearAligner(pre_post_fn=pre_post, method="median")
+        al.solve(pred.cuda(), tgt.cuda())
+        want = linear_median_solve(pred, tgt, inverse=pre_post == "inverse")
+        assert torch.equal(al.sol[:, 0].cpu(), want), (pre_post, al.sol[:, 0].cpu(), want)
+        assert float(al.sol[:, 1].abs().max()) == 0.0
+        y = al.apply(pred.cuda()).cpu()
+        fn = _safe_inverse if pre_post == "inverse" else (lambda x: x)
+        ref = fn(want.view(2, 1) * fn(pred))
+        assert (y - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def test_quantile_and_rank_select_on_signed_values(dev):
+    """l4p_quantile / l4p_select_rank accept finite floats of either sign (order-preserving key), incl. -0.0 next to +0.0."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(2052, dtype=torch.int32, device="cuda")
+    out = torch.empty(1, dtype=torch.float32, device="cuda")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(10007, generator=g)
+    x[:50] = 0.0
+    x[50:80] = -0.0
+    xd = x.cuda()
+    for q in (0.0, 0.02, 0.5, 0.77, 1.0):
+        _lib.check(lib.l4p_quantile(st, xd.data_ptr(), x.numel(), q, ws.data_ptr(), out.data_ptr()), "l4p_quantile")
+        want = float(torch.quantile(x, q))
+        assert abs(float(out.cpu()) - want) <= 1e-6 * max(abs(want), 1e-3), (q, float(out.cpu()), want)
+    srt = torch.sort(x).values
+    for r in (0, 1, 4999, 5003, 10006):
+        _lib.check(lib.l4p_select_rank(st, xd.data_ptr(), x.numel(), r, ws.data_ptr(), out.data_ptr()), "l4p_select_rank")
+        assert float(out.cpu()) == float(srt[r]), (r, float(out.cpu()), float(srt[r]))
 
 
 def test_depth_stitch_with_linear_aligner(dev):

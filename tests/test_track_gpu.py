@@ -274,3 +274,85 @@ def test_edge_cases_no_queries_and_one_query(dev, mini):
     for k in ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"):
         a, r = o1[k][:, 0].float().cpu(), o5[k][:, 0].float().cpu()
         assert (a - r).abs().max() <= 1e-4 * r.abs().max() + 1e-6, k
+
+
+def test_chunked_queries_on_clip_streams_beside_dense_heads_equal_serial(dev, mini, monkeypatch):
+    """B > 1, dense heads in the task list (deferred stream join) AND N >= max_queries (chunk loop): every chunk's buffers are
+    written on the clip streams and concatenated on the launching stream, so forward_windowed must join before it
+    concatenates (round-2 advisor finding: the concatenation read buffers the clip streams had not written yet, and freed
+    them into the allocator under the running streams).  Equal to the serial order bit for bit, repeatedly."""
+    cfg, sd = mini
+    model = build(cfg, sd, "bf16")
+    head = model.l4p_model.task_heads["track_2d"]
+    head.max_queries = 4
+    b1 = make_batch(32, 10)  # 3 windows, 10 queries = chunks 4 + 4 + 2
+    batch = {k: (torch.cat([v, v.flip(-1) if k == "rgb_b3thw" else v], dim=0) if torch.is_tensor(v) else v) for k, v in b1.items()}
+    tasks = ["track_2d", "depth", "dyn_mask"]
+    keys = ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t", "depth_est_b1thw", "dyn_mask_est_b1thw"]
+    with torch.no_grad():
+        monkeypatch.setenv("L4P_TRACK_STREAMS", "1")
+        runs = [model.forward({k: v.clone() for k, v in batch.items()}, tasks) for _ in range(3)]
+        monkeypatch.setenv("L4P_TRACK_STREAMS", "0")
+        serial = model.forward({k: v.clone() for k, v in batch.items()}, tasks)
+    torch.cuda.synchronize()
+    assert tuple(serial["track_2d_traj_est_bn2t"].shape) == (2, 10, 2, 32)
+    for k in keys:
+        for r in runs:
+            assert torch.equal(r[k], serial[k]), k
+
+
+def test_trace_is_recorded_with_the_clip_streams_on(dev, mini, monkeypatch):
+    """Recording the integer / boolean window state does not change the stream schedule: with two clips on their own
+    streams the trace holds every (clip, window) pair in host order and equals the serial run's."""
+    cfg, sd = mini
+    model = build(cfg, sd, "bf16")
+    head = model.l4p_model.task_heads["track_2d"]
+    b1 = make_batch(32, 7)
+    batch = {k: (torch.cat([v, v.flip(-1) if k == "rgb_b3thw" else v], dim=0) if torch.is_tensor(v) else v) for k, v in b1.items()}
+    traces = []
+    for streams in ("1", "0"):
+        monkeypatch.setenv("L4P_TRACK_STREAMS", streams)
+        head.trace = []
+        with torch.no_grad():
+            model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d", "depth"])
+        torch.cuda.synchronize()
+        traces.append(head.trace)
+    head.trace = None
+    assert [(t["clip"], t["window"]) for t in traces[0]] == [(b, w) for b in range(2) for w in range(3)]
+    for a, b in zip(*traces):
+        for name in ("labels", "prompt_labels", "valid_t", "queries"):
+            assert torch.equal(a[name].cpu(), b[name].cpu()), (a["clip"], a["window"], name)
+
+
+def test_more_queries_than_max_queries_vs_oracle(dev, mini):
+    """Row f4 (demo.py:38-40,57): N > max_queries over 3 windows against the ORACLE (not against the engine's own one-pass
+    result): 300 queries at mixed start frames in chunks of 128 (128 + 128 + 44), f32 engine, 1e-3; integer / boolean window
+    state bit-exact per chunk.  The oracle chunks the same way (OracleModel.track, sparse_heads.py:162-211)."""
+    from oracle.l4p_oracle import OracleModel
+
+    cfg, sd = mini
+    model = build(cfg, sd, "32-true")
+    head = model.l4p_model.task_heads["track_2d"]
+    head.max_queries = 128
+    nq = 300
+    batch = make_batch(32, nq)
+    g = torch.Generator().manual_seed(5)
+    batch["track_2d_pointquerries_bn3"][0, :, 1:] = torch.rand(nq, 2, generator=g) * 200 + 12  # off-grid positions
+    head.trace = []
+    otrace = []
+    with torch.no_grad():
+        out = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+        om = OracleModel(sd, cfg, max_queries=128)
+        ref = om.forward(batch, ["track_2d"], trace=otrace)
+    torch.cuda.synchronize()
+    for k in ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"):
+        y, r = out[k].float().cpu(), ref[k]
+        assert tuple(y.shape) == tuple(r.shape) and y.shape[1] == nq, k
+        assert (y - r).abs().max() <= 1e-3 * r.abs().max(), (k, float((y - r).abs().max() / r.abs().max()))
+    assert len(head.trace) == len(otrace) == 9  # 3 chunks x 3 windows, chunk-major on both sides
+    for tr, ot in zip(head.trace, otrace):
+        assert torch.equal(tr["labels"].cpu(), ot["labels"])
+        assert torch.equal(tr["prompt_labels"].cpu(), ot["prompt_labels"])
+        assert torch.equal(tr["valid_t"].cpu().bool(), ot["valid_t"])
+        assert torch.equal(tr["queries"][:, 0].cpu(), ot["queries"][:, 0])
+    head.trace = None

@@ -94,6 +94,12 @@ def main():
     e = rel_err(lo.linear_mean_apply(pr, lo.linear_mean_solve(pr, tg)), la.apply(pr))
     report["linear_aligner_apply_rel_err"] = e
     assert e <= 1e-6, e
+    for pp in ("inverse", "identity"):
+        lm = ref_al.LinearAligner(pre_post_fn=pp, method="median")
+        lm.solve(pr, tg - (0.0 if pp == "inverse" else 2.0), None, None)  # identity: ratios of either sign
+        got = lo.linear_median_solve(pr, tg - (0.0 if pp == "inverse" else 2.0), inverse=pp == "inverse")
+        assert torch.equal(got, lm.sol), (pp, got, lm.sol)
+        report[f"linear_aligner_median_{pp}_abs_diff"] = float((got - lm.sol).abs().max())
     aa = ref_al.LstSqAffineAligner(pre_post_fn="inverse")
     aa.solve(pr, tg, None, None)
     e = rel_err(lo.lstsq_affine_apply(pr, lo.lstsq_affine_solve(pr, tg)), aa.apply(pr))
