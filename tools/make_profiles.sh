@@ -3,7 +3,8 @@
 #   tools/make_profiles.sh r02
 # Writes gpurun_out/<tag>_*: bench lines (c3, c2, c5, demo, prep), rocprofv3 --kernel-trace --stats summaries of the c3 / c2
 # commands, the per-shape event profile, and HBM bytes per launch from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE;
-# --kernel-trace only, as gpurun requires).  Copy what should be judged into profiles/.
+# --kernel-trace only, as gpurun requires), matrix-pipe utilisation + effective clock per hot kernel (SQ_VALU_MFMA_BUSY_CYCLES /
+# GRBM_GUI_ACTIVE passes, tools/pmc_mfma_util.py) with the rocm-smi power trace.  Copy what should be judged into profiles/.
 TAG=${1:-r02}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out
@@ -25,7 +26,11 @@ L4P_TRACK_STREAMS=0 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_c3 -o out
 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_c2 -o out -- $CMD2 > $O/prof_${TAG}_c2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_${TAG}_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_${TAG}_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $O/pmc_${TAG}_sq -o out -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_${TAG}_grbm -o out -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
 cd $R
+bash tools/probes/power_probe.sh > $O/${TAG}_power_probe.txt 2>&1
+python tools/pmc_mfma_util.py $O/pmc_${TAG}_sq $O/pmc_${TAG}_grbm $O/${TAG}_power_probe.txt > $O/${TAG}_c3_mfma_util.md 2> $O/${TAG}_mfma_util.err
 python tools/rocprof_summary.py $(find $O/prof_${TAG}_c3 -name "*.db" | head -1) "L4P_TRACK_STREAMS=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof (c3: 7 steps, every kernel serialised on one stream)" > $O/${TAG}_c3_kernel_stats.md
 python tools/rocprof_summary.py $(find $O/prof_${TAG}_c2 -name "*.db" | head -1) "python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-prof (c2: 13 steps)" > $O/${TAG}_c2_kernel_stats.md
 python tools/pmc_hbm_traffic.py $O/pmc_${TAG}_fetch $O/pmc_${TAG}_write $O/${TAG}_c3_hbm_traffic > /dev/null
