@@ -1,0 +1,248 @@
+// 3x3x3 conv (stride 1, pad 1, channels-last, bf16) with the input block staged ONCE per channel slice in LDS ("halo"
+// tile) and the 27 taps walked out of LDS — the full-resolution convs of the DPT decoders (reference dpt_block.py:110-157
+// ResidualConvUnit, :406-414 head; dpt_head.py:41-86).  Same math, descriptor and epilogues as the implicit-GEMM form
+// (gemm.hpp / gemm8p.hpp MODE 1), different data movement:
+//
+//  * implicit GEMM streams, per (tap, channel slice), the A rows of its tile from global memory: every input element
+//    travels L2 -> LDS 27 times (PMC: 7x the operand bytes even reach the fabric) and the A stream is half of the
+//    kernel's L2 -> LDS traffic.
+//  * here a workgroup owns an output BLOCK of TT x TH x TW = 2 x (8|16) x 16 voxels and all BN = 256 | 128 output
+//    channels.  For a slice of CK = 32 input channels it holds the (TT+2) x (TH+2) x (TW+2) halo block in LDS (64-byte
+//    rows, zero rows outside the volume: no masks in the loop) and runs the 27 taps as 27 k-tiles whose A fragments are
+//    ds_read_b128 at a tap-dependent row offset.  Only the weights stream: one BN x 32 tile per k-tile through a 4-slot
+//    LDS-DMA ring.  L2 -> LDS bytes per MFMA drop by ~45 % (256 x 256: 64 KB -> 35 KB per 64-deep k step).
+//  * the halo is a SINGLE buffer refilled plane by plane while it is in use: t-plane 0 is only read by the nine dt = -1
+//    taps and plane 1 by the eighteen dt <= 0 taps, so the next slice's planes 0 / 1 are fetched during taps 9.. / 18..
+//    of the current slice, and planes 2 / 3 during the first taps of their own slice (first needed at tap 9 / 18).
+//  * LDS rows are 64 bytes = 4 chunks; the chunk is XORed with ((x >> 2) & 1) << 1, x = the row's position along w inside
+//    its halo row (W tiles: the MFMA row).  A fragment is 16 consecutive rows of one halo row, so among the four lanes
+//    that share a 256-byte bank row (rows 4 apart) the XOR term alternates, which makes the four 16-lane groups of
+//    ds_read_b128 conflict-free at ANY row alignment, i.e. for every tap offset (checked exhaustively).  The term depends
+//    on the lane and on dw only: a lane keeps three fragment base addresses (dw = -1, 0, 1) and a k-tile's eight A
+//    fragment reads are ONE add + immediates.  W tiles are stored in fragment order (LDS row = wave column block * 64 +
+//    j * 16 + MFMA row).  All staging is LDS-DMA with the swizzle applied to the per-lane SOURCE chunk.
+//  * pipeline: the 8-phase kernel's structure with a 32-deep k-tile = two phases of 16 MFMAs per wave
+//        P1: read W(t) + A rows 0-63 | stage W(t+3)        | barrier | 16 MFMAs | barrier
+//        P2: read A rows 64-127      | stage a halo piece  | vmcnt   | barrier | 16 MFMAs | barrier
+//    the two 4-wave groups run one barrier apart (one wave's MFMA segment over its SIMD partner's read / stage
+//    segment).  Hazards: W(t+3) overwrites the slot of W(t-1), last read three barriers earlier by the delayed group;
+//    W(t+1) is waited for (vmcnt(2 * W_PASS): everything but the two youngest W tiles; halo pieces in flight only make
+//    the wait stricter) at the end of P2(t) and first read after the following barrier; a halo plane is refilled >= 4
+//    barriers after its last read and first read >= 6 k-tiles after its refill was issued.
+#pragma once
+#include "gemm.hpp"
+
+template <int WR, int WC>
+struct ConvHaloCfg {
+    static constexpr int BM = WR * 128, BN = WC * 64, CK = 32;
+    static constexpr int TT = 2, TW = 16, TH = BM / (TT * TW);
+    static constexpr int HH = TH + 2, HW = TW + 2, PR = HH * HW, NPL = TT + 2;
+    static constexpr int PRP = (PR + 15) / 16 * 16;  // plane stride in rows: whole waves of LDS-DMA slots (4 slots per row), the
+                                                      // rows PR .. PRP-1 are filler that is written (zeros) and never read
+    static constexpr int HALO_BYTES = NPL * PRP * 64;
+    static constexpr int WSLOT = BN * 64, NSLOT = 4;
+    static constexpr int LDS_BYTES = HALO_BYTES + NSLOT * WSLOT;
+    static constexpr int W_PASS = BN * 4 / 512;            // LDS-DMA instructions per lane and W tile
+    static constexpr int H_PASS = (PRP * 4 + 511) / 512;   // ... per halo plane
+};
+
+template <int WR, int WC>
+__global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
+    static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
+    typedef bf16_t T;
+    typedef ConvHaloCfg<WR, WC> Cfg;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, TM = 8, TN = 4;
+    constexpr int TT = Cfg::TT, TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, PR = Cfg::PR, PRP = Cfg::PRP;
+    constexpr int WSLOT = Cfg::WSLOT, W_PASS = Cfg::W_PASS, H_PASS = Cfg::H_PASS;
+    static_assert(2 * H_PASS <= 9, "planes 2 / 3 are refilled before tap 9");
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [halo NPL x PRP rows x 64 B][W ring 4 x BN x 64 B]
+    char* const wring = smem + Cfg::HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC, grp = wave >> 2;
+    const int li = lane & 15, kg = lane >> 4;
+
+    // ---- workgroup -> output block: XCD x (workgroup b runs on XCD b % 8) owns a contiguous range of blocks in the order
+    //      (batch, t block, h block, w block fastest): the ~32 blocks an XCD runs at a time are a compact slab whose halos
+    //      overlap in its L2 ----
+    const int nbw = p.Wo / TW, nbh = p.Ho / TH, nbt = p.To / TT;
+    const int ntiles = (p.M / BM);
+    int tile;
+    {
+        const int bid = (int)blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = ntiles >> 3, r = ntiles & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int rem = tile;
+    const int bw = rem % nbw;
+    rem /= nbw;
+    const int bh = rem % nbh;
+    rem /= nbh;
+    const int bt = rem % nbt, bb = rem / nbt;
+    const int t0 = bt * TT, h0 = bh * TH, w0 = bw * TW;
+
+    // ---- W staging: LDS slot s = pass * 512 + tid  ->  (LDS row s >> 2 = colblock * 64 + j * 16 + a, physical chunk s & 3) ----
+    const char* w_src[W_PASS];
+#pragma unroll
+    for (int i = 0; i < W_PASS; ++i) {
+        const int s = i * 512 + tid, row = s >> 2, cp = s & 3;
+        const int cb = row >> 6, j = (row >> 4) & 3, a = row & 15;
+        const int n = cb * 64 + 16 * (a >> 2) + 4 * j + (a & 3);  // the output column this MFMA row accumulates (gemm.hpp)
+        const int c = cp ^ (((a >> 2) & 1) << 1);
+        w_src[i] = (const char*)((const T*)p.W + (long long)n * p.ldw) + c * 16;
+    }
+    // ---- halo staging: slot s = pass * 512 + tid of a plane -> (row r = s >> 2 = hh * HW + hw, physical chunk s & 3) ----
+    unsigned h_off[H_PASS];  // byte offset of (h, w, chunk) inside a (b, t) plane of the input
+    bool h_ok[H_PASS];
+#pragma unroll
+    for (int i = 0; i < H_PASS; ++i) {
+        const int s = i * 512 + tid, r = s >> 2;
+        const int hh = r / HW, hw = r - hh * HW;
+        const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+        h_ok[i] = s < PR * 4 && (unsigned)gh < (unsigned)p.Hi && (unsigned)gw < (unsigned)p.Wi;
+        const int c = (s & 3) ^ (((hw >> 2) & 1) << 1);  // logical chunk held by this physical slot
+        h_off[i] = h_ok[i] ? (unsigned)(((long long)gh * p.Wi + gw) * p.Cin * 2 + c * 16) : 0u;
+    }
+    const long long plane_bytes = (long long)p.Hi * p.Wi * p.Cin * 2;
+    const char* zero = (const char*)g_zero_chunk;
+    auto stage_halo = [&](int plane, int cs, int pass) {  // one LDS-DMA instruction (per lane) of a halo plane
+#pragma unroll
+        for (int i = 0; i < H_PASS; ++i) {
+            if (i != pass) continue;
+            if (i * 512 + wave * 64 >= PRP * 4) continue;  // (whole waves past the plane issue nothing: wave-uniform)
+            const int gt = t0 - 1 + plane;
+            const bool ok = h_ok[i] && (unsigned)gt < (unsigned)p.Ti;
+            const char* src = ok ? (const char*)p.A + ((long long)bb * p.Ti + gt) * plane_bytes + h_off[i] + cs * 64 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (plane * PRP * 4 + i * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    const int ncs = p.Cin / 32, nk = ncs * 27;
+    auto stage_w = [&](int t, int koff) {  // W tile of k-tile t (byte offset koff of its k range) into ring slot t & 3
+#pragma unroll
+        for (int i = 0; i < W_PASS; ++i) {
+            const char* src = t < nk ? w_src[i] + koff : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wring + (t & 3) * WSLOT + (i * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read addresses ----
+    // A: fragment f (0..7) of this wave = output rows (ft, fh) = block row wr * 8 + f, 16 voxels along w; its centre halo row
+    const int F0 = wr * 8;
+    const int rho_c = (F0 / TH + 1) * PRP + (F0 % TH + 1) * HW + 1 + li;  // + f * HW
+    int a_base[3];  // byte address of fragment 0 at tap (0, 0, dw): the swizzle term follows the w position 1 + dw + li
+#pragma unroll
+    for (int d = 0; d < 3; ++d) a_base[d] = (rho_c + d - 1) * 64 + ((kg ^ ((((li + d) >> 2) & 1) << 1)) << 4);
+    // W: fragment j = LDS rows wc * 64 + j * 16 + li
+    const int w_off = (wc * 64 + li) * 64 + ((kg ^ (((li >> 2) & 1) << 1)) << 4);  // + j * 1024
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 xa[4], wb[4];
+
+    auto read_w = [&](int t) {
+        const char* base = wring + (t & 3) * WSLOT + w_off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wb[j] = *(const bf16x8*)(base + j * 1024);
+    };
+    auto read_a = [&](int half, int abase) {  // fragments half * 4 .. + 3; abase = this tap's address of fragment 0
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) xa[ii] = *(const bf16x8*)(smem + abase + (half * 4 + ii) * (HW * 64));
+    };
+    auto mfma16 = [&](int half) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[half * 4 + ii][j] = mma16(wb[j], xa[ii], acc[half * 4 + ii][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: the whole halo of slice 0 and W(0..2) ----
+#pragma unroll
+    for (int pl = 0; pl < Cfg::NPL; ++pl)
+#pragma unroll
+        for (int i = 0; i < H_PASS; ++i) stage_halo(pl, 0, i);
+    const int tap_bytes = p.Cin * 2;
+    stage_w(0, 0);
+    stage_w(1, tap_bytes);
+    stage_w(2, 2 * tap_bytes);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    int tap = 0, cs = 0;          // k-tile t = cs * 27 + tap = tap (dt, dh, dw) of channel slice cs
+    int dw = 0, dh = 0;           // dw + 1, dh + 1 of the tap
+    int toff = (-PRP - HW) * 64;  // byte offset of the tap's (dt, dh) rows relative to the centre (dw is in a_base)
+    int tap3 = 3, koff3 = 3 * tap_bytes;  // k-tile t + 3 (the one being staged): its tap and the byte offset of its k range
+    for (int t = 0; t < nk; ++t) {
+        const int abase = (dw == 0 ? a_base[0] : dw == 1 ? a_base[1] : a_base[2]) + toff;
+        // ---- P1 ----
+        read_w(t);
+        read_a(0, abase);
+        stage_w(t + 3, koff3);
+        bar();
+        mfma16(0);
+        bar();
+        // ---- P2 ----
+        read_a(1, abase);
+        if (cs + 1 < ncs) {  // next slice's planes 0 / 1 once the current slice no longer reads them
+            if (tap >= 9 && tap < 9 + H_PASS) stage_halo(0, cs + 1, tap - 9);
+            if (tap >= 18 && tap < 18 + H_PASS) stage_halo(1, cs + 1, tap - 18);
+        }
+        if (cs > 0) {        // this slice's planes 2 / 3 (first read at tap 9 / 18)
+            if (tap < H_PASS) stage_halo(2, cs, tap);
+            else if (tap < 2 * H_PASS) stage_halo(3, cs, tap - H_PASS);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W_PASS) : "memory");  // W(t+1) (and everything older) has landed
+        bar();
+        mfma16(1);
+        bar();
+        // next tap: dw fastest, then dh, then dt, then the next channel slice
+        ++tap;
+        if (++dw == 3) {
+            dw = 0;
+            toff += HW * 64;
+            if (++dh == 3) {
+                dh = 0;
+                toff += (PRP - 3 * HW) * 64;
+                if (tap == 27) {
+                    tap = 0;
+                    ++cs;
+                    toff = (-PRP - HW) * 64;
+                }
+            }
+        }
+        koff3 += tap_bytes;
+        if (++tap3 == 27) {  // k range of (tap 0, next slice): back by 27 taps, on by 32 channels
+            tap3 = 0;
+            koff3 += 64 - 27 * tap_bytes;
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with the trailing barrier of the delayed group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (only zero-chunk dummies are still in flight)
+
+    // ---- epilogue: the lean dense family on the block's rows.  Logical row (inside this block) r = f * 16 + li lives at
+    //      output voxel (t0 + f / TH, h0 + f % TH, w0 + li) ----
+    const long long origin = (((long long)bb * p.To + t0) * p.Ho + h0) * p.Wo + w0;
+    const int m_tile = tile * BM;
+    const long long hw_out = (long long)p.Ho * p.Wo;
+    const int Wo = p.Wo;
+    auto rowmap = [=](int m) -> long long {
+        const int r = m - m_tile, f = r >> 4;
+        return origin + (long long)(f / TH) * hw_out + (f % TH) * Wo + (r & 15);
+    };
+    gemm_epilogue_dense_cases<T, TM, TN>(p, acc, m_tile + wr * 128, wc * 64, li, kg, rowmap);
+}

@@ -395,9 +395,18 @@ __device__ __forceinline__ void epi_static_for(F&& f) {
     }
 }
 
-template <typename T, int TM, int TN, int ACT, int RES>
+// logical row m -> physical row of the output / residual: the descriptor's optional one-level row map (l4p_gemm_desc.c_*)
+struct EpiRowMapDesc {
+    const GemmParams& p;
+    __device__ __forceinline__ long long operator()(int m) const {
+        return p.c_gr > 0 ? (long long)(m / p.c_gr) * p.c_gs + p.c_go + (m % p.c_gr) : m;
+    }
+};
+
+// RowMap: any callable int -> long long (conv3_halo.hpp passes the voxel-tile map of its 3-D output tiles)
+template <typename T, int TM, int TN, int ACT, int RES, class RowMap>
 __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0, int li,
-                                                    int kg) {
+                                                    int kg, const RowMap& crow) {
     constexpr int ES = sizeof(T);
     constexpr int NV = 4 * TN, NG = NV / 8;
     const int nb = n_wave0 + NV * kg;
@@ -426,8 +435,7 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
     constexpr int RD = RES == 0 ? 1 : RES == 2 ? 2 : (GEMM_EPI_RES_DEPTH < TM ? GEMM_EPI_RES_DEPTH : TM);
     f32x4 rf[RD][RES == 1 ? 2 * NG : 1][1];
     u32x4 rt[RD][RES == 2 ? NG : 1][2];
-    // optional row map of the output and the residual (l4p_gemm_desc.c_*): logical row m lives at physical row crow(m)
-    auto crow = [&](int m) -> long long { return p.c_gr > 0 ? (long long)(m / p.c_gr) * p.c_gs + p.c_go + (m % p.c_gr) : m; };
+    // (row map of the output and the residual: logical row m lives at physical row crow(m))
     auto load_res = [&](int m, auto slot_) {
         constexpr int sl = decltype(slot_)::value;
         const long long roff = crow(m) * p.ldr + nb;
@@ -520,6 +528,12 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
             }
         }
     });
+}
+
+template <typename T, int TM, int TN, int ACT, int RES>
+__device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0, int li,
+                                                    int kg) {
+    gemm_epilogue_dense<T, TM, TN, ACT, RES>(p, acc, m_wave0, n_wave0, li, kg, EpiRowMapDesc{p});
 }
 
 // Lean form of the L4P_EPI_QKV epilogue (bf16): what a lane's two 8-column groups are (q / k / v, head, dim) does not
@@ -641,6 +655,29 @@ __device__ __forceinline__ void gemm_epilogue_convt(const GemmParams& p, f32x4 (
     }
 }
 
+// the plain dense family (activation x residual kind); false = a combination that has no lean body.  Host-side twin of the
+// condition: dense_epilogue_is_lean() in gemm_launch.inc.
+template <typename T, int TM, int TN, class RowMap>
+__device__ __forceinline__ bool gemm_epilogue_dense_cases(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0,
+                                                          int li, int kg, const RowMap& crow) {
+    if (p.epi != EPI_DENSE || p.res_mod > 0) return false;
+    const int res = !p.res1 ? 0 : (p.res_f32 ? 1 : 2);
+    if (res == 1 && p.res2) return false;  // (two float residuals: no caller; the generic body handles it)
+#define L4P_EPI_CASE(A, R)                                                                    \
+    if (p.act == A && res == R) {                                                             \
+        gemm_epilogue_dense<T, TM, TN, A, R>(p, acc, m_wave0, n_wave0, li, kg, crow);         \
+        return true;                                                                          \
+    }
+    L4P_EPI_CASE(ACT_NONE, 0)
+    L4P_EPI_CASE(ACT_GELU, 0)
+    L4P_EPI_CASE(ACT_RELU, 0)
+    L4P_EPI_CASE(ACT_NONE, 1)
+    L4P_EPI_CASE(ACT_NONE, 2)
+    L4P_EPI_CASE(ACT_RELU, 2)
+#undef L4P_EPI_CASE
+    return false;
+}
+
 // run-time selection of the specialisation (wave-uniform); false = not a plain dense epilogue, use the generic one
 template <typename T, int TM, int TN>
 __device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0,
@@ -655,22 +692,7 @@ __device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p
         gemm_epilogue_convt<T, TM, TN>(p, acc, m_wave0, n_wave0, li, kg);
         return true;
     }
-    if (p.epi != EPI_DENSE || p.res_mod > 0) return false;
-    const int res = !p.res1 ? 0 : (p.res_f32 ? 1 : 2);
-    if (res == 1 && p.res2) return false;  // (two float residuals: no caller; the generic body handles it)
-#define L4P_EPI_CASE(A, R)                                                                    \
-    if (p.act == A && res == R) {                                                             \
-        gemm_epilogue_dense<T, TM, TN, A, R>(p, acc, m_wave0, n_wave0, li, kg);               \
-        return true;                                                                          \
-    }
-    L4P_EPI_CASE(ACT_NONE, 0)
-    L4P_EPI_CASE(ACT_GELU, 0)
-    L4P_EPI_CASE(ACT_RELU, 0)
-    L4P_EPI_CASE(ACT_NONE, 1)
-    L4P_EPI_CASE(ACT_NONE, 2)
-    L4P_EPI_CASE(ACT_RELU, 2)
-#undef L4P_EPI_CASE
-    return false;
+    return gemm_epilogue_dense_cases<T, TM, TN>(p, acc, m_wave0, n_wave0, li, kg, EpiRowMapDesc{p});
 }
 
 // GLDS = true: tiles are staged with global_load_lds (LDS-DMA, no VGPR round trip, no ds_write); the LDS image is

@@ -291,7 +291,8 @@ def _conv_rows_reference(x_ref, w_ref, bias, rows, stride=(1, 1, 1)):
 @pytest.mark.parametrize("shape,cout", [((4, 16, 64, 64, 256), 256),   # refinenet RCU convs of a B = 4 step: K = 6912
                                          ((4, 16, 32, 32, 512), 256),   # layer_rn: K = 13824
                                          ((2, 16, 56, 56, 256), 256)])  # plane 3136 = 12.25 tiles: walk falls back, ragged rows
-def test_gemm8p_conv3d(dev, shape, cout):
+def test_gemm8p_conv3d(dev, shape, cout, monkeypatch):
+    monkeypatch.setenv("L4P_CONV_HALO", "0")  # the implicit-GEMM form (the LDS-halo kernel has its own tests below)
     B, T, H, W, Cin = shape
     x, x_ref = as_mode(rnd(shape, 70), MODE)
     w = rnd((cout, Cin, 3, 3, 3), 71, (27 * Cin) ** -0.5)
@@ -315,3 +316,82 @@ def test_gemm8p_conv3d(dev, shape, cout):
     assert bool(torch.isfinite(y.float()).all())
     rms = y.float().pow(2).mean(dim=-1).sqrt().reshape(-1)
     assert float(rms.min()) > 0.05 * float(rms.mean())
+
+
+def _assert_halo(p, n=1):
+    tags = [ln[1] for ln in p.lines if ln[0] == "conv3d"]
+    assert len(tags) >= n and all(" halo " in t for t in tags), f"expected the LDS-halo conv kernel, launches were: {p.lines}"
+
+
+def _halo_rows(B, T, H, W, th):
+    """Output voxels that exercise every kind of position of the LDS-halo kernel's 2 x th x 16 blocks: whole first / last
+    blocks (volume borders in t, h, w: zero halo rows), block seams inside the volume, batch seams, scattered rows."""
+    g = torch.Generator().manual_seed(7)
+    M = B * T * H * W
+    idx = torch.arange(M).reshape(B, T, H, W)
+    picks = [idx[0, :2, :th, :16], idx[-1, -2:, -th:, -16:],             # first and last block
+             idx[0, 1:3, th - 1:th + 1, 14:18],                          # a corner where eight blocks meet
+             idx[B // 2, T // 2 - 1:T // 2 + 1, H // 2 - 1:H // 2 + 1, :],  # two full image rows across w blocks
+             idx[:, 0, 0, 0], idx[:, -1, -1, -1]]                        # batch seams
+    rows = torch.cat([p.reshape(-1) for p in picks] + [torch.randint(0, M, (3072,), generator=g)])
+    return rows
+
+
+@pytest.mark.parametrize("shape,cout,act,res", [
+    ((4, 16, 64, 64, 256), 256, ACT_NONE, 2),    # refinenet RCU conv2 of a B = 4 step: two T residuals + relu copy
+    ((4, 16, 64, 64, 256), 256, ACT_RELU, 0),    # RCU conv1
+    ((4, 16, 32, 32, 512), 256, ACT_NONE, 0),    # layer_rn: 16 channel slices
+    ((1, 16, 128, 128, 256), 128, ACT_NONE, 0),  # head1 at batch 1: 512-voxel blocks (2 x 16 x 16), N = 128
+    ((2, 4, 224, 224, 128), 128, ACT_RELU, 0),   # head2 geometry (224 = 14 blocks), short in t: every block touches a t border
+])
+def test_conv3_halo(dev, shape, cout, act, res):
+    """csrc/conv3_halo.hpp (input block staged once per 32-channel slice in LDS, 27 taps walked out of LDS) against fp32
+    torch on the same bf16-rounded inputs (dpt_block.py:110-157,406-414), at the shapes the benchmark runs."""
+    B, T, H, W, Cin = shape
+    x, x_ref = as_mode(rnd(shape, 80), MODE)
+    w = rnd((cout, Cin, 3, 3, 3), 81, (27 * Cin) ** -0.5)
+    bias = rnd((cout,), 82)
+    wT, w_ref = as_mode(w.permute(0, 2, 3, 4, 1).reshape(cout, 27 * Cin), MODE)
+    M = B * T * H * W
+    kw = {}
+    if res:
+        s1, s1_ref = as_mode(rnd((B, T, H, W, cout), 83), MODE)
+        s2, s2_ref = as_mode(rnd((B, T, H, W, cout), 84), MODE)
+        kw = dict(res1=s1, res2=s2, relu_copy=True)
+    with prof_tags() as p:
+        out = ops.conv3d_k3(x, ops.pad_rows(wT, 256), cout, bias=bias.cuda(), act=act, **kw)
+    _assert_halo(p)
+    y, yr = out if res else (out, None)
+    rows = _halo_rows(B, T, H, W, 8 if cout == 256 else 16)
+    ref = _conv_rows_reference(x_ref, w_ref, bias, rows)
+    if act == ACT_RELU:
+        ref = F.relu(ref)
+    if res:
+        ref = ref + s1_ref.reshape(M, cout)[rows] + s2_ref.reshape(M, cout)[rows]
+    check(y.reshape(M, cout)[rows.cuda()], ref, MODE, True)
+    if res:
+        check(yr.reshape(M, cout)[rows.cuda()], F.relu(ref), MODE, True)
+    assert bool(torch.isfinite(y.float()).all())
+    rms = y.float().pow(2).mean(dim=-1).sqrt().reshape(-1)
+    assert float(rms.min()) > 0.05 * float(rms.mean())  # (a block that was never written, or written at the wrong voxels)
+
+
+def test_conv3_halo_equals_implicit_gemm_form(dev, monkeypatch):
+    """Same arithmetic, different data movement: on the same inputs the LDS-halo kernel and the implicit-GEMM kernel agree to
+    the summation-order level (the k order differs: channel slice outermost vs tap outermost) on EVERY output voxel."""
+    shape, cout = (2, 8, 64, 64, 256), 256
+    x, _ = as_mode(rnd(shape, 90), MODE)
+    w = rnd((cout, 256, 3, 3, 3), 91, (27 * 256) ** -0.5)
+    wT, _ = as_mode(w.permute(0, 2, 3, 4, 1).reshape(cout, 27 * 256), MODE)
+    wp = ops.pad_rows(wT, 256)
+    bias = rnd((cout,), 92).cuda()
+    with prof_tags() as p:
+        a = ops.conv3d_k3(x, wp, cout, bias=bias)
+    _assert_halo(p)
+    monkeypatch.setenv("L4P_CONV_HALO", "0")
+    with prof_tags() as p:
+        b = ops.conv3d_k3(x, wp, cout, bias=bias)
+    assert all(" halo " not in ln[1] for ln in p.lines)
+    d = (a.float() - b.float()).abs()
+    assert float(d.max()) <= 2 ** -6 * float(b.float().abs().max()), float(d.max())  # <= 2 bf16 ulp of the maximum, everywhere
+    assert float((a.float() - b.float()).norm() / b.float().norm()) <= 3e-3
