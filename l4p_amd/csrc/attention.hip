@@ -49,11 +49,15 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// QS = 2 ("query split", batch >= 4): the workgroup has 8 waves that cover 256 query rows (waves 0-3 the first 128, waves
+// 4-7 the second) of ONE (batch, head) and SHARE one K / V^T tile ring: a tile is fetched and written into LDS once per 256
+// query rows instead of once per 128 (half the L2 -> LDS bytes and LDS-DMA writes per MFMA), every wave issues 3 LDS-DMA
+// requests per KV block instead of 6, and a batch-4 launch is ONE round of 512 workgroups (two per CU, four waves per SIMD).
 // HS (bf16 only): the KV-block body is hand scheduled - see the comment at its definition below.
-template <typename T, int DP, int KVB, int DH, int SPLIT, bool HS = false>
-__global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__ q, const T* __restrict__ kt,
+template <typename T, int DP, int KVB, int DH, int SPLIT, bool HS = false, int QS = 1>
+__global__ __launch_bounds__(256 * SPLIT * QS) void attn_kernel(const T* __restrict__ q, const T* __restrict__ kt,
                                                            const T* __restrict__ vt, T* __restrict__ out, int S, int H,
-                                                           float c_scale) {
+                                                           float c_scale, int ntiles) {
     typedef typename Frag<T>::type frag_t;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -75,9 +79,26 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     constexpr int HI_L = (I_L >> 2) & 1, R_L = (I_L & 3) + 4 * (I_L >> 3);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // KV-split group of this wave
-    char* Ks = smem + grp * 2 * (KBYTES + VBYTES);  // [2][KBYTES]   (per group)
+    static_assert(SPLIT == 1 || QS == 1, "KV split and query split are alternatives");
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // KV-split / query-split group of this wave
+    const int kgrp = QS > 1 ? 0 : grp;                                  // KV blocks walked: every one (QS) or every SPLIT-th
+    char* Ks = smem + kgrp * 2 * (KBYTES + VBYTES);  // [2][KBYTES]   (per KV-split group; shared by the query-split groups)
     char* Vs = Ks + 2 * KBYTES;                      // [2][VBYTES]
+    // PERSIST (no KV split): a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the NEXT tile's K_0 / K_1 / V_0 ride the rings
+    // through the seam (requested by the last two iterations of the current tile) and its Q rows are fetched into Qs by
+    // LDS-DMA a few iterations before the end, so a seam costs one barrier instead of a round trip to HBM with every
+    // workgroup of the chip fetching its prologue at the same time (measured: ~3.8 us per seam at batch 4).
+#ifdef ATTN_NO_PERSIST
+    constexpr bool PERSIST = false;
+#else
+    // (Only the 8-wave query-split form: the 4-wave form would need 276 registers, i.e. one wave per SIMD.  -DATTN_SEAM_STEP
+    //  goes one step further - the last step of a tile builds the next tile's first scores from Q read out of Qs, so a seam is
+    //  the output store only - but it needs ~10 registers more than the 256 two waves per SIMD leave: hipcc spills pointers
+    //  to scratch inside the steady-state loop; kept for a future hand-allocated form.)
+    constexpr bool PERSIST = SPLIT == 1 && QS > 1;
+#endif
+    constexpr int QROWS = 128 * QS, QBYTES = QROWS * DP * ES;
+    char* Qs = smem + 2 * (KBYTES + VBYTES);         // [QROWS][DP] (PERSIST only)
 
     const int tid = threadIdx.x & 255, lane = tid & 63;  // thread / wave index inside the group
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,34 +106,25 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     // XCD-aware work mapping: workgroup L runs on XCD L % 8 (observed dispatch order; speed only, not
     // correctness).  All S/128 query blocks of one (batch, head) are given to the SAME XCD so that head's
     // K / V^T (786 KB) is fetched into one L2 instead of eight.
-    const int nqb = S / 128, units = gridDim.x / nqb;  // units = B * H
-    int unit, qb;
-    if ((units & 7) == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        unit = xcd + 8 * (j / nqb);
-        qb = j % nqb;
-    } else {
-        unit = blockIdx.x / nqb;
-        qb = blockIdx.x % nqb;
-    }
-    const int b = unit / H, h = unit % H;
-    const int q_row = qb * 128 + wave * 32 + lq;
-
-    // Q fragments (B operand: column = query, 8 consecutive d per k-step half)
-    frag_t qf[NKS];
-    {
-        const T* qp = q + ((long long)b * S + q_row) * ((long long)H * DP) + (long long)h * DP;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            u32x4* d = (u32x4*)&qf[ks];
-#pragma unroll
-            for (int c = 0; c < CPF; ++c) d[c] = *(const u32x4*)(qp + ks * 16 + hi * 8 + c * EPC);
+    const int nqb = S / (128 * QS), units = ntiles / nqb;  // units = B * H
+    auto decode = [&](int v, int& bh_, int& qrow0_) {  // tile v -> (batch * H + head, first query row of the tile in its batch item)
+        int unit, qb;
+        if ((units & 7) == 0) {
+            const int xcd = v & 7, j = v >> 3;
+            unit = xcd + 8 * (j / nqb);
+            qb = j % nqb;
+        } else {
+            unit = v / nqb;
+            qb = v % nqb;
         }
-    }
-
-    // ---- LDS-DMA sources -----------------------------------------------------------------------------
+        bh_ = unit;
+        qrow0_ = (unit / H) * S + qb * (128 * QS);  // row of q / out: batch * S + token
+    };
+    const int qloc = (QS > 1 ? grp * 128 : 0) + wave * 32 + lq;  // this lane's query row inside the tile
     const int nkb = S / KVB;
-    const char* kbase = (const char*)kt + ((long long)(b * H + h) * nkb) * KBYTES + tid * 16;  // + kb*KBYTES + i*4096
+
+    // ---- LDS-DMA sources: lane-constant parts (the tile adds batch-head offsets koff / voff, wave-uniform) ----------------
+    const char* kbase = (const char*)kt + tid * 16;  // + kb*KBYTES + i*4096
     // V^T: LDS position (row d, slot) <- chunk slot ^ ((d >> 1) & 7) of that row
     const int vrow0 = tid >> 3, vslot = tid & 7;
     const int vchunk = vslot ^ ((vrow0 >> 1) & 7);  // (d >> 1) & 7 is the same for d = vrow0 + 32*i
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     for (int i = 0; i < V_IT; ++i) {
         const int d = vrow0 + 32 * i;
         vones[i] = d == DH;
-        vsrc[i] = (const char*)(vt + (((long long)b * H + h) * DP + d) * S) + vchunk * 16;  // + kb*128
+        vsrc[i] = (const char*)(vt + (long long)d * S) + vchunk * 16;  // + voff + kb*128
     }
     const char* ones = ES == 2 ? (const char*)g_ones_bf16 : (const char*)g_ones_f32;
     // chunk c = tid + 256 i of a K tile is (k-step c / (2 KVB), key (c % (2 KVB)) / 2, half (c & 1) ^ ((key >> 3) & 1))
@@ -133,30 +145,143 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         kpad[i] = DEFER && (c / (2 * KVB)) * 16 + (((c & 1) ^ ((key >> 3) & 1)) << 3) == DH;
     }
     const char* kone = (const char*)g_kone_bf16;
-    auto issue_k = [&](int kb, int buf) {
+    // QS: the 768 chunks of a tile are spread over 512 lanes: chunk gt (all lanes) + one more for half of the waves (K: chunk
+    // 512 + gt from waves 0-3; V^T: chunk gt - 256 from waves 4-7, its first pass being chunks 256 + gt) - 3 requests per wave
+    const int gt = threadIdx.x, gwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char* qk_src[2];
+    const char* qv_src[2];
+    bool qk_pad[2], qv_ones[2];
+    if constexpr (QS > 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i == 0 ? gt : 512 + (gt & 255), key = (c % (2 * KVB)) >> 1;
+            qk_pad[i] = DEFER && (c / (2 * KVB)) * 16 + (((c & 1) ^ ((key >> 3) & 1)) << 3) == DH;
+            qk_src[i] = (const char*)kt + c * 16;
+            const int cv = i == 0 ? 256 + gt : (gt & 255), d = cv >> 3, slot = cv & 7;
+            qv_ones[i] = d == DH;
+            qv_src[i] = (const char*)(vt + (long long)d * S) + (slot ^ ((d >> 1) & 7)) * 16;
+        }
+    }
+    // (tko / tvo: byte offset of the tile's (batch, head) in kt / vt relative to the per-lane pointers, which are those of
+    //  the CURRENT tile: 0 for it, the distance to the next tile's head for the prefetch across the seam)
+    auto issue_k = [&](long long tko, int kb, int buf) {
+        if constexpr (QS > 1) {
+            const char* s0 = qk_pad[0] ? kone : qk_src[0] + tko + (long long)kb * KBYTES;
+            __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)(Ks + buf * KBYTES + (gwave * 64) * 16), 16, 0, 0);
+            if (gwave < 4) {
+                const char* s1 = qk_pad[1] ? kone : qk_src[1] + tko + (long long)kb * KBYTES;
+                __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(Ks + buf * KBYTES + (512 + gwave * 64) * 16), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < K_IT; ++i) {
-            const char* src = kpad[i] ? kone : kbase + (long long)kb * KBYTES + i * 4096;
+            const char* src = kpad[i] ? kone : kbase + tko + (long long)kb * KBYTES + i * 4096;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ks + buf * KBYTES + (wave * 64 + i * 256) * 16), 16, 0, 0);
         }
     };
-    auto issue_v = [&](int kb, int buf) {
+    auto issue_v = [&](long long tvo, int kb, int buf) {
+        if constexpr (QS > 1) {
+            const char* s0 = qv_ones[0] ? ones : qv_src[0] + tvo + (long long)kb * 128;
+            __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)(Vs + buf * VBYTES + (256 + gwave * 64) * 16), 16, 0, 0);
+            if (gwave >= 4) {
+                const char* s1 = qv_ones[1] ? ones : qv_src[1] + tvo + (long long)kb * 128;
+                __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(Vs + buf * VBYTES + ((gwave - 4) * 64) * 16), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < V_IT; ++i) {
-            const char* src = vones[i] ? ones : vsrc[i] + (long long)kb * 128;
+            const char* src = vones[i] ? ones : vsrc[i] + tvo + (long long)kb * 128;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vs + buf * VBYTES + (wave * 64 + i * 256) * 16), 16, 0, 0);
         }
     };
-
-    // HS: the softmax scale (times log2 e) is folded into Q once, here (the reference scales q before q k^T as well,
-    // modeling_finetune.py:180), so the scores come out of the MFMA in the exp2 domain
-    if constexpr (DEFER) {
-        if (c_scale != 1.0f) {  // (pre-scaled q: nothing to do, and no second rounding)
+    // the next tile's Q rows -> Qs, a linear [QROWS][DP] image: chunk c = pass * NT + thread is (row c / CPR, 16-byte piece c % CPR)
+    auto issue_q = [&](int qrow0n, int bhn) {
+        constexpr int CPR = DP * ES / 16, NT = 256 * QS;
+        static_assert((QROWS * CPR) % NT == 0, "whole LDS-DMA passes");
+        const char* qb_ = (const char*)(q + (long long)qrow0n * ((long long)H * DP) + (long long)(bhn % H) * DP);
+        // (an opaque zero: the per-lane address arithmetic below is invariant in the KV loop, and hoisted out of it, it would
+        //  hold ~25 registers through the whole tile - 231 + 25 no longer fits two waves per SIMD)
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        const int t_ = (int)threadIdx.x + z;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = from_f32<T>(to_f32<T>(qf[ks][e]) * c_scale);
+        for (int i = 0; i < QROWS * CPR / NT; ++i) {
+            const int c = i * NT + t_, row = c / CPR, pc = c - row * CPR;
+            __builtin_amdgcn_global_load_lds((gptr_t)(qb_ + (long long)row * ((long long)H * DP * ES) + pc * 16),
+                                             (lptr_t)(Qs + (i * NT + (int)(threadIdx.x >> 6) * 64) * 16), 16, 0, 0);
         }
+    };
+
+    // ================================ tile loop ================================
+    int bh_at = 0;  // the (batch, head) the per-lane source pointers currently point at
+    // State that crosses a tile seam (PERSIST): the LAST pipeline step of a tile already builds the first scores of the next
+    // tile (its Q fragments are read from Qs into qf once the current tile's last QK^T is done, the K ring already holds the
+    // next K_0), so a seam is the output store of the finished tile and nothing else.
+    frag_t qf[NKS];             // Q fragments (B operand: column = query, 8 consecutive d per k-step half)
+    f32x16 s_a[NST], s_b[NST];  // score registers, used ping-pong (no copy between pipeline steps)
+    float mx = 0.f;             // row maximum of the scores the next step consumes
+    auto q_from_lds = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4* d = (u32x4*)&qf[ks];
+#pragma unroll
+            for (int c = 0; c < CPF; ++c) d[c] = *(const u32x4*)(Qs + (qloc * DP + ks * 16 + hi * 8 + c * EPC) * ES);
+        }
+    };
+    // HS: the softmax scale (times log2 e) is folded into Q once (the reference scales q before q k^T as well,
+    // modeling_finetune.py:180), so the scores come out of the MFMA in the exp2 domain
+    auto q_prescale = [&]() {
+        if constexpr (DEFER) {
+            if (c_scale != 1.0f) {  // (pre-scaled q: nothing to do, and no second rounding)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qf[ks][e] = from_f32<T>(to_f32<T>(qf[ks][e]) * c_scale);
+            }
+        }
+    };
+    for (int v = blockIdx.x; v < ntiles; v += PERSIST ? (int)gridDim.x : ntiles) {
+    int bh, qrow0;
+    decode(v, bh, qrow0);
+    const int vn = v + (int)gridDim.x;
+    const bool has_next_tile = PERSIST && vn < ntiles;
+    int bhn = 0, qrow0n = 0;
+    if (has_next_tile) decode(vn, bhn, qrow0n);
+    bh = __builtin_amdgcn_readfirstlane(bh), qrow0 = __builtin_amdgcn_readfirstlane(qrow0);  // (wave-uniform: keep them scalar)
+    bhn = __builtin_amdgcn_readfirstlane(bhn), qrow0n = __builtin_amdgcn_readfirstlane(qrow0n);
+    // the per-lane source pointers are moved to this tile's (batch, head); the next tile is addressed relative to them
+    {
+        const long long dk = (long long)(bh - bh_at) * nkb * KBYTES, dv = (long long)(bh - bh_at) * DP * S * ES;
+        kbase += dk;
+#pragma unroll
+        for (int i = 0; i < V_IT; ++i) vsrc[i] += dv;
+        if constexpr (QS > 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) qk_src[i] += dk, qv_src[i] += dv;
+        }
+        bh_at = bh;
+    }
+    const long long tk = 0, tv = 0;                                                                  // this tile's K / V^T
+    const long long tkn = (long long)(bhn - bh) * nkb * KBYTES, tvn = (long long)(bhn - bh) * DP * S * ES;  // the next tile's
+    // later tiles: K_0, K_1, V_0 were requested and Q, the first scores and their row maximum left by the previous tile's last step
+    const bool first_tile = !PERSIST || v == (int)blockIdx.x;
+    const int q_row = qrow0 + qloc;                // row of q / out (batch * S + token)
+    const int h = bh % H;
+    const int nit = nkb / SPLIT;
+    if (first_tile) {
+        issue_k(tk, kgrp, 0);
+        issue_v(tv, kgrp, 0);
+        if (nit > 1) issue_k(tk, SPLIT + kgrp, 1);
+        const T* qp = q + (long long)q_row * ((long long)H * DP) + (long long)h * DP;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4* d = (u32x4*)&qf[ks];
+#pragma unroll
+            for (int c = 0; c < CPF; ++c) d[c] = *(const u32x4*)(qp + ks * 16 + hi * 8 + c * EPC);
+        }
+        q_prescale();
     }
 
     f32x16 o[NDT];
@@ -215,15 +340,21 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     //   iteration j:  [ S_{j+1} = K_{j+1} Q^T  (MFMA)  ||  P_j = exp2(S_j*c - m)  (VALU) ]
     //                 [ O^T += V_j^T P_j^T     (MFMA)  ||  row max of S_{j+1}     (VALU) ]
     // so each MFMA batch has independent VALU work to issue under it.  K runs one block ahead of V in the LDS rings.
-    const int nit = nkb / SPLIT;
-    issue_k(grp, 0);
-    issue_v(grp, 0);
-    if (nit > 1) issue_k(SPLIT + grp, 1);
-    __syncthreads();
-    f32x16 s_a[NST], s_b[NST];  // score registers, used ping-pong (no copy between pipeline steps)
-    qk_tile(Ks, s_a);
-    float mx = row_max(s_a);
-    __syncthreads();  // every wave has read K_0 before the first iteration re-stages its slot
+#ifdef ATTN_SEAM_STEP
+    if (first_tile)  // (later tiles: s_a and mx come out of the previous tile's last step)
+#endif
+    {
+        __syncthreads();  // K_0 / V_0 / K_1 (and, past the first tile, Q in Qs) have landed; the previous tile's reads are done
+#ifndef ATTN_SEAM_STEP
+        if (!first_tile) {
+            q_from_lds();
+            q_prescale();
+        }
+#endif
+        qk_tile(Ks, s_a);
+        mx = row_max(s_a);
+        __syncthreads();  // every wave has read K_0 before the first iteration re-stages its slot
+    }
 
     // one pipeline step; HAS_NEXT is a compile-time flag so that the steady-state body is ONE basic block in which the
     // scheduler is free to interleave the two MFMA batches with the VALU work (the last block is peeled)
@@ -233,8 +364,9 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     // maximum exceeds it by more than RESCALE_THR (P <= 2^THR otherwise), and always at the first block.  The block body
     // has no multiply-add in front of the exponential.
     constexpr float RESCALE_THR = 8.f;
-    auto step = [&](int it, auto has_next, f32x16* s_cur, f32x16* s_nxt) __attribute__((always_inline)) {
-        constexpr bool HAS_NEXT = decltype(has_next)::value;
+    // SEAM (compile time): the last step of a tile that has a successor - its "next" scores are the next tile's first ones
+    auto step = [&](int it, auto has_next, auto seam_, f32x16* s_cur, f32x16* s_nxt) __attribute__((always_inline)) {
+        constexpr bool HAS_NEXT = decltype(has_next)::value, SEAM = decltype(seam_)::value;
         const int cur = it & 1;
 #ifndef ATTN_DBG_NOLOAD  // (tools/probes/attn_variants.hip: compute-only timing)
 #ifdef ATTN_DMA_IN_SLOTS_ALL  // (probe)
@@ -243,8 +375,13 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         constexpr bool DMA_IN_SLOTS = HS && SPLIT > 1;  // measured: +4 % for the KV-split (batch 1) form, -2 % otherwise
 #endif
         if (!DMA_IN_SLOTS) {
-            if (it + 2 < nit) issue_k((it + 2) * SPLIT + grp, cur);  // K_{it} (ring slot cur) was consumed last iteration
-            if (HAS_NEXT) issue_v((it + 1) * SPLIT + grp, cur ^ 1);  // V_{it-1} (slot cur^1) was consumed last iteration
+            // (K_{it} in ring slot cur and V_{it-1} in slot cur^1 were consumed last iteration)  Past the end of this tile the
+            // rings carry on with the next tile's first blocks (nit is even: its block j lands in slot j & 1 as well)
+            if (it + 2 < nit) issue_k(tk, (it + 2) * SPLIT + kgrp, cur);
+            else if (has_next_tile) issue_k(tkn, it + 2 - nit, cur);
+            if (it + 1 < nit) issue_v(tv, (it + 1) * SPLIT + kgrp, cur ^ 1);
+            else if (has_next_tile) issue_v(tvn, 0, cur ^ 1);
+            if (PERSIST && has_next_tile && it == nit - 4) issue_q(qrow0n, bhn);
         }
 #endif
 #ifdef ATTN_DBG_NOCOMPUTE  // (probe: staging-only timing)
@@ -353,6 +490,10 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
                 mxn = fmaxf(fmaxf(mxn, s_nxt[t][r]), s_nxt[t][r + 1]);
 #endif
             };
+            if constexpr (SEAM) {  // the current tile's last QK^T is done: qf takes the next tile's Q (prefetched into Qs)
+                q_from_lds();
+                q_prescale();
+            }
             static_for<0, PRE>(rd);
             if constexpr (!HAS_NEXT) static_for<0, 16>(exp_pair);
             __builtin_amdgcn_s_setprio(1);  // the MFMA run outranks the co-resident waves' vector work (+4 % at batch 4)
@@ -375,12 +516,12 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
                 if constexpr (!DMA_IN_SLOTS) {
                 } else if constexpr (m < K_IT) {
                     if (it + 2 < nit) {
-                        const char* src = kpad[m < K_IT ? m : 0] ? kone : kbase + (long long)((it + 2) * SPLIT + grp) * KBYTES + m * 4096;
+                        const char* src = kpad[m < K_IT ? m : 0] ? kone : kbase + tk + (long long)((it + 2) * SPLIT + grp) * KBYTES + m * 4096;
                         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ks + cur * KBYTES + (wave * 64 + m * 256) * 16), 16, 0, 0);
                     }
                 } else if constexpr (m < K_IT + V_IT && HAS_NEXT) {
                     constexpr int i = m - K_IT;
-                    const char* src = vones[i] ? ones : vsrc[i] + (long long)((it + 1) * SPLIT + grp) * 128;
+                    const char* src = vones[i] ? ones : vsrc[i] + tv + (long long)((it + 1) * SPLIT + grp) * 128;
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vs + (cur ^ 1) * VBYTES + (wave * 64 + i * 256) * 16), 16, 0, 0);
                 }
                 // VALU slice riding behind this MFMA: 16 pairs over 12 slots (2 pairs in the first four, then 1)
@@ -407,6 +548,10 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
             return;
         }
         // ---- next block's scores (MFMA) alongside this block's exponentials (VALU) ----------------
+        if constexpr (SEAM) {  // (see the hand-scheduled body)
+            q_from_lds();
+            q_prescale();
+        }
         if (HAS_NEXT) qk_tile(Ks + (cur ^ 1) * KBYTES, s_nxt);
         frag_t pf[NST][2];
         {
@@ -449,14 +594,19 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
     {
         int it = 0;
         for (; it + 2 < nit; it += 2) {
-            step(it, std::true_type{}, s_a, s_b);
-            step(it + 1, std::true_type{}, s_b, s_a);
+            step(it, std::true_type{}, std::false_type{}, s_a, s_b);
+            step(it + 1, std::true_type{}, std::false_type{}, s_b, s_a);
         }
         if (it + 2 == nit) {
-            step(it, std::true_type{}, s_a, s_b);
-            step(it + 1, std::false_type{}, s_b, s_a);
+            step(it, std::true_type{}, std::false_type{}, s_a, s_b);
+#ifdef ATTN_SEAM_STEP  // (experiment: the last step of a tile also builds the next tile's first scores - see the note at PERSIST)
+            if (PERSIST && has_next_tile)
+                step(it + 1, std::true_type{}, std::integral_constant<bool, PERSIST>{}, s_b, s_a);  // leaves the next tile's first scores in s_a
+            else
+#endif
+                step(it + 1, std::false_type{}, std::false_type{}, s_b, s_a);
         } else {
-            step(it, std::false_type{}, s_a, s_b);
+            step(it, std::false_type{}, std::false_type{}, s_a, s_b);  // (a single KV block: never persistent)
         }
     }
 
@@ -490,7 +640,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
         if (hi != HI_L) l_tot = other;
     }
     const float inv = 1.0f / l_tot;
-    T* op = out + ((long long)b * S + q_row) * ((long long)H * DH) + (long long)h * DH;
+    T* op = out + (long long)q_row * ((long long)H * DH) + (long long)h * DH;
 #ifndef ATTN_NO_WIDE_STORE
     if constexpr (ES == 2) {
         // The row is split across the half-waves in 4-column pieces (lane: columns 8k + 4hi .. + 3 of every 8-column group
@@ -514,7 +664,7 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
             *(u32x4*)(op + 8 * k + 8 * hi) = (u32x4){x[0], y[0], x[1], y[1]};
         }
         if constexpr (NG & 1) *(u32x2*)(op + 8 * (NG - 1) + 4 * hi) = pk[NG - 1];
-        return;
+        continue;  // next tile
     }
 #endif
 #pragma unroll
@@ -534,21 +684,29 @@ __global__ __launch_bounds__(256 * SPLIT) void attn_kernel(const T* __restrict__
                 }
             }
         }
+    }  // tile loop
 }
 
-template <typename T, int KVB, int DH, int SPLIT, bool HS = false>
+template <typename T, int KVB, int DH, int SPLIT, bool HS = false, int QS = 1>
 static int launch_attn_t(const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, float scale,
                          hipStream_t stream) {
     constexpr int DP = 96;
-    const size_t lds = SPLIT * 2 * (size_t)(DP / 16 * KVB * 2 * 8 * sizeof(T) + DP * 128);
-    auto kern = attn_kernel<T, DP, KVB, DH, SPLIT, HS>;
+    const int ntiles = (S / (128 * QS)) * H * B;
+    // query-split form: persistent workgroups (one 8-wave workgroup per CU) that walk the tiles with the next tile's operands
+    // prefetched across the seam; the Q staging buffer sits behind the tile rings
+    static const int persist_env = getenv("L4P_ATTN_PERSIST") ? atoi(getenv("L4P_ATTN_PERSIST")) : 1;
+    const bool persist = SPLIT == 1 && QS > 1 && persist_env && S / KVB >= 4 && (S / KVB) % 2 == 0;  // (the kernel's PERSIST)
+    const int slots = 256;  // one 8-wave workgroup per CU (250 registers: two waves per SIMD)
+    const int grid = persist && ntiles > slots ? slots : ntiles;
+    const size_t lds = SPLIT * 2 * (size_t)(DP / 16 * KVB * 2 * 8 * sizeof(T) + DP * 128) + (QS > 1 ? (size_t)128 * QS * DP * sizeof(T) : 0);
+    auto kern = attn_kernel<T, DP, KVB, DH, SPLIT, HS, QS>;
     static std::atomic<unsigned long long> attr_done{0};
     HIP_TRY(lds_attr_once(attr_done, kern, (int)lds));
     // scale == 0 (L4P_ATTN_PRESCALED): q already carries head_dim^-0.5 * log2(e); the kernels then multiply by exactly 1
     const float c_scale = scale > 0.f ? scale * 1.4426950408889634f : 1.0f;
     ProfScope prof(PROF_ATTENTION, stream);
-    hipLaunchKernelGGL(kern, dim3((S / 128) * H * B), dim3(256 * SPLIT), lds, stream, (const T*)q, (const T*)kt, (const T*)vt, (T*)out,
-                       S, H, c_scale);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * SPLIT * QS), lds, stream, (const T*)q, (const T*)kt, (const T*)vt, (T*)out,
+                       S, H, c_scale, ntiles);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -564,6 +722,9 @@ int launch_attention(int dtype, const void* q, const void* kt, const void* vt, v
     const bool split = (long long)(S / 128) * H * B < 512 && (S / 64) % 2 == 0;
     static const int variant = getenv("L4P_ATTN_VARIANT") ? atoi(getenv("L4P_ATTN_VARIANT")) : 0;  // tuning aid: 1 = compiler-scheduled body
     if (dtype == L4P_BF16 && variant != 1) {
+        // query split (8 waves share the K / V^T tiles): when the launch still fills the chip with 256-row workgroups, two per CU
+        const bool qsplit = !split && S % 256 == 0 && (long long)(S / 256) * H * B >= 512 && variant != 2;
+        if (Dh == 88 && qsplit) return launch_attn_t<bf16_t, 64, 88, 1, true, 2>(q, kt, vt, out, B, S, H, scale, stream);
         if (Dh == 88)
             return split ? launch_attn_t<bf16_t, 64, 88, 2, true>(q, kt, vt, out, B, S, H, scale, stream)
                          : launch_attn_t<bf16_t, 64, 88, 1, true>(q, kt, vt, out, B, S, H, scale, stream);
