@@ -704,7 +704,7 @@ __device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p
 // reading tile kt-1) -> issue tile kt+2 into the buffer tile kt-1 used -> MFMAs on tile kt.
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS, int STAGES = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
-    static_assert(STAGES == 2 || (STAGES == 3 && GLDS), "3-stage pipeline needs LDS-DMA staging");
+    static_assert(STAGES == 2 || (STAGES >= 3 && STAGES <= 5 && GLDS), "deeper pipelines need LDS-DMA staging");
     constexpr int NT = WM * WN * 64;
     constexpr int ES = sizeof(T);
     constexpr int BK = 128 / ES;   // 64 bf16 / 32 f32 per LDS row
@@ -917,9 +917,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     // split-K: this workgroup contracts k-tiles [kt0, kt1) only and leaves a float partial (see below)
     const int nsplit = p.splitk > 1 ? p.splitk : 1;
     const int kt0 = (int)((long long)nk * ksplit / nsplit), kt1 = (int)((long long)nk * (ksplit + 1) / nsplit);
-    if (STAGES == 3) {
-        issue_tile(kt0, 0);
-        if (kt0 + 1 < kt1) issue_tile(kt0 + 1, 1);
+    if (STAGES >= 3) {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (kt0 + s < kt1) issue_tile(kt0 + s, s);
     } else if (GLDS) {
         issue_tile(kt0, 0);
         __syncthreads();
@@ -930,14 +931,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     }
 
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = STAGES == 3 ? (kt - kt0) % 3 : (kt - kt0) & 1;
-        if (STAGES == 3) {
-            if (kt + 1 < kt1)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + W_IT) : "memory");  // tile kt landed, tile kt+1 may fly
+        const int cur = STAGES >= 3 ? (kt - kt0) % STAGES : (kt - kt0) & 1;
+        if (STAGES >= 3) {
+            // tile kt has landed once only the tiles issued after it (at most STAGES - 2 of them) are still in flight
+            const int ahead = kt1 - 1 - kt < STAGES - 2 ? kt1 - 1 - kt : STAGES - 2;
+            if (ahead >= 3)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (A_IT + W_IT)) : "memory");
+            else if (ahead == 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_IT + W_IT)) : "memory");
+            else if (ahead == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + W_IT) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < kt1) issue_tile(kt + 2, (kt + 2 - kt0) % 3);
+            if (kt + STAGES - 1 < kt1) issue_tile(kt + STAGES - 1, (kt + STAGES - 1 - kt0) % STAGES);
         } else if (kt + 1 < kt1) {
 #ifndef GEMM_DBG_NOLOAD  // (tools/probes/gemm_variants.hip: ablation timing)
             if (GLDS)
