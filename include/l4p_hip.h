@@ -248,6 +248,14 @@ int l4p_similarity_apply(l4p_stream stream, const float* sim, float* pose, int T
 int l4p_layernorm_ex(l4p_stream stream, int dtype, const float* x, const float* gamma, const float* beta, float eps,
                      void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act);
 
+/* keys = LayerNorm(keys + attention output) (sam/transformer.py:183-185) with the sum formed in the LayerNorm: the row
+ * normalised is x[row % x_mod] (float; x_mod = 0: x[row]) + delta[row] (engine dtype, the out projection's result), outputs as
+ * l4p_layernorm_ex.  The float key stream is read once here instead of read + written by the projection's epilogue and read
+ * again; out_f32 may alias x when x_mod = 0. */
+int l4p_layernorm_res(l4p_stream stream, int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma,
+                      const float* beta, float eps, void* out_T, float* out_f32, int M, int C, const float* add, int add_mod,
+                      void* out_T2);
+
 /* The same LayerNorm (+ optional GELU) for rows that are STORED in the engine dtype: x_T, out_T are T [M][C] and may be the
  * same buffer.  Used for LayerNorm3d + GELU after the first up-scaling ConvTranspose (mask_decoder.py:60-62), whose 1M x 352
  * activation per clip is then never held in float (the reference holds it in fp16 under autocast).  L4P_F32: T = float. */

@@ -6,6 +6,8 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
                         hipStream_t stream);
 int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T, int M, int C,
                        int act, hipStream_t stream);
+int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
+                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, hipStream_t stream);
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
@@ -31,6 +33,10 @@ int launch_track_commit(const float* w_traj, const float* w_vis, const float* w_
 
 extern "C" {
 
+int l4p_layernorm_res(l4p_stream s, int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta,
+                      float eps, void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2) {
+    return launch_layernorm_res(dtype, x, x_mod, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, (hipStream_t)s);
+}
 int l4p_layernorm_ex(l4p_stream s, int dtype, const float* x, const float* gamma, const float* beta, float eps,
                      void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act) {
     return launch_layernorm_ex(dtype, x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, (hipStream_t)s);

@@ -18,6 +18,8 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
                         hipStream_t stream);
 int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T, int M, int C,
                        int act, hipStream_t stream);
+int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
+                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, hipStream_t stream);
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
@@ -241,19 +243,25 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
             void* iv = c.proj(qT, 6ll * N, Cc, lo + "i2t.v", Dh);
             void* ia = c.T(NP, Dh);
             c.attn(shared ? 4 : 2, iq, ik, iv, ia, N, P, Dh, g.sam_heads);
-            if (shared) {  // from here on every track owns its keys: residual = the common key set, row m % P
-                c.gemm(ia, NP, Dh, Dh, lo + "i2t.out", Cc, true, ACT_NONE, cur32, P, k32, nullptr, Cc);
+            // keys = norm4(keys + out_proj(attention)): the projection leaves its result in the engine dtype and the LayerNorm
+            // forms the sum (l4p_layernorm_res): the float key stream is read once per layer instead of read + written by the
+            // projection's epilogue and read again (1.48 GB per launch at 64 tracks; that GEMM was two serial phases, MFMA then
+            // HBM).  While the keys are still common to all tracks the float residual is row m % P of the common set.
+            void* delta = c.T(NP, Cc);
+            c.gemm(ia, NP, Dh, Dh, lo + "i2t.out", Cc, true, ACT_NONE, nullptr, 0, nullptr, delta, Cc);
+            // (after the last layer nothing adds to the float keys any more: only the T copies are written)
+            float* o32 = l + 1 < g.sam_depth ? k32 : nullptr;
+            if (!c.rc && !c.dry)
+                c.rc = launch_layernorm_res(c.dt, cur32, shared ? P : 0, delta, c.Wf(lo + "norm4.g"), c.Wf(lo + "norm4.b"), 1e-5f, kT, o32,
+                                            (int)NP, Cc, pos, P, kP, c.st);
+            if (shared) {  // from here on every track owns its keys
                 Nk = N;
-                cur32 = k32;
                 curT = kT;
                 curP = kP;
-            } else {
-                c.gemm(ia, NP, Dh, Dh, lo + "i2t.out", Cc, true, ACT_NONE, cur32, 0, cur32, nullptr, Cc);
             }
+            cur32 = k32;
         }
         c.ws.off = mark;
-        // (after the last layer nothing adds to the float keys any more: only the T copies are written)
-        c.ln(cur32, lo + "norm4", 1e-5f, curT, l + 1 < g.sam_depth ? cur32 : nullptr, NP, Cc, pos, P, curP, ACT_NONE);
     }
     // --- final tokens -> image attention (transformer.py:103-109) ---
     size_t mark = c.ws.off;

@@ -15,10 +15,14 @@
 // ROWS: rows per wave (all requested before the first is reduced).  Measured on the 1M x 352 LayerNorm + GELU of the tracker:
 // 1 row 556 us, 2 rows 696 us, 4 rows 889 us - that launch is VALU-bound (GELU on 369 M elements), not latency-bound, and
 // more rows only add register pressure; every launcher uses ROWS = 1.
-template <typename T, int MAXV, bool XT = false, int ROWS = 1>
+// RES: the row normalised is x[row % x_mod] + delta[row] (delta in the engine dtype): the tracker's "keys += attention
+// output; keys = LayerNorm(keys)" (sam/transformer.py:183-185) with the sum formed HERE instead of in the projection's
+// epilogue - the float key stream is read once by this kernel instead of read + written by the GEMM and read again.
+template <typename T, int MAXV, bool XT = false, int ROWS = 1, bool RES = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, T* out_T, float* out_f32, int M,
-                                                        int C, const float* __restrict__ add, int add_mod, T* out_T2, int act) {
+                                                        int C, const float* __restrict__ add, int add_mod, T* out_T2, int act,
+                                                        const T* __restrict__ delta = nullptr, int x_mod = 0) {
     // (x and the outputs are NOT restrict-qualified: the tracker normalises its key stream and the up-scaled activation in
     //  place; a wave has its whole row in registers - every store depends on the row statistics - before it writes)
     const int lane = threadIdx.x & 63;
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int row = row0 + r < M ? row0 + r : M - 1;  // (a clamped duplicate row is loaded but never stored)
-        const f32x4* xr = (const f32x4*)(x + (long long)row * C);
+        const f32x4* xr = (const f32x4*)(x + (long long)(RES && x_mod > 0 ? row % x_mod : row) * C);
         const f32x4* ar = out_T2 ? (const f32x4*)(add + (long long)(row % add_mod) * C) : nullptr;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
@@ -44,6 +48,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                 for (int k = 0; k < 4; ++k) v[r][i][k] = in ? (float)t[k] : 0.f;
             } else {
                 v[r][i] = in ? xr[idx] : z;
+            }
+            if constexpr (RES) {
+                if (sizeof(T) == 2) {
+                    const bf16x4 t = ((const bf16x4*)((const bf16_t*)delta + (long long)row * C))[in ? idx : 0];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[r][i][k] += in ? (float)t[k] : 0.f;
+                } else {
+                    const f32x4 t = ((const f32x4*)((const float*)delta + (long long)row * C))[in ? idx : 0];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[r][i][k] += in ? t[k] : 0.f;
+                }
             }
             av[r][i] = (in && ar) ? ar[idx] : z;
         }
@@ -145,6 +160,34 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
         launch_ln<bf16_t>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
     else
         launch_ln<float>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// y = LayerNorm(x[row % x_mod] + delta[row]) with the tracker's outputs (see layernorm_kernel RES)
+int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
+                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, hipStream_t stream) {
+    if (C % 4 || C > 1536 || !delta_T || (out_T2 && (!add || add_mod <= 0))) {
+        l4p_set_error("layernorm_res: C=%d must be a multiple of 4 and <= 1536, delta must be given (and out_T2 needs add/add_mod)", C);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d res T2%d f32%d", M, C, out_T2 != nullptr, out_f32 != nullptr);
+    const dim3 grid((M + 3) / 4);
+    if (dtype == L4P_BF16) {
+        if (C <= 512)
+            hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod);
+        else
+            hipLaunchKernelGGL((layernorm_kernel<bf16_t, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod);
+    } else {
+        if (C <= 512)
+            hipLaunchKernelGGL((layernorm_kernel<float, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod);
+        else
+            hipLaunchKernelGGL((layernorm_kernel<float, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -213,22 +213,23 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             _lib.check(lib.l4p_small_attn(_stream(), dt, 4 if shared else 2, _p(iq), _p(ik), _p(iv), _p(ia), N, P, Dh,
                                           cfg.sam_heads), "l4p_small_attn")
             del iq
-            if shared:  # from here on every track owns its keys: residual = the common key set, row m % P
-                k_common = k32
+            # keys = norm4(keys + out_proj(attention)): the projection leaves its result in the engine dtype, the LayerNorm forms
+            # the sum (l4p_layernorm_res; csrc/api_trackwin.hip has the same sequence).  While the keys are still common to all
+            # tracks the float residual is row m % P of the common set; from here on every track owns its keys.
+            delta = torch.empty((N * P, Cc), dtype=td, device=dev)
+            _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), out_T=delta)
+            del ia
+            k_res = k32
+            if shared:
                 k32 = torch.empty((N * P, Cc), **f32)
                 kT = torch.empty((N * P, Cc), dtype=td, device=dev)
                 kP = torch.empty((N * P, Cc), dtype=td, device=dev)
-                _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), res1=k_common,
-                      out_f32=k32, res_mod=P)
                 Nk = N
-                del k_common
-            else:
-                _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), res1=k32, out_f32=k32)
-            del ia
             # (after the last layer nothing adds to the float keys any more: only the T copies are written)
-            _lib.check(lib.l4p_layernorm_ex(_stream(), dt, _p(k32), _p(self._w(lo + "norm4.g")), _p(self._w(lo + "norm4.b")),
-                                            1e-5, _p(kT), _p(k32) if l + 1 < cfg.sam_depth else None, N * P, Cc, _p(pos), P,
-                                            _p(kP), ACT_NONE), "l4p_layernorm_ex")
+            _lib.check(lib.l4p_layernorm_res(_stream(), dt, _p(k_res), P if shared else 0, _p(delta), _p(self._w(lo + "norm4.g")),
+                                             _p(self._w(lo + "norm4.b")), 1e-5, _p(kT), _p(k32) if l + 1 < cfg.sam_depth else None,
+                                             N * P, Cc, _p(pos), P, _p(kP)), "l4p_layernorm_res")
+            del delta, k_res
         # --- final tokens -> image attention (transformer.py:103-109) ---
         fq = self._proj(qP, "final.q", Dh)
         fk = self._proj(kP, "final.k", Dh)
