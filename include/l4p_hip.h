@@ -135,6 +135,12 @@ typedef struct l4p_gemm_desc {
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
+/* n <= L4P_GEMM_GROUP_MAX INDEPENDENT dense GEMMs (no output of one is an input of another).  Equal to n l4p_gemm calls,
+ * bit for bit; small bf16 problems run as ONE kernel launch (the tracker's token-side projections, sam/transformer.py:159-185:
+ * q / k / v of the self-attention, k / v of the image -> token attention, the hyper-network MLP stages of the three mask
+ * tokens, mask_decoder.py:130-133), anything else as separate launches. */
+#define L4P_GEMM_GROUP_MAX 4
+int l4p_gemm_group(l4p_stream stream, int dtype, const l4p_gemm_desc* d, int n);
 int l4p_conv3d_k3(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
 
 /* Row LayerNorm of a float [M][C] stream -> T and/or float.  Replaces nn.LayerNorm

@@ -33,6 +33,13 @@ int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d) {
     }
     return launch_gemm(dtype, 0, *d, (hipStream_t)stream);
 }
+int l4p_gemm_group(l4p_stream stream, int dtype, const l4p_gemm_desc* d, int n) {
+    if (!d) {
+        l4p_set_error("l4p_gemm_group: null descriptors");
+        return L4P_E_INVALID;
+    }
+    return launch_gemm_group(dtype, d, n, (hipStream_t)stream);
+}
 int l4p_conv3d_k3(l4p_stream stream, int dtype, const l4p_gemm_desc* d) {
     if (!d) {
         l4p_set_error("l4p_conv3d_k3: null descriptor");

@@ -82,8 +82,19 @@ struct TW {
     void gemm(const void* a, long long M, int K, long long lda, const std::string& wk, int n, bool bias, int act, const float* res1,
               int res_mod, float* out_f32, void* out_T, long long ldc, const int* a_map = nullptr, const int* c_map = nullptr) {
         if (rc || dry) return;
+        GemmParams p = desc(a, M, K, lda, wk, n, bias, act, res1, res_mod, out_f32, out_T, ldc, a_map, c_map);
+        if (!rc) rc = launch_gemm(dt, 0, p, st);
+    }
+    // several INDEPENDENT projections as one launch (l4p_gemm_group: bit-identical to separate launches)
+    void group(const GemmParams* d, int n) {
+        if (rc || dry) return;
+        rc = launch_gemm_group(dt, d, n, st);
+    }
+    GemmParams desc(const void* a, long long M, int K, long long lda, const std::string& wk, int n, bool bias, int act, const float* res1,
+                    int res_mod, float* out_f32, void* out_T, long long ldc, const int* a_map = nullptr, const int* c_map = nullptr) {
         GemmParams p;
         memset(&p, 0, sizeof(p));
+        if (dry) return p;
         p.A = a;
         p.lda = lda;
         p.W = W(wk + ".w");
@@ -113,7 +124,7 @@ struct TW {
             p.c_gs = c_map[1];
             p.c_go = c_map[2];
         }
-        if (!rc) rc = launch_gemm(dt, 0, p, st);
+        return p;
     }
     // x[M][K] T -> new T [M][n] = act(x W^T + b)
     void* proj(const void* x, long long M, int K, const std::string& wk, int n, int act = ACT_NONE) {
@@ -204,9 +215,12 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         // --- self attention of the prompt tokens (transformer.py:159-166) ---
         const size_t mark_self = c.ws.off;
         {
-            void* sq = c.proj(qP, 6ll * N, Cc, lo + "self.q", Cc);
-            void* sk = c.proj(qP, 6ll * N, Cc, lo + "self.k", Cc);
-            void* sv = c.proj(qT, 6ll * N, Cc, lo + "self.v", Cc);
+            void *sq = c.T(6ll * N, Cc), *sk = c.T(6ll * N, Cc), *sv = c.T(6ll * N, Cc);
+            const GemmParams qkv[3] = {
+                c.desc(qP, 6ll * N, Cc, Cc, lo + "self.q", Cc, true, ACT_NONE, nullptr, 0, nullptr, sq, Cc),
+                c.desc(qP, 6ll * N, Cc, Cc, lo + "self.k", Cc, true, ACT_NONE, nullptr, 0, nullptr, sk, Cc),
+                c.desc(qT, 6ll * N, Cc, Cc, lo + "self.v", Cc, true, ACT_NONE, nullptr, 0, nullptr, sv, Cc)};
+            c.group(qkv, 3);
             void* sa = c.T(6ll * N, Cc);
             c.attn(0, sq, sk, sv, sa, N, 6, Cc, g.sam_heads);
             c.gemm(sa, 6ll * N, Cc, Cc, lo + "self.out", Cc, true, ACT_NONE, q32, 0, x32, nullptr, Cc);
@@ -239,8 +253,10 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         {
             void* iq = half_shared && l == 0 ? proj_half_shared(curP, lo + "i2t.q", Dh)
                                              : c.proj(curP, (long long)Nk * P, Cc, lo + "i2t.q", Dh);
-            void* ik = c.proj(qP, 6ll * N, Cc, lo + "i2t.k", Dh);
-            void* iv = c.proj(qT, 6ll * N, Cc, lo + "i2t.v", Dh);
+            void *ik = c.T(6ll * N, Dh), *iv = c.T(6ll * N, Dh);
+            const GemmParams kv[2] = {c.desc(qP, 6ll * N, Cc, Cc, lo + "i2t.k", Dh, true, ACT_NONE, nullptr, 0, nullptr, ik, Dh),
+                                      c.desc(qT, 6ll * N, Cc, Cc, lo + "i2t.v", Dh, true, ACT_NONE, nullptr, 0, nullptr, iv, Dh)};
+            c.group(kv, 2);
             void* ia = c.T(NP, Dh);
             c.attn(shared ? 4 : 2, iq, ik, iv, ia, N, P, Dh, g.sam_heads);
             // keys = norm4(keys + out_proj(attention)): the projection leaves its result in the engine dtype and the LayerNorm
@@ -286,15 +302,24 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
             c.rc = L4P_E_HIP;
         }
     }
-    for (int i = 0; i < 3; ++i) {
-        const std::string hk = "hyper" + std::to_string(i);
-        void* h1 = c.T(N, Cc);
-        c.gemm((const char*)hsT + (size_t)i * Cc * c.es, N, Cc, 6ll * Cc, hk + ".0", Cc, true, ACT_RELU, nullptr, 0, nullptr, h1, Cc);
-        void* h2 = c.proj(h1, N, Cc, hk + ".1", Cc, ACT_RELU);
-        c.gemm(h2, N, Cc, Cc, hk + ".2", d1, true, ACT_NONE, nullptr, 0, c.dry ? nullptr : hyper + (size_t)i * d1p, nullptr, 3ll * d1p);
+    // (the three tokens' MLPs are independent: each stage of the three runs as one grouped launch; the prompt feature for the
+    //  next window (sparse_heads.py:650-658: io token 5) rides with the first stage)
+    {
+        void *h1[3], *h2[3];
+        GemmParams st0[4], st1[3], st2[3];
+        for (int i = 0; i < 3; ++i) {
+            const std::string hk = "hyper" + std::to_string(i);
+            h1[i] = c.T(N, Cc);
+            h2[i] = c.T(N, Cc);
+            st0[i] = c.desc((const char*)hsT + (size_t)i * Cc * c.es, N, Cc, 6ll * Cc, hk + ".0", Cc, true, ACT_RELU, nullptr, 0, nullptr, h1[i], Cc);
+            st1[i] = c.desc(h1[i], N, Cc, Cc, hk + ".1", Cc, true, ACT_RELU, nullptr, 0, nullptr, h2[i], Cc);
+            st2[i] = c.desc(h2[i], N, Cc, Cc, hk + ".2", d1, true, ACT_NONE, nullptr, 0, c.dry ? nullptr : hyper + (size_t)i * d1p, nullptr, 3ll * d1p);
+        }
+        st0[3] = c.desc((const char*)hsT + (size_t)5 * Cc * c.es, N, Cc, 6ll * Cc, "prompt_lin", Cc, true, ACT_NONE, nullptr, 0, new_pfeat, nullptr, Cc);
+        c.group(st0, 4);
+        c.group(st1, 3);
+        c.group(st2, 3);
     }
-    // prompt feature for the next window (sparse_heads.py:650-658): io token 5
-    c.gemm((const char*)hsT + (size_t)5 * Cc * c.es, N, Cc, 6ll * Cc, "prompt_lin", Cc, true, ACT_NONE, nullptr, 0, new_pfeat, nullptr, Cc);
 
     // --- memory tokens for the next window (sparse_heads.py:406-448,660-665): project the 2nd temporal half of the
     //     processed video tokens into the 1st half of the history, pad the rest with the learned mask token ---

@@ -18,3 +18,25 @@ int launch_gemm(int dtype, int mode, const GemmParams& p, hipStream_t stream) {
     }
     return dtype == L4P_BF16 ? launch_gemm_bf16(mode, p, stream) : launch_gemm_f32(mode, p, stream);
 }
+
+int launch_gemm_group_bf16(const GemmParams* p, int n, hipStream_t stream);
+int launch_gemm_group(int dtype, const GemmParams* p, int n, hipStream_t stream) {
+    if (!p || n < 1 || n > L4P_GEMM_GROUP_MAX) {
+        l4p_set_error("gemm_group: 1 <= n <= %d descriptors", L4P_GEMM_GROUP_MAX);
+        return L4P_E_INVALID;
+    }
+    if (dtype == L4P_BF16) {
+        for (int i = 0; i < n; ++i) {  // the checks of launch_gemm that the fast path would skip
+            if (p[i].M <= 0 || p[i].N <= 0 || p[i].K <= 0 || p[i].N % 8 || (p[i].K * 2) % 16 || (p[i].ldw * 2) % 16 || (p[i].lda * 2) % 16 ||
+                p[i].splitk > 1)
+                goto one_by_one;
+        }
+        return launch_gemm_group_bf16(p, n, stream);
+    }
+one_by_one:
+    for (int i = 0; i < n; ++i) {
+        const int rc = launch_gemm(dtype, 0, p[i], stream);
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -702,8 +702,10 @@ __device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p
 // tile) followed by a raw s_barrier, so the next tile's DMA is not drained at the barrier (a __syncthreads() would emit
 // vmcnt(0)).  Order per iteration: wait(own loads of tile kt) -> barrier (everyone's tile kt landed, everyone finished
 // reading tile kt-1) -> issue tile kt+2 into the buffer tile kt-1 used -> MFMAs on tile kt.
+// (the kernel body is a device function of (descriptor, workgroup index): gemm_kernel runs it for one problem,
+//  gemm_group_kernel for up to four problems in ONE launch, see below)
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS, int STAGES = 2>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int wg_index) {
     static_assert(STAGES == 2 || (STAGES >= 3 && STAGES <= 5 && GLDS), "deeper pipelines need LDS-DMA staging");
     constexpr int NT = WM * WN * 64;
     constexpr int ES = sizeof(T);
@@ -724,8 +726,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = (p.N + BN - 1) / BN;
     const int ntiles = ntn * ((p.M + BM - 1) / BM);
-    const int ksplit = blockIdx.x / ntiles;  // split-K slice of this workgroup
-    int tile = blockIdx.x - ksplit * ntiles;
+    const int ksplit = wg_index / ntiles;  // split-K slice of this workgroup
+    int tile = wg_index - ksplit * ntiles;
     if (MODE == 1 && p.splitk <= 1) {  // conv: XCD-contiguous tile ranges (workgroup b runs on XCD b % 8)
         const int xcd = tile & 7, idx = tile >> 3, q = ntiles >> 3, r = ntiles & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -1061,5 +1063,34 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     gemm_epilogue<T, TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), li, kg);
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS, int STAGES = 2>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+    gemm_body<T, BM, BN, WM, WN, MODE, GLDS, STAGES>(p, (int)blockIdx.x);
+}
+
+// Up to L4P_GEMM_GROUP_MAX independent dense GEMMs as ONE launch: workgroups [first[g], first[g + 1]) run problem g.  For the
+// tracker's token-side projections (self-attention q / k / v, image -> token k / v, the three hyper-network MLP stages): each is
+// a 20 us launch that fills a quarter of the chip, and they come in independent groups of two or three.
+struct GemmGroupParams {
+    GemmParams p[L4P_GEMM_GROUP_MAX];
+    int first[L4P_GEMM_GROUP_MAX + 1];
+};
+template <typename T, int BM, int BN, int WM, int WN, bool GLDS, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_group_kernel(const GemmGroupParams g) {
+    const int b = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < L4P_GEMM_GROUP_MAX; ++k)
+        if (b >= g.first[k]) i = k;
+    // (a uniform switch keeps the descriptor accesses static: kernel arguments are read through scalar loads)
+    switch (i) {
+        case 0: gemm_body<T, BM, BN, WM, WN, 0, GLDS, STAGES>(g.p[0], b - g.first[0]); break;
+        case 1: gemm_body<T, BM, BN, WM, WN, 0, GLDS, STAGES>(g.p[1], b - g.first[1]); break;
+        case 2: gemm_body<T, BM, BN, WM, WN, 0, GLDS, STAGES>(g.p[2], b - g.first[2]); break;
+        default: gemm_body<T, BM, BN, WM, WN, 0, GLDS, STAGES>(g.p[3], b - g.first[3]); break;
+    }
+}
+
 // host launcher (gemm.hip)
 int launch_gemm(int dtype, int mode, const GemmParams& p, hipStream_t stream);
+int launch_gemm_group(int dtype, const GemmParams* p, int n, hipStream_t stream);

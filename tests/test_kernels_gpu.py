@@ -335,3 +335,68 @@ def test_maskdot_fused_upscaling(dev, mode, Nq, T, h, w, Cin, d1):
     # bf16 mode: the fused path keeps the activation in float (the unfused engine path rounds it to bf16), so it is the
     # more accurate of the two; the bf16 GELU is the A&S erfc form (1.5e-7 absolute)
     check(masks, ref, mode, False)
+
+
+def test_gemm_group_equals_separate_launches(dev):
+    """l4p_gemm_group: up to four INDEPENDENT small bf16 GEMMs as one kernel launch (the tracker's token-side projections:
+    q / k / v of the self-attention, M = 6 x tracks rows; hyper-network stages with strided A rows and a float output) —
+    bit-identical to separate l4p_gemm calls; one profiler entry tagged "group"; a member that does not fit the small-problem
+    kernel (here: a large M) makes the call fall back to separate launches."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+    from l4p_amd._lib import EPI_DENSE, GemmDesc
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    M, K = 384, 1408
+    xs = [as_mode(rnd((M, K), 300 + i), L4P_BF16)[0] for i in range(2)]
+    hs = as_mode(rnd((64, 6 * K), 310), L4P_BF16)[0]                       # hyper-network input: token i of a [64, 6, K] block
+    ws = [ops.pad_rows(as_mode(rnd((n, K), 320 + i, K ** -0.5), L4P_BF16)[0], 128) for i, n in enumerate((1408, 1408, 704, 176))]
+    bs = [rnd((n,), 330 + i).cuda() for i, n in enumerate((1408, 1408, 704, 176))]
+
+    def descs(outs):
+        ds = (GemmDesc * 4)()
+        spec = [(xs[0], M, K, 1408, ACT_NONE), (xs[0], M, K, 1408, ACT_RELU), (xs[1], M, K, 704, ACT_NONE), (hs, 64, 6 * K, 176, ACT_NONE)]
+        for i, (a, m, lda, n, act) in enumerate(spec):
+            d = ds[i]
+            d.A, d.lda, d.W, d.ldw = a.data_ptr() + (2 * K * 2 if i == 3 else 0), lda, ws[i].data_ptr(), K
+            d.M, d.N, d.K = m, n, K
+            d.bias, d.act, d.epi = bs[i].data_ptr(), act, EPI_DENSE
+            if i == 3:
+                d.out_f32, d.ldc = outs[i].data_ptr(), n
+            else:
+                d.out_T, d.ldc = outs[i].data_ptr(), n
+        return ds
+
+    def outs():
+        return [torch.zeros(384, 1408, dtype=torch.bfloat16, device="cuda"), torch.zeros(384, 1408, dtype=torch.bfloat16, device="cuda"),
+                torch.zeros(384, 704, dtype=torch.bfloat16, device="cuda"), torch.zeros(64, 176, dtype=torch.float32, device="cuda")]
+
+    a, b = outs(), outs()
+    da, db = descs(a), descs(b)
+    from tests.test_gemm8p_gpu import prof_tags
+    with prof_tags() as p:
+        _lib.check(lib.l4p_gemm_group(st, L4P_BF16, da, 4), "l4p_gemm_group")
+    tags = [ln[1] for ln in p.lines if ln[0] == "gemm"]
+    assert len(tags) == 1 and tags[0].startswith("group of 4"), tags
+    for i in range(4):
+        _lib.check(lib.l4p_gemm(st, L4P_BF16, C.byref(db[i])), "l4p_gemm")
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    ref = hs.float().cpu().reshape(64, 6, K)[:, 2] @ ws[3][:176].float().cpu().t() + bs[3].cpu()
+    check(a[3], ref, L4P_BF16, False)
+    # a large member: the group falls back to separate launches (still correct)
+    big = as_mode(rnd((65536, K), 340), L4P_BF16)[0]
+    ob = torch.zeros(65536, 1408, dtype=torch.bfloat16, device="cuda")
+    ds = (GemmDesc * 2)()
+    for i, (aa, m, o) in enumerate(((big, 65536, ob), (xs[0], M, a[0]))):
+        ds[i].A, ds[i].lda, ds[i].W, ds[i].ldw = aa.data_ptr(), K, ws[0].data_ptr(), K
+        ds[i].M, ds[i].N, ds[i].K = m, 1408, K
+        ds[i].bias, ds[i].epi, ds[i].out_T, ds[i].ldc = bs[0].data_ptr(), EPI_DENSE, o.data_ptr(), 1408
+    with prof_tags() as p:
+        _lib.check(lib.l4p_gemm_group(st, L4P_BF16, ds, 2), "l4p_gemm_group")
+    assert len([ln for ln in p.lines if ln[0] == "gemm"]) == 2
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ob.float()).all()) and float(ob.float().abs().max()) > 0
