@@ -209,6 +209,15 @@ int l4p_rays_to_pose(l4p_stream stream, const float* rays, const float* K, float
 int l4p_rays_to_intrinsics(l4p_stream stream, const float* rays, float* out_K, float* diag, int B, int T, int h, int w,
                            int H, int W, int t0, float reproj_thr);
 
+/* The per-frame VARIABLE intrinsics branch (fixed_intrinsics = False: rays_to_cameras_and_variable_per_frame_intrinsics,
+ * geometry_utils.py:582-654; reached from dense_heads.py:336-344): the same estimator run on EVERY frame's ray map:
+ * out_K float [B][4][4][T] = frame t's own K; out_R float [B][9][T] = the rotation R of H^-1 = K R (row-major), which that
+ * branch uses as the camera rotation as it is (no Kabsch step); diag optional float [B*T][2].  l4p_rays_to_pose_rot then
+ * gives world_T_cam = [R^T | c] with the camera centre c solved from the rays (intersect_skew_lines_high_dim, :249-282). */
+int l4p_rays_to_intrinsics_frames(l4p_stream stream, const float* rays, float* out_K, float* out_R, float* diag, int B, int T,
+                                  int h, int w, int H, int W, float reproj_thr);
+int l4p_rays_to_pose_rot(l4p_stream stream, const float* rays, const float* R, float* out, int B, int T, int h, int w);
+
 /* ------------------------------------------------------------------------------------------------
  * Joint depth + camera seam alignment (KabaschUmeyama3DAligner, aligner.py:121-265;
  * generate_point_map, geometry_utils.py:13-53).  The reference runs numpy + skimage.measure.ransac on

@@ -102,6 +102,8 @@ SIGNATURES = {
     "l4p_affine_align_apply": (_I, [_VP, _VP, _VP, _LL, _I, _VP]),
     "l4p_rays_to_pose": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I]),
     "l4p_rays_to_intrinsics": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "l4p_rays_to_intrinsics_frames": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _F]),
+    "l4p_rays_to_pose_rot": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I]),
     "l4p_quantile": (_I, [_VP, _VP, _LL, _F, _VP, _VP]),
     "l4p_select_rank": (_I, [_VP, _VP, _LL, _LL, _VP, _VP]),
     "l4p_ratio_median_solve": (_I, [_VP, _VP, _VP, _LL, _I, _VP, _VP, _VP]),

@@ -83,6 +83,9 @@ int l4p_rays_to_pose(l4p_stream stream, const float* rays, const float* K, float
                      int H, int W) {
     return launch_rays_to_pose(rays, K, out, B, T, h, w, H, W, (hipStream_t)stream);
 }
+int l4p_rays_to_pose_rot(l4p_stream stream, const float* rays, const float* R, float* out, int B, int T, int h, int w) {
+    return launch_rays_to_pose_rot(rays, R, out, B, T, h, w, (hipStream_t)stream);
+}
 
 // ---------------------------------------------------------------------------------------------
 // engine

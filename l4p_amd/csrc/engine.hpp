@@ -38,5 +38,6 @@ int launch_head_out(int dtype, const void* x, const float* w, const float* bias,
 int launch_affine_solve(const float* pred, const float* tgt, long long n, int inverse, double* scratch, float* sol,
                         hipStream_t stream);
 int launch_affine_apply(const float* x, float* y, long long n, int inverse, const float* sol, hipStream_t stream);
+int launch_rays_to_pose_rot(const float* rays, const float* R, float* out, int B, int T, int h, int w, hipStream_t stream);
 int launch_rays_to_pose(const float* rays, const float* K, float* out, int B, int T, int h, int w, int H, int W,
                         hipStream_t stream);

@@ -142,14 +142,18 @@ __device__ void jacobi_eig3(double A[3][3], double V[3][3]) {
     }
 }
 
+// R_in (optional, [B][9][T] row-major): the rotation is GIVEN (the per-frame variable-intrinsics branch takes it from the RQ
+// decomposition, geometry_utils.py:636-644) - only the camera centre is solved here; K is then unused.
 __global__ __launch_bounds__(256) void rays_to_pose_kernel(const float* __restrict__ rays, const float* __restrict__ K,
                                                            float* __restrict__ out, int B, int T, int h, int w, int H,
-                                                           int W) {
+                                                           int W, const float* __restrict__ R_in) {
     const int bt = blockIdx.x, b = bt / T, t = bt % T;
     const int r = threadIdx.x, nr = h * w;
     __shared__ double red[4][24];
     __shared__ double Kinv[9];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && R_in) {
+        for (int i = 0; i < 9; ++i) Kinv[i] = i % 4 == 0 ? 1.0 : 0.0;  // (unused: the Kabsch sums are ignored below)
+    } else if (threadIdx.x == 0) {
         // K' = denormalize(normalize(K, H, W), h, w), upper-left 3x3; then invert
         double k[3][3];
         for (int i = 0; i < 3; ++i)
@@ -256,6 +260,9 @@ __global__ __launch_bounds__(256) void rays_to_pose_kernel(const float* __restri
     double R[3][3];  // R = Rpre^T, Rpre[i][j] = sum_k u_k[i] v_k[j]
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) R[j][i] = u1[i] * v1[j] + u2[i] * v2[j] + u3[i] * v3[j];
+    if (R_in)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[i][j] = R_in[((long long)b * 9 + i * 3 + j) * T + t];
     // world_T_cam = inv([R | -R c]) = [R^T | c]
     float* op = out + (long long)b * 16 * T + t;
     for (int i = 0; i < 3; ++i) {
@@ -277,7 +284,17 @@ int launch_rays_to_pose(const float* rays, const float* K, float* out, int B, in
         return L4P_E_INVALID;
     }
     ProfScope prof(PROF_ELEMENTWISE, stream, "rays_to_pose");
-    hipLaunchKernelGGL(rays_to_pose_kernel, dim3(B * T), dim3(256), 0, stream, rays, K, out, B, T, h, w, H, W);
+    hipLaunchKernelGGL(rays_to_pose_kernel, dim3(B * T), dim3(256), 0, stream, rays, K, out, B, T, h, w, H, W, (const float*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_rays_to_pose_rot(const float* rays, const float* R, float* out, int B, int T, int h, int w, hipStream_t stream) {
+    if (h * w > 256 || !R) {
+        l4p_set_error("rays_to_pose_rot: ray map %dx%d larger than 256 rays per frame, or no rotations", h, w);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_ELEMENTWISE, stream, "rays_to_pose_rot");
+    hipLaunchKernelGGL(rays_to_pose_kernel, dim3(B * T), dim3(256), 0, stream, rays, (const float*)nullptr, out, B, T, h, w, 1, 1, R);
     HIP_TRY(hipGetLastError());
     return 0;
 }

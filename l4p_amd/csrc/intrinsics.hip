@@ -87,10 +87,16 @@ __device__ void mul3(const double* a, const double* b, double* o) {
 
 // one workgroup per batch item; rays [B][6][T][h*w]; frame t0; out_K: [B][4][4][T] pixel-unit intrinsics of an H x W image
 // (the same K for every frame: "fixed" intrinsics), diag: [B][2] = (consensus size, iterations used)
+// per_frame (the reference's fixed_intrinsics = False branch, geometry_utils.py:582-654): grid (B, T), workgroup (b, t) estimates
+// frame t's own K and writes it to frame t only, together with the rotation R of H^-1 = K R (out_R [B][9][T], row-major), which
+// that branch uses as the camera rotation directly.  The minimal samples are hashed from the item index b * T + t.
 __global__ __launch_bounds__(256) void rays_to_intrinsics_kernel(const float* __restrict__ rays, float* __restrict__ out_K,
                                                                  float* __restrict__ diag, int T, int h, int w, int H, int W,
-                                                                 int t0, float thr, float z_thr) {
+                                                                 int t0_arg, float thr, float z_thr, float* __restrict__ out_R,
+                                                                 int per_frame) {
     const int b = blockIdx.x, r = threadIdx.x, nr = h * w;
+    const int t0 = per_frame ? (int)blockIdx.y : t0_arg;
+    const int item = per_frame ? b * T + t0 : b;
     __shared__ double red[4][48];
     __shared__ double Hs[9];
     __shared__ double nrm[8];  // src: mx,my,s ; dst: mx,my,s ; count
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void rays_to_intrinsics_kernel(const float* __
         int idx[4];
         bool ok = true;
         for (int k = 0; k < 4; ++k) {
-            unsigned hsh = (unsigned)(b * 131 + r) * 2654435761u + 40503u * (unsigned)k;
+            unsigned hsh = (unsigned)(item * 131 + r) * 2654435761u + 40503u * (unsigned)k;
             hsh ^= hsh >> 15;
             hsh *= 2246822519u;
             hsh ^= hsh >> 13;
@@ -334,7 +340,13 @@ __global__ __launch_bounds__(256) void rays_to_intrinsics_kernel(const float* __
     for (int i = 0; i < 3; ++i) t0v[i] = m0[i] - K[2] * q2[i] - K[1] * q1[i];
     K[0] = sqrt(t0v[0] * t0v[0] + t0v[1] * t0v[1] + t0v[2] * t0v[2]);
     for (int i = 0; i < 3; ++i) q0[i] = t0v[i] / K[0];
-    (void)q0;
+    if (out_R) {  // H^-1 = K R with a positive diagonal of K: the rows of R
+        for (int j = 0; j < 3; ++j) {
+            out_R[((long long)b * 9 + 0 + j) * T + t0] = (float)q0[j];
+            out_R[((long long)b * 9 + 3 + j) * T + t0] = (float)q1[j];
+            out_R[((long long)b * 9 + 6 + j) * T + t0] = (float)q2[j];
+        }
+    }
     for (int i = 0; i < 9; ++i) K[i] /= K[8];
     // ray-grid units -> pixel units of the H x W image: denormalize(normalize(K, h, w), H, W)  (geometry_utils.py:110-125,575-577)
     double Kp[16] = {0};
@@ -352,11 +364,15 @@ __global__ __launch_bounds__(256) void rays_to_intrinsics_kernel(const float* __
     Kp[0 * 4 + 2] -= 0.5;
     Kp[1 * 4 + 2] -= 0.5;
     Kp[15] = 1.0;
-    for (int k = 0; k < 16; ++k)
-        for (int t = 0; t < T; ++t) out_K[((long long)b * 16 + k) * T + t] = (float)Kp[k];
+    for (int k = 0; k < 16; ++k) {
+        if (per_frame)
+            out_K[((long long)b * 16 + k) * T + t0] = (float)Kp[k];
+        else
+            for (int t = 0; t < T; ++t) out_K[((long long)b * 16 + k) * T + t] = (float)Kp[k];
+    }
     if (diag) {
-        diag[b * 2] = (float)nrm[6];
-        diag[b * 2 + 1] = (float)iters;
+        diag[item * 2] = (float)nrm[6];
+        diag[item * 2 + 1] = (float)iters;
     }
 }
 
@@ -372,7 +388,23 @@ int l4p_rays_to_intrinsics(l4p_stream s_, const float* rays, float* out_K, float
     }
     ProfScope prof(PROF_ELEMENTWISE, s, "l4p_rays_to_intrinsics");
     hipLaunchKernelGGL(rays_to_intrinsics_kernel, dim3(B), dim3(256), 0, s, rays, out_K, diag, T, h, w, H, W, t0, reproj_thr,
-                       1e-4f);
+                       1e-4f, (float*)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+/* Per-frame variable intrinsics (rays_to_cameras_and_variable_per_frame_intrinsics, geometry_utils.py:582-654): every frame's own
+ * K (out_K [B][4][4][T], pixel units of the H x W image) and the rotation of H^-1 = K R (out_R [B][9][T], row-major), which
+ * that branch takes as the camera rotation; diag (optional): float [B*T][2]. */
+int l4p_rays_to_intrinsics_frames(l4p_stream s_, const float* rays, float* out_K, float* out_R, float* diag, int B, int T, int h,
+                                  int w, int H, int W, float reproj_thr) {
+    hipStream_t s = (hipStream_t)s_;
+    if (h * w > 256 || !out_K || !out_R) {
+        l4p_set_error("rays_to_intrinsics_frames: unsupported ray map %dx%d or null output", h, w);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_ELEMENTWISE, s, "l4p_rays_to_intrinsics_frames");
+    hipLaunchKernelGGL(rays_to_intrinsics_kernel, dim3(B, T), dim3(256), 0, s, rays, out_K, diag, T, h, w, H, W, 0, reproj_thr, 1e-4f,
+                       out_R, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -234,7 +234,11 @@ class VideoMAETraj3DDPTHead(VideoMAEFlowDPTHead):
                 raise ValueError("intrinsics_b44t is required when use_intrinsics=True")
             return {key: poses_from_rays(rays, intrinsics_b44t.to(rays.device, torch.float32), H, W)}
         if not self.fixed_intrinsics:
-            raise NotImplementedError("per-frame variable intrinsics (fixed_intrinsics=False) are not used by configs/model.yaml")
+            # per-frame intrinsics and extrinsics (dense_heads.py:336-344): every frame's own K, rotation from its RQ step
+            from ...utils.geometry_utils import cameras_from_rays_variable_intrinsics
+
+            pose, K_est = cameras_from_rays_variable_intrinsics(rays, H, W, reproj_threshold=0.2)
+            return {key: pose, f"{self.task_name}_intrinsics_est_{self.task_suffix}": K_est.reshape(K_est.shape[0], 16, T)}
         # fixed intrinsics, estimated once on the first window (dense_heads.py:303-334)
         assert "win_id" in kwargs, "win_id is required when setting fixed intrinsics as True"
         if kwargs["win_id"] == 0:

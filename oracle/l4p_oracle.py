@@ -305,6 +305,43 @@ def optimal_rotation_intrinsics(rays_origin: Tensor, rays_target: Tensor, find_h
     return torch.from_numpy(np.asarray(out[2])).float(), torch.from_numpy(K).float(), Hm
 
 
+def rays_to_cameras_variable_intrinsics(rays_b6thw: Tensor, output_size: Tuple[int, int], find_h=dlt_homography, rq=rq3,
+                                        estimate=None) -> Tuple[Tensor, Tensor]:
+    """rays_to_cameras_and_variable_per_frame_intrinsics geometry_utils.py:582-654 (ctr_only=False; reached from
+    dense_heads.py:336-344 when fixed_intrinsics=False): for EVERY frame, (R, K) = compute_optimal_rotation_intrinsics of the
+    identity-intrinsics rays against that frame's predicted directions - R is the rotation of the RQ step itself, no Kabsch -,
+    translation -R c from the ray intersection, K rescaled from the ray grid to ``output_size``.  ``estimate(b, t, rays_origin,
+    rays_target)`` -> (R 3x3, K 3x3 ray-grid) replaces the two third-party calls by another estimator (the engine's).
+    Returns (cam_T_world [B,4,4,T], K [B,4,4,T] in output pixels)."""
+    B, _, T, h, w = rays_b6thw.shape
+    rays = rays_b6thw.float()
+    origins, directions = plucker_to_point_direction(rays)
+    o = origins.permute(0, 2, 3, 4, 1).reshape(-1, h * w, 3)
+    d = directions.permute(0, 2, 3, 4, 1).reshape(-1, h * w, 3)
+    centers = intersect_skew_lines(o, d).reshape(B, T, 3)
+    j, i = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    pix = torch.stack([i, j, torch.ones_like(i)], dim=-1).reshape(-1, 3)
+    rd = pix / pix.norm(dim=-1, keepdim=True)  # rays of the identity intrinsics
+    E = torch.zeros(B, 4, 4, T)
+    E[:, 3, 3] = 1.0
+    Kest = torch.zeros_like(E)
+    Kest[:, 3, 3] = 1.0
+    Kest[:, 2, 2] = 1.0
+    for b in range(B):
+        for t in range(T):
+            tgt = directions[b, :, t].reshape(3, -1).T.float()
+            if estimate is not None:
+                R, K = estimate(b, t, rd, tgt)
+            else:
+                R, K, _ = optimal_rotation_intrinsics(rd, tgt, find_h, rq, reproj_threshold=0.2)
+            E[b, :3, :3, t] = torch.as_tensor(R).float()
+            Kest[b, :3, :3, t] = torch.as_tensor(K).float()
+    tr = -torch.matmul(E[:, :3, :3].permute(0, 3, 1, 2), centers[..., None]).squeeze(3)
+    E[:, :3, -1] = tr.permute(0, 2, 1)
+    Ho, Wo = output_size
+    return E, denormalize_intrinsics(normalize_intrinsics(Kest, h, w), Ho, Wo)
+
+
 # ---- the ENGINE's deterministic K estimator (csrc/intrinsics.hip rays_to_intrinsics_kernel), restated --------------------------
 # It stands where cv2's RANSAC draw stands in the reference, so it has no reference result to be compared with; restating
 # its schedule here makes a GPU estimate reproducible on the CPU at any geometry (tests/test_full_model_gpu.py compares the
@@ -389,7 +426,8 @@ def engine_rays_to_intrinsics(dirs_n3: np.ndarray, h: int, w: int, H: int, W: in
             break
         wgt = nw
     A = Hs if np.linalg.det(Hs) >= 0 else -Hs
-    _, K, _ = rq3(np.linalg.inv(A))
+    _, K, Rm = rq3(np.linalg.inv(A))
+    engine_rays_to_intrinsics.last_R = Rm  # rotation of H^-1 = K R (the per-frame variable branch uses it as the camera rotation)
     K = K / K[2, 2]
     K4 = np.eye(4)
     K4[:3, :3] = K
@@ -675,6 +713,8 @@ class OracleModel:
         # use_intrinsics=False (the shipped default): the two third-party calls of the K estimation (stand-ins pinned against
         # the reference, tools/gen_golden_intrinsics.py), or a supplied ray-grid K per batch item instead of an estimate
         self.find_h, self.rq, self.k_override = dlt_homography, rq3, None
+        self.fixed_intrinsics = True  # configs/model.yaml:45; False: every frame's own K (dense_heads.py:336-344)
+        self.frame_estimate = None    # fixed_intrinsics=False: estimator in place of the two cv2 calls (see rays_to_cameras_variable_intrinsics)
         self.first_window_K: Optional[Tensor] = None
         # actpost / fusion scale factors: dense_heads.py:30-31 and :269-271
         self._actpost = lambda t: ((1, 0, 0), (1, 0, 0), (0, 0, 0), (-1, -1, -1)) if t == "camray" else ((1, 2, 2), (1, 1, 1), (0, 0, 0), (-1, -1, -1))
@@ -696,6 +736,8 @@ class OracleModel:
             Kest = None
             if self.use_intrinsics:
                 E = rays_to_cameras(raw.float(), normalize_intrinsics(intrinsics_b44t, H, W).float())
+            elif not self.fixed_intrinsics:
+                E, Kest = rays_to_cameras_variable_intrinsics(raw.float(), (H, W), self.find_h, self.rq, self.frame_estimate)
             else:
                 # VideoMAETraj3DDPTHead.forward with use_intrinsics=False, fixed_intrinsics=True (dense_heads.py:303-334):
                 # K is estimated on the first window and reported for every later one, whose rotations use the INPUT K

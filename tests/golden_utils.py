@@ -75,3 +75,27 @@ def single_window_batch():
     b = make_batch(16, 6)
     b["track_2d_pointlabels_bn"] = torch.tensor([[1.0, 0.0, 2.0, 1.0, 2.0, 0.0]])
     return b
+
+
+def synthetic_rays(B=2, T=4, h=16, w=16, seed=5, noise=2e-3):
+    """Pluecker ray maps [B,6,T,h,w] of cameras with ONE ray-grid K per batch item, rotations / centres per frame."""
+    g = torch.Generator().manual_seed(seed)
+    Ks, rays = [], torch.zeros(B, 6, T, h, w)
+    j, i = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    pix = torch.stack([i, j, torch.ones_like(i)], dim=-1).reshape(-1, 3)
+    for b in range(B):
+        K = torch.tensor([[13.0 + b, 0.2, 7.3], [0.0, 14.5 - b, 7.9], [0.0, 0.0, 1.0]])
+        Ks.append(K)
+        for t in range(T):
+            R = torch.linalg.qr(torch.eye(3) + 0.15 * torch.randn(3, 3, generator=g)).Q
+            if torch.linalg.det(R) < 0:
+                R = -R
+            c = torch.randn(3, generator=g)
+            d_cam = (torch.inverse(K) @ pix.T).T
+            d_cam = d_cam / d_cam.norm(dim=-1, keepdim=True)
+            d = d_cam @ R  # world-frame directions of cam_T_world rotation R: d_world = R^T d_cam
+            d = d + noise * torch.randn(d.shape, generator=g)
+            m = torch.cross(c.expand_as(d), d, dim=-1)
+            rays[b, :3, t] = d.T.reshape(3, h, w)
+            rays[b, 3:, t] = m.T.reshape(3, h, w)
+    return rays, Ks

@@ -197,3 +197,22 @@ def test_full_size_joint_and_q64_goldens_are_pinned():
     assert all(rep[f"T40_engine_seam{i}"]["inliers"] >= 1 and rep[f"T40_engine_seam{i}"]["n"] == 15051 for i in range(3)), rep
     q = np.load(os.path.join(GOLD, "full_T16_q64.npz"))
     assert q["track_2d_traj_est_bn2t"].shape == (1, 64, 2, 16)
+
+
+def test_variable_intrinsics_oracle_matches_reference_fixture():
+    """fixed_intrinsics=False (geometry_utils.py:582-654): tests/golden/intrinsics_variable.npz holds the reference's own
+    rays_to_cameras_and_variable_per_frame_intrinsics on seeded synthetic ray maps with its two cv2 calls replaced by the oracle's
+    deterministic stand-ins (tools/gen_golden_intrinsics.py); the oracle's restatement must reproduce it."""
+    from oracle import l4p_oracle as lo
+    from tests.golden_utils import synthetic_rays
+
+    gold = np.load(os.path.join(GOLD, "intrinsics_variable.npz"))
+    rays, Ks = synthetic_rays()
+    E, K = lo.rays_to_cameras_variable_intrinsics(rays, (224, 224))
+    assert np.abs(E.numpy() - gold["E"]).max() <= 1e-5 * np.abs(gold["E"]).max()
+    assert np.abs(K.numpy() - gold["K"]).max() <= 1e-5 * np.abs(gold["K"]).max()
+    # every frame recovers its item's camera (one K per batch item in the synthetic data, estimated per frame)
+    K_ray = lo.denormalize_intrinsics(lo.normalize_intrinsics(K, 224, 224), 16, 16)
+    for b, Kb in enumerate(Ks):
+        for t in range(K.shape[-1]):
+            assert float((K_ray[b, :3, :3, t] - Kb).abs().max() / Kb.abs().max()) <= 2e-2, (b, t)

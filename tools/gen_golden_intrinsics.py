@@ -31,32 +31,8 @@ import torch
 from l4p_amd.weights import ModelCfg, seeded_state_dict
 from oracle import joint_oracle as jo
 from oracle import l4p_oracle as lo
-from tests.golden_utils import make_batch, sample_indices
+from tests.golden_utils import make_batch, sample_indices, synthetic_rays
 from tools.gen_golden import build_reference, install_stubs, rel_err
-
-
-def synthetic_rays(B=2, T=4, h=16, w=16, seed=5, noise=2e-3):
-    """Pluecker ray maps [B,6,T,h,w] of cameras with ONE ray-grid K per batch item, rotations / centres per frame."""
-    g = torch.Generator().manual_seed(seed)
-    Ks, rays = [], torch.zeros(B, 6, T, h, w)
-    j, i = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
-    pix = torch.stack([i, j, torch.ones_like(i)], dim=-1).reshape(-1, 3)
-    for b in range(B):
-        K = torch.tensor([[13.0 + b, 0.2, 7.3], [0.0, 14.5 - b, 7.9], [0.0, 0.0, 1.0]])
-        Ks.append(K)
-        for t in range(T):
-            R = torch.linalg.qr(torch.eye(3) + 0.15 * torch.randn(3, 3, generator=g)).Q
-            if torch.linalg.det(R) < 0:
-                R = -R
-            c = torch.randn(3, generator=g)
-            d_cam = (torch.inverse(K) @ pix.T).T
-            d_cam = d_cam / d_cam.norm(dim=-1, keepdim=True)
-            d = d_cam @ R  # world-frame directions of cam_T_world rotation R: d_world = R^T d_cam
-            d = d + noise * torch.randn(d.shape, generator=g)
-            m = torch.cross(c.expand_as(d), d, dim=-1)
-            rays[b, :3, t] = d.T.reshape(3, h, w)
-            rays[b, 3:, t] = m.T.reshape(3, h, w)
-    return rays, Ks
 
 
 def main():
@@ -84,6 +60,13 @@ def main():
         e = float((K_ray[b, :3, :3, 0] - K).abs().max() / K.abs().max())
         report[f"synthetic_K_recovery_rel_err_b{b}"] = e
         assert e <= 2e-2, (b, e, K_ray[b, :3, :3, 0], K)
+    # the per-frame VARIABLE intrinsics branch (fixed_intrinsics=False, geometry_utils.py:582-654): every frame's own (R, K)
+    Ev_ref, _, Kv_ref = gu.rays_to_cameras_and_variable_per_frame_intrinsics(rays.clone(), reproj_threshold=0.2, output_size=(224, 224))
+    Ev_o, Kv_o = lo.rays_to_cameras_variable_intrinsics(rays.clone(), (224, 224))
+    report["variable_intrinsics_extrinsics_rel_err"] = rel_err(Ev_o, Ev_ref)
+    report["variable_intrinsics_K_rel_err"] = rel_err(Kv_o, Kv_ref)
+    assert report["variable_intrinsics_extrinsics_rel_err"] <= 1e-5 and report["variable_intrinsics_K_rel_err"] <= 1e-5, report
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "intrinsics_variable.npz"), E=Ev_ref.numpy(), K=Kv_ref.numpy())
     # a supplied K (k_override) gives the same downstream result as estimating that K
     E_k, K_k = lo.rays_to_cameras_fixed_intrinsics(rays.clone(), (224, 224), k_override=lambda b: K_ray[b, :3, :3, 0])
     assert rel_err(E_k, E_ref) <= 1e-5 and rel_err(K_k, K_ref) <= 1e-5
