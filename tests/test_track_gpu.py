@@ -2,8 +2,8 @@
 single window and 3-window sliding tracking (memory tokens, prompt-feature carry, query re-seeding)
 against the oracle run live and the reference's golden vectors.
 
-Float outputs: L4P_F32 engine 1e-3 relative-to-max (north_star); L4P_BF16 engine rel-L2 <= 5e-2 (bf16
-drift through 4 encoder blocks + 2 two-way layers, reported).  Integer / boolean window state (labels,
+Float outputs: L4P_F32 engine 1e-3 relative-to-max (north_star); L4P_BF16 engine rel-L2 <= 2e-2 (bf16
+drift through 4 encoder blocks + 2 two-way layers: 1e-3 .. 7e-3 measured).  Integer / boolean window state (labels,
 prompt labels, validity masks, re-seeded query times = argmax index) is asserted BIT-EXACT in f32 mode
 against both the oracle trace and the reference's recorded trace; in bf16 mode the tracks whose state differs
 from the f32 trace are counted and bounded (<= 1 per fixture)."""
@@ -53,7 +53,7 @@ def test_tracker_vs_oracle_and_golden(dev, mini, precision, case, T, nq):
             g = torch.from_numpy(gold[key])
             assert (y - g).abs().max() <= 1e-3 * g.abs().max(), key
         else:
-            assert rel_l2(y, ref) <= 5e-2, (key, rel_l2(y, ref))
+            assert rel_l2(y, ref) <= 2e-2, (key, rel_l2(y, ref))  # measured 1e-3 .. 7e-3: ~2x the drift
     nwin = (T - 16) // 8 + 1
     assert len(head.trace) == nwin == len(otrace)
     if exact:

@@ -1,5 +1,6 @@
 """Per-shape kernel time table for one bench workload (event profiler, l4p_prof_detail).
 usage: python tools/prof_detail.py [c2|c3|c5|prep|demo] [steps]   (demo: 64 frames, 625 queries, depth+flow+mask+tracks)"""
+import contextlib
 import ctypes as C
 import os
 import sys
@@ -64,7 +65,8 @@ def main():
 
         def run():
             with torch.no_grad():
-                return model.forward(data, tasks)
+                with contextlib.redirect_stdout(sys.stderr):  # (the model mirrors the reference's stdout messages)
+                    return model.forward(data, tasks)
 
     for _ in range(2):
         run()
