@@ -28,14 +28,28 @@ __device__ int g_tile_gm = 0;
 #endif
 // SPLITK is a compile-time form: the k-range arithmetic it adds to the staging segments of every phase cost the plain kernel
 // 1.7 % of the c3 step when it was a run-time condition
-template <int MODE, int WR, int WC, bool SPLITK = false>
+template <int WR, int WC, int TM, int TN>
+struct Gemm8pCfg {
+    static constexpr int BM = WR * TM * 16, BN = WC * TN * 16;
+    static constexpr int A_HALF = WR * TM * 8 * 128, W_HALF = (WC * TN * 8 + 63) / 64 * 64 * 128;
+    static constexpr int LDS_BYTES = 2 * (2 * A_HALF + 2 * W_HALF);
+};
+// TM x TN (round 3): MFMA tiles per wave.  8 x 4 (wave tile 128 x 64) is the default form described above; 4 x 6 (wave tile
+// 64 x 96, WR = 4, WC = 2: workgroup tile 256 x 192) exists for the encoder's N = 1408 / 4608 linears at batch 4: 256 x 256 tiles
+// give 192 / 576 tiles on 256 CUs (0.75 / 2.25 rounds: a CU that has a tile computes 65 536 outputs where its fair share is 45 056),
+// 256 x 192 tiles give 256 / 768 (whole rounds of 49 152 outputs).  Same phases with quadrants of (TM/2) x (TN/2) tiles.
+template <int MODE, int WR, int WC, bool SPLITK = false, int TM = 8, int TN = 4>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
+    static_assert(TM % 2 == 0 && TN % 2 == 0 && (WR * TM) % 8 == 0, "half tiles; A half-tile = whole 64-row staging passes");
     typedef bf16_t T;
-    constexpr int BM = WR * 128, BN = WC * 64, BK = 64, TM = 8, TN = 4;
-    constexpr int A_HALF = WR * 64 * 128, W_HALF = WC * 32 * 128;  // bytes
+    constexpr int BM = WR * TM * 16, BN = WC * TN * 16, BK = 64;
+    constexpr int RH = TM * 8, CH = TN * 8;               // rows of A / of W that one wave owns in a half-tile
+    constexpr int A_PASS = WR * RH / 64, W_PASS = (WC * CH + 63) / 64;  // 512-lane LDS-DMA passes (64 rows each) per half-tile
+    // (a W half-tile is allocated as whole passes: rows past WC * CH are filler - zero chunks, never read - so that every
+    //  lane issues the same number of requests and the counted vmcnt waits hold for all waves)
+    constexpr int A_HALF = WR * RH * 128, W_HALF = W_PASS * 64 * 128;  // bytes
     constexpr int BUF = 2 * A_HALF + 2 * W_HALF;
-    constexpr int A_PASS = WR, W_PASS = WC / 2;          // 512-lane LDS-DMA passes (64 rows each) per half-tile
     constexpr int INFLIGHT = 2 * A_PASS + 2 * W_PASS;    // loads of the four most recent half-tiles
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -92,7 +106,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     // ---- staging sources (one 16-byte chunk per lane per pass) ----
     const int srow = tid >> 3, slot = tid & 7;
     const int cs_a = slot ^ ((srow >> 1) & 7);
-    const int cs_w = slot ^ ((((srow >> 3) & 3) << 1) | ((srow >> 1) & 1));
+    // (W rows are stored per wave column block as (q, 4 jj + r): q = the lane group that owns the column in the epilogue; the
+    //  XOR phase is distinct over (q, r >> 1), conflict-free for the fragment reads of either wave tile shape - brute-forced)
+    int cs_w[W_PASS];
+#pragma unroll
+    for (int i = 0; i < W_PASS; ++i) {
+        const int lr = srow + 64 * i;
+        cs_w[i] = slot ^ (((((lr % CH) / (2 * TN)) & 3) << 1) | ((lr >> 1) & 1));
+    }
     const char* a_src[A_PASS][2];
     unsigned a_mask[A_PASS][2];
     const char* w_src[W_PASS][2];
@@ -100,7 +121,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     for (int i = 0; i < A_PASS; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            int m = m0 + i * 128 + h * 64 + srow;
+            const int lra = i * 64 + srow;  // LDS row of the A half-tile: (wave row block, row inside the block's half)
+            int m = m0 + (lra / RH) * (TM * 16) + h * RH + lra % RH;
             if (m >= p.M) m = p.M - 1;
             if (MODE == 0) {
                 const long long pm = p.a_gr > 0 ? (long long)(m / p.a_gr) * p.a_gs + p.a_go + (m % p.a_gr) : m;
@@ -131,10 +153,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     for (int i = 0; i < W_PASS; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int lr = srow + 64 * i;
-            int n = n0 + (lr >> 5) * 64 + ((lr >> 3) & 3) * 16 + 8 * h + (lr & 7);
+            const int lr = srow + 64 * i, within = lr % CH;
+            int n = n0 + (lr / CH) * (TN * 16) + (within / (2 * TN)) * (4 * TN) + 4 * (h * (TN / 2)) + within % (2 * TN);
             if (n >= p.N) n = p.N - 1;  // columns past N are computed on a clamped row and never stored
-            w_src[i][h] = (const char*)((const T*)p.W + (long long)n * p.ldw + cs_w * 8);
+            w_src[i][h] = (const char*)((const T*)p.W + (long long)n * p.ldw + cs_w[i] * 8);
+            if (lr >= WC * CH) w_src[i][h] = nullptr;  // filler rows of the padded half-tile
         }
 
     const int nk_all = (p.K + BK - 1) / BK;
@@ -191,9 +214,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         }
     };
     auto stage_w = [&](int h, int kt, int buf) {
-        const bool ok = (!SPLITK || kt < nk) && (kt0 + kt) * BK + cs_w * 8 < p.K;
 #pragma unroll
         for (int i = 0; i < W_PASS; ++i) {
+            const bool ok = (!SPLITK || kt < nk) && (kt0 + kt) * BK + cs_w[i] * 8 < p.K && w_src[i][h] != nullptr;
             const char* src = ok ? w_src[i][h] + (long long)(kt0 + kt) * (BK * 2) : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src,
                                              (lptr_t)(smem + buf * BUF + 2 * A_HALF + h * W_HALF + (i * 512 + wave * 64) * 16), 16, 0, 0);
@@ -205,8 +228,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     int a_off[2], w_off[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        a_off[kk] = (wr * 64 + li) * 128 + (((kk * 4 + kg) ^ sw_a) << 4);                        // + ii * 2048
-        w_off[kk] = (wc * 32 + 8 * (li >> 2) + (li & 3)) * 128 + (((kk * 4 + kg) ^ sw_w) << 4);  // + jj * 512
+        a_off[kk] = (wr * RH + li) * 128 + (((kk * 4 + kg) ^ sw_a) << 4);                                // + ii * 2048
+        w_off[kk] = (wc * CH + 2 * TN * (li >> 2) + (li & 3)) * 128 + (((kk * 4 + kg) ^ sw_w) << 4);  // + jj * 512
     }
 
     f32x4 acc[TM][TN];
@@ -214,19 +237,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 xa[4][2], wb[2][2][2];
+    bf16x8 xa[TM / 2][2], wb[2][TN / 2][2];
 
     auto read_a = [&](int h, int buf) {
         const char* base = smem + buf * BUF + h * A_HALF;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
+        for (int ii = 0; ii < TM / 2; ++ii)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) xa[ii][kk] = *(const bf16x8*)(base + a_off[kk] + ii * 2048);
     };
     auto read_w = [&](int h, int buf) {
         const char* base = smem + buf * BUF + 2 * A_HALF + h * W_HALF;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < TN / 2; ++jj)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) wb[h][jj][kk] = *(const bf16x8*)(base + w_off[kk] + jj * 512);
     };
@@ -235,10 +258,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
+            for (int ii = 0; ii < TM / 2; ++ii)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-                    acc[qa * 4 + ii][qw * 2 + jj] = mma16(wb[qw][jj][kk], xa[ii][kk], acc[qa * 4 + ii][qw * 2 + jj]);
+                for (int jj = 0; jj < TN / 2; ++jj)
+                    acc[qa * (TM / 2) + ii][qw * (TN / 2) + jj] =
+                        mma16(wb[qw][jj][kk], xa[ii][kk], acc[qa * (TM / 2) + ii][qw * (TN / 2) + jj]);
         __builtin_amdgcn_s_setprio(0);
     };
     // end of a phase's read/stage segment: counted wait for the half-tile staged four phases ago, then the barrier
@@ -301,10 +325,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (only zero-chunk dummies are still in flight)
 
     if constexpr (SPLITK) {  // raw float partial [ksplit][M][N]; bias / activation / residuals / conversion: splitk_finish_kernel
-        const int nb2 = n0 + wc * 64 + 4 * TN * kg;
+        const int nb2 = n0 + wc * (TN * 16) + 4 * TN * kg;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wr * 128 + i * 16 + li;
+            const int m = m0 + wr * (TM * 16) + i * 16 + li;
             if (m >= p.M) continue;
             float* pp = p.partial + ((long long)ksplit * p.M + m) * p.N + nb2;
 #pragma unroll
@@ -320,12 +344,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
 #ifdef GEMM_DBG_ONLY_FAST  // (probe: the kernel with nothing but the lean bias + store epilogue)
-    gemm_epilogue_dense<T, TM, TN, ACT_NONE, 0>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
+    gemm_epilogue_dense<T, TM, TN, ACT_NONE, 0>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg);
     return;
 #endif
     if (p.epi == EPI_MASKDOT)
-        gemm_epilogue_maskdot<T, TM, TN>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
-    else if (!gemm_epilogue_dense_dispatch<T, TM, TN>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg))
-        gemm_epilogue<T, TM, TN, true>(p, acc, m0 + wr * 128, n0 + wc * 64, li, kg);
+        gemm_epilogue_maskdot<T, TM, TN>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg);
+    else if (!gemm_epilogue_dense_dispatch<T, TM, TN>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg))
+        gemm_epilogue<T, TM, TN, true>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg);
 #endif
 }

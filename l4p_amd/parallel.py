@@ -12,6 +12,15 @@ import torch.distributed as dist
 from .packing import PackedWeights
 
 
+def _collectives_on() -> bool:
+    """True when the exchange steps must go through torch.distributed.  A one-rank group skips them unless
+    L4P_FORCE_COLLECTIVES=1: the single-GPU boxes of the test pool then still push the very same tensors (packed arena, decoded
+    windows, query shards) through RCCL's broadcast / all-gather with one rank (tests/test_rccl_one_rank_gpu.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("L4P_FORCE_COLLECTIVES", "0") == "1"
+
+
 def env_rank() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -19,7 +28,8 @@ def env_rank() -> Tuple[int, int, int]:
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
     rank, world, local = env_rank()
-    if world > 1 and not dist.is_initialized():
+    forced = os.environ.get("L4P_FORCE_COLLECTIVES", "0") == "1"
+    if (world > 1 or forced) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -32,7 +42,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
 
 def broadcast_weights(weights: Optional[PackedWeights], device: torch.device, src: int = 0) -> PackedWeights:
     """Rank ``src`` holds the packed arena; every other rank receives layout + bytes.  One collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         assert weights is not None
         return weights
     rank = dist.get_rank()
@@ -95,7 +105,7 @@ def all_gather_windows(local: dict, n_windows: int, rank: int, world: int) -> Li
     """local: {window id: {key: tensor}} for this rank's chunk -> list over ALL windows of {key: tensor}.
     One all_gather per key on a [chunk_max, ...] block (chunks differ by at most one window; the pad slot is ignored)."""
     chunks = window_chunks(n_windows, world)
-    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+    if not _collectives_on():
         return [local[w] for w in range(n_windows)]
     cmax = max(e - s for s, e in chunks)
     s0, e0 = chunks[rank]
@@ -127,7 +137,7 @@ def shard_queries(n_queries: int, rank: int, world: int) -> Tuple[int, int]:
 
 def all_gather_queries(x: torch.Tensor, n_queries: int, rank: int, world: int, dim: int = 1) -> torch.Tensor:
     """Inverse of shard_queries along ``dim`` (shards differ by at most one query: padded to the largest)."""
-    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+    if not _collectives_on():
         return x
     chunks = window_chunks(n_queries, world)
     cmax = max(e - s for s, e in chunks)
@@ -200,7 +210,7 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
     local = decode_local_windows(net, data, tasks, rank, world, group)
     gathered = all_gather_windows(local, nwin, rank, world)  # the one exchange step of the dense path
     out = stitch_gathered_windows(net, data, tasks, gathered, rank, world)
-    if "track_2d" in tasks and world > 1:
+    if "track_2d" in tasks and (world > 1 or _collectives_on()):
         nq = data["track_2d_pointquerries_bn3"].shape[1]
         name = net.task_heads["track_2d"].task_name
         for key, shp in ((f"{name}_traj_est_bn2t", 2), (f"{name}_vis_est_bn1t", 1), (f"{name}_depth_est_bn1t", 1)):

@@ -1,0 +1,8 @@
+cd /root/repo
+mkdir -p gpurun_out/r3h
+timeout 900 python -m pytest tests/test_gemm8p_gpu.py -x -q 2>&1 | tail -5 > gpurun_out/r3h/pytest.log
+one() { python bench.py --workload $1 --steps 20 --warmup 5 --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
+for i in 1 2; do echo -n "c3 T192=1: "; one c3; echo -n "c3 T192=0: "; L4P_GEMM_T192=0 one c3; done > gpurun_out/r3h/ab.txt 2>&1
+python tools/prof_detail.py c3 3 > gpurun_out/r3h/shapes_t192.txt 2>/dev/null
+L4P_GEMM_T192=0 python tools/prof_detail.py c3 3 > gpurun_out/r3h/shapes_t256.txt 2>/dev/null
+cat gpurun_out/r3h/pytest.log gpurun_out/r3h/ab.txt
