@@ -32,7 +32,17 @@ __device__ __forceinline__ f32x4 mma16(f32x8 a, f32x8 b, f32x4 c) {
     return c;
 }
 __device__ __forceinline__ f32x16 mma32(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef ATTN_DBG_MFMA16  // (probe, WRONG results: every 32x32x16 MFMA issued as two 16x16x32 on the same operand registers - the
+                        //  same matrix-pipe cycles, FLOPs and operand reads, a quarter of the accumulator registers per MFMA:
+                        //  prices the MFMA shape's share of the attention kernel's power, tools/probes/ab_attn16.sh)
+    const f32x4 q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[4], c[5], c[6], c[7]}, q2 = {c[8], c[9], c[10], c[11]},
+                q3 = {c[12], c[13], c[14], c[15]};
+    const f32x4 n0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q2, 0, 0, 0);
+    const f32x4 n1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, q3, 0, 0, 0);  // (operands swapped: not the same value as n0)
+    return (f32x16){n0[0], n0[1], n0[2], n0[3], n1[0], n1[1], n1[2], n1[3], q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ f32x16 mma32(f32x8 a, f32x8 b, f32x16 c) {
 #pragma unroll
