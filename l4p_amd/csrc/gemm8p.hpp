@@ -38,8 +38,16 @@ struct Gemm8pCfg {
 // 64 x 96, WR = 4, WC = 2: workgroup tile 256 x 192) exists for the encoder's N = 1408 / 4608 linears at batch 4: 256 x 256 tiles
 // give 192 / 576 tiles on 256 CUs (0.75 / 2.25 rounds: a CU that has a tile computes 65 536 outputs where its fair share is 45 056),
 // 256 x 192 tiles give 256 / 768 (whole rounds of 49 152 outputs).  Same phases with quadrants of (TM/2) x (TN/2) tiles.
-template <int MODE, int WR, int WC, bool SPLITK = false, int TM = 8, int TN = 4>
+// PERSIST (round 3 EXPERIMENT, measured slower and not instantiated by default - see launch_8p; MODE 0 without split-K): the grid is one workgroup per CU and a workgroup walks tiles bid, bid + gridDim.x, ...
+// Between the main loop of a tile and its epilogue the NEXT tile's prologue (k-tile 0 and half of k-tile 1: six half-tile stages) is
+// requested - the LDS buffers are free by then and no epilogue of this mode touches LDS - so the next main loop starts on data that
+// landed under the epilogue instead of paying a workgroup launch + an exposed HBM / L2 round trip per tile.  The per-lane source
+// pointers of the next tile live only across those six stage calls (they are recomputed at the top of the next iteration from an
+// opaque copy of the tile origin): the epilogue's register budget is unchanged.  Matters most where tiles are short: the mask
+// product (K = 352: 5.5 k-tiles per tile, 48 - 96 tiles per CU).
+template <int MODE, int WR, int WC, bool SPLITK = false, int TM = 8, int TN = 4, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
+    static_assert(!PERSIST || (MODE == 0 && !SPLITK), "persistent form: dense GEMM without split-K");
     static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
     static_assert(TM % 2 == 0 && TN % 2 == 0 && (WR * TM) % 8 == 0, "half tiles; A half-tile = whole 64-row staging passes");
     typedef bf16_t T;
@@ -56,10 +64,32 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A0 | A1 | W0 | W1]
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int wr = wave / WC, wc = wave % WC, grp = wave >> 2;
-    const int li = lane & 15, kg = lane >> 4;
+    // per-lane constants (lane_setup): PERSIST re-derives them from an opaque copy of the thread index after every epilogue, so that
+    // none of them - and nothing the compiler would hoist out of the tile loop on their account - is live across an epilogue
+    int li, kg, srow, slot, cs_a, cs_w[W_PASS], a_off[2], w_off[2];
+    auto lane_setup = [&](int tid) {
+        const int lane = tid & 63;
+        li = lane & 15, kg = lane >> 4;
+        srow = tid >> 3, slot = tid & 7;
+        cs_a = slot ^ ((srow >> 1) & 7);
+        // (W rows are stored per wave column block as (q, 4 jj + r): q = the lane group that owns the column in the epilogue; the
+        //  XOR phase is distinct over (q, r >> 1), conflict-free for the fragment reads of either wave tile shape - brute-forced)
+#pragma unroll
+        for (int i = 0; i < W_PASS; ++i) {
+            const int lr = srow + 64 * i;
+            cs_w[i] = slot ^ (((((lr % CH) / (2 * TN)) & 3) << 1) | ((lr >> 1) & 1));
+        }
+        // fragment read offsets (bytes inside a half-tile); the k-step's chunk is XORed with the row phase
+        const int sw_a = (li >> 1) & 7, sw_w = (((li >> 2) & 3) << 1) | ((li >> 1) & 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            a_off[kk] = (wr * RH + li) * 128 + (((kk * 4 + kg) ^ sw_a) << 4);                                // + ii * 2048
+            w_off[kk] = (wc * CH + 2 * TN * (li >> 2) + (li & 3)) * 128 + (((kk * 4 + kg) ^ sw_w) << 4);  // + jj * 512
+        }
+    };
+    lane_setup((int)threadIdx.x);
 
     // ---- workgroup -> tile: XCD x gets a contiguous range of tiles (workgroup b runs on XCD b % 8), n fastest, so the
     //      tiles that share an A row panel / the W panels stay inside one L2 ----
@@ -68,55 +98,52 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     // leaves a float partial that splitk_finish_kernel sums (fixed order) and finishes, as in gemm_kernel
     const int nsplit = SPLITK ? p.splitk : 1;
     const int ksplit = SPLITK ? (int)blockIdx.x / ntiles : 0;
-    const int bid = SPLITK ? (int)blockIdx.x - ksplit * ntiles : (int)blockIdx.x;
-    int tile;
-    {
-        const int xcd = bid & 7, idx = bid >> 3, q = ntiles >> 3, r = ntiles & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    const int bid0 = SPLITK ? (int)blockIdx.x - ksplit * ntiles : (int)blockIdx.x;
     // Linear order of the tiles: column BANDS of <= 8 tile columns, inside a band m-major with the band's columns fastest.
     // The ~32 tiles an XCD runs at a time are consecutive in this order, i.e. a block of ~(32 / band width) tile rows x the
     // band: they share that many A panels and <= 8 W panels, all walking k together, so each panel k-tile is fetched into the
     // XCD's L2 once for the whole block.  (Plain row-major order made a round touch every W panel of a wide N: 2 + 24 panels
     // for the MLP's first linear instead of 4 + 8; PMC: 2.4x the operand bytes fetched.)
-    int mt, nt_;
-    {
-        const int nb = (ntn + 7) >> 3, bw = (ntn + nb - 1) / nb, full = (nb - 1) * ntm * bw;
-#ifdef GEMM_PROBE_VARIANTS
-        const bool banded = g_tile_gm >= 0;
-#else
-        const bool banded = true;
-#endif
-        if (!banded || nb == 1) {
-            mt = tile / ntn;
-            nt_ = tile % ntn;
-        } else if (tile < full) {
-            const int band = tile / (ntm * bw), rem = tile - band * (ntm * bw);
-            mt = rem / bw;
-            nt_ = band * bw + rem % bw;
-        } else {
-            const int w = ntn - (nb - 1) * bw, rem = tile - full;  // last band: the remaining w columns
-            mt = rem / w;
-            nt_ = (nb - 1) * bw + rem % w;
+    // (PERSIST: workgroup b's j-th tile is "workgroup" b + j * gridDim.x of the plain launch; gridDim.x is a multiple of 8, so
+    //  the XCD of a tile and the block of tiles an XCD works on at a time are those of the plain launch)
+    auto decode_tile = [&](int bid, int& m0_, int& n0_) {
+        int tile;
+        {
+            const int xcd = bid & 7, idx = bid >> 3, q = ntiles >> 3, r = ntiles & 7;
+            tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
-    }
-    if (MODE == 1) mt = conv_tile_walk(p, mt, BM, 2);
-    const int m0 = mt * BM, n0 = nt_ * BN;
+        int mt, nt_;
+        {
+            const int nb = (ntn + 7) >> 3, bw = (ntn + nb - 1) / nb, full = (nb - 1) * ntm * bw;
+#ifdef GEMM_PROBE_VARIANTS
+            const bool banded = g_tile_gm >= 0;
+#else
+            const bool banded = true;
+#endif
+            if (!banded || nb == 1) {
+                mt = tile / ntn;
+                nt_ = tile % ntn;
+            } else if (tile < full) {
+                const int band = tile / (ntm * bw), rem = tile - band * (ntm * bw);
+                mt = rem / bw;
+                nt_ = band * bw + rem % bw;
+            } else {
+                const int w = ntn - (nb - 1) * bw, rem = tile - full;  // last band: the remaining w columns
+                mt = rem / w;
+                nt_ = (nb - 1) * bw + rem % w;
+            }
+        }
+        if (MODE == 1) mt = conv_tile_walk(p, mt, BM, 2);
+        m0_ = mt * BM, n0_ = nt_ * BN;
+    };
+    int bid = bid0, m0, n0;
+    decode_tile(bid, m0, n0);
 
     // ---- staging sources (one 16-byte chunk per lane per pass) ----
-    const int srow = tid >> 3, slot = tid & 7;
-    const int cs_a = slot ^ ((srow >> 1) & 7);
-    // (W rows are stored per wave column block as (q, 4 jj + r): q = the lane group that owns the column in the epilogue; the
-    //  XOR phase is distinct over (q, r >> 1), conflict-free for the fragment reads of either wave tile shape - brute-forced)
-    int cs_w[W_PASS];
-#pragma unroll
-    for (int i = 0; i < W_PASS; ++i) {
-        const int lr = srow + 64 * i;
-        cs_w[i] = slot ^ (((((lr % CH) / (2 * TN)) & 3) << 1) | ((lr >> 1) & 1));
-    }
     const char* a_src[A_PASS][2];
     unsigned a_mask[A_PASS][2];
     const char* w_src[W_PASS][2];
+    auto setup_src = [&](int m0, int n0) {
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i)
 #pragma unroll
@@ -159,6 +186,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
             w_src[i][h] = (const char*)((const T*)p.W + (long long)n * p.ldw + cs_w[i] * 8);
             if (lr >= WC * CH) w_src[i][h] = nullptr;  // filler rows of the padded half-tile
         }
+    };
+    setup_src(m0, n0);
 
     const int nk_all = (p.K + BK - 1) / BK;
     const int kt0 = SPLITK ? (int)((long long)nk_all * ksplit / nsplit) : 0;
@@ -223,20 +252,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
         }
     };
 
-    // ---- fragment read offsets (bytes inside a half-tile); the k-step's chunk is XORed with the row phase ----
-    const int sw_a = (li >> 1) & 7, sw_w = (((li >> 2) & 3) << 1) | ((li >> 1) & 1);
-    int a_off[2], w_off[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        a_off[kk] = (wr * RH + li) * 128 + (((kk * 4 + kg) ^ sw_a) << 4);                                // + ii * 2048
-        w_off[kk] = (wc * CH + 2 * TN * (li >> 2) + (li & 3)) * 128 + (((kk * 4 + kg) ^ sw_w) << 4);  // + jj * 512
-    }
-
     f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 xa[TM / 2][2], wb[2][TN / 2][2];
 
     auto read_a = [&](int h, int buf) {
@@ -278,17 +294,27 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     };
 
     // ---- prologue: k-tile 0 complete, A0/W0 of k-tile 1 ----
-    stage_a(0, 0, 0);
-    stage_w(0, 0, 0);
-    stage_w(1, 0, 0);
-    stage_a(1, 0, 0);
-    stage_a(0, 1, 1);
-    stage_w(0, 1, 1);
+    auto prologue_stage = [&]() {
+        stage_a(0, 0, 0);
+        stage_w(0, 0, 0);
+        stage_w(1, 0, 0);
+        stage_a(1, 0, 0);
+        stage_a(0, 1, 1);
+        stage_w(0, 1, 1);
+    };
+    prologue_stage();
+    for (;;) {  // tile loop (one pass unless PERSIST)
+    // (past a seam the epilogue's stores are younger than the prologue's requests and memory operations retire in order: the
+    //  counted wait still means "at most the four youngest half-tile stages are outstanding")
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");  // A0(0), W0(0) landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (grp == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto ktile = [&](int t, auto cur_c) {
         constexpr int cur = decltype(cur_c)::value, nxt = cur ^ 1;
@@ -324,6 +350,21 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with the trailing barrier of the delayed group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (only zero-chunk dummies are still in flight)
 
+    // ---- seam (PERSIST): every wave is past its last fragment read (the barrier above), the LDS-DMA queue is empty: request the
+    //      next tile's prologue now, then run this tile's epilogue under it ----
+    int nm0 = 0, nn0 = 0;
+    bool more = false;
+    if constexpr (PERSIST) {
+        const int nbid = bid + (int)gridDim.x;
+        more = nbid < ntiles;
+        if (more) {
+            bid = nbid;
+            decode_tile(nbid, nm0, nn0);
+            setup_src(nm0, nn0);
+            prologue_stage();
+        }
+    }
+
     if constexpr (SPLITK) {  // raw float partial [ksplit][M][N]; bias / activation / residuals / conversion: splitk_finish_kernel
         const int nb2 = n0 + wc * (TN * 16) + 4 * TN * kg;
 #pragma unroll
@@ -352,4 +393,18 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     else if (!gemm_epilogue_dense_dispatch<T, TM, TN>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg))
         gemm_epilogue<T, TM, TN, true>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg);
 #endif
+    if constexpr (!PERSIST) {
+        break;
+    } else {
+        if (!more) break;
+        // the next tile becomes the current one; its source pointers are recomputed from an OPAQUE copy of its origin, so that
+        // the ones computed at the seam are dead across the epilogue
+        m0 = nm0, n0 = nn0;
+        asm volatile("" : "+s"(m0), "+s"(n0));
+        int t_ = (int)threadIdx.x;
+        asm volatile("" : "+v"(t_));
+        lane_setup(t_);
+        setup_src(m0, n0);
+    }
+    }  // tile loop
 }
