@@ -388,10 +388,15 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     gemm_epilogue_dense<T, TM, TN, ACT_NONE, 0>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg);
     return;
 #endif
-    if (p.epi == EPI_MASKDOT)
-        gemm_epilogue_maskdot<T, TM, TN>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg);
-    else if (!gemm_epilogue_dense_dispatch<T, TM, TN>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg))
-        gemm_epilogue<T, TM, TN, true>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg);
+    // (the mask-product epilogue exists for the 8 x 4 wave tile only - launch_gemm never sends it to another form)
+    if (TN == 4 && p.epi == EPI_MASKDOT) {
+        if constexpr (TN == 4) gemm_epilogue_maskdot<T, TM, TN>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg);
+    } else if (!gemm_epilogue_dense_dispatch<T, TM, TN>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg)) {
+        // (the generic row body - every scatter form, row map and residual kind decided at run time - is compiled into the 8 x 4
+        //  form only: beside the 4 x 6 form's lean epilogues it pushed hipcc into scratch; launch_gemm sends the 4 x 6 form
+        //  lean epilogues only, epilogue_is_lean_8p)
+        if constexpr (TN == 4) gemm_epilogue<T, TM, TN, true>(p, acc, m0 + wr * (TM * 16), n0 + wc * (TN * 16), li, kg);
+    }
 #endif
     if constexpr (!PERSIST) {
         break;
