@@ -266,10 +266,12 @@ int l4p_layernorm_ex(l4p_stream stream, int dtype, const float* x, const float* 
 /* keys = LayerNorm(keys + attention output) (sam/transformer.py:183-185) with the sum formed in the LayerNorm: the row
  * normalised is x[row % x_mod] (float; x_mod = 0: x[row]) + delta[row] (engine dtype, the out projection's result), outputs as
  * l4p_layernorm_ex.  The float key stream is read once here instead of read + written by the projection's epilogue and read
- * again; out_f32 may alias x when x_mod = 0. */
+ * again; out_f32 may alias x when x_mod = 0.  x_shared (may be NULL): rows p = row % x_period with p >= x_split read
+ * x_shared[p - x_split] instead - the part of the key stream that is the same for every track of a later window (encoder
+ * feature + the learned mask token: l4p_track_keys_init's k32_shared); x_shared is never written, so out_f32 may still alias x. */
 int l4p_layernorm_res(l4p_stream stream, int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma,
                       const float* beta, float eps, void* out_T, float* out_f32, int M, int C, const float* add, int add_mod,
-                      void* out_T2);
+                      void* out_T2, const float* x_shared, int x_period, int x_split);
 
 /* The same LayerNorm (+ optional GELU) for rows that are STORED in the engine dtype: x_T, out_T are T [M][C] and may be the
  * same buffer.  Used for LayerNorm3d + GELU after the first up-scaling ConvTranspose (mask_decoder.py:60-62), whose 1M x 352
@@ -285,9 +287,14 @@ int l4p_track_tokens(l4p_stream stream, const float* queries, const float* label
                      float* tokens, int N, int C, int T, int H, int W);
 
 /* keys = enc_features[-1] (broadcast over queries) + per-query history (sparse_heads.py:341-346):
- * k32 float, kT = T(keys), kP = T(keys + dense_pe), each [N][P][C]. */
+ * k32 float, kT = T(keys), kP = T(keys + dense_pe), each [N][P][C].
+ * shared_from > 0 (later windows of a long clip: the history rows [shared_from, P) of every track are the learned mask token
+ * again, sparse_heads.py:418-427): those rows are formed for track 0 only - hist rows past shared_from of the other tracks
+ * are not read, their k32 / kT / kP rows not written - and track 0's float rows are also stored in k32_shared
+ * [P - shared_from][C] (the residual master l4p_layernorm_res reads for those rows of every track).  shared_from = 0: every
+ * row of every track (k32_shared ignored). */
 int l4p_track_keys_init(l4p_stream stream, int dtype, const float* enc, const float* hist, const float* pos,
-                        float* k32, void* kT, void* kP, int N, int P, int C);
+                        float* k32, void* kT, void* kP, int N, int P, int C, int shared_from, float* k32_shared);
 
 /* Broadcast a C-vector into `rows` rows of a float matrix (row map as in l4p_gemm_desc.a_*): the learned
  * mask token of the memory mechanism (sparse_heads.py:262-265,418-427). */
@@ -385,7 +392,10 @@ int l4p_dpt_forward(l4p_engine* e, l4p_stream stream, const char* task, const l4
  * prompt tokens, key initialisation, sam_depth two-way layers + final attention, hyper-network MLPs, prompt feature for
  * the next window, memory tokens (need_history), up-scaling fused with the mask product, fused up-sample + soft-argmax.
  * enc_last float [P][C] (enc_features[-1] of the clip); hist float [N][P][C] per-query history tokens (read; rewritten in
- * place for the next window when need_history) — or, with hist_uniform (every track still has the same history rows: the
+ * place for the next window when need_history: the second temporal half of the processed tokens projected into rows
+ * [0, P/2), rows [P/2, P) set to the learned mask token; need_history == 2: the caller guarantees that rows [P/2, P) already
+ * hold the mask token - true for a buffer that was filled with it once and only ever passed to this function, which writes
+ * nothing else there - and the fill is skipped) — or, with hist_uniform (every track still has the same history rows: the
  * first window / the plain single-window forward), only its first P rows are read; hist_uniform == 2: rows [P/2, P) of every
  * track's history are identical (the state need_history leaves behind: the learned mask token), so the layer-0 projections
  * of those rows are computed once and copied (l4p_broadcast_block) — same values, half the key-side projection work of

@@ -7,13 +7,14 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
 int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T, int M, int C,
                        int act, hipStream_t stream);
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
-                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, hipStream_t stream);
+                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
+                         int x_period, int x_split, hipStream_t stream);
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
                         int W, hipStream_t stream);
 int launch_track_keys_init(int dtype, const float* enc, const float* hist, const float* pos, float* k32, void* kT,
-                           void* kP, int N, int P, int C, hipStream_t stream);
+                           void* kP, int N, int P, int C, int shared_from, float* k32_shared, hipStream_t stream);
 int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
                      long long group_off, hipStream_t stream);
 int launch_broadcast_block(void* base, long long off, long long bytes, long long stride, int n, hipStream_t stream);
@@ -34,8 +35,10 @@ int launch_track_commit(const float* w_traj, const float* w_vis, const float* w_
 extern "C" {
 
 int l4p_layernorm_res(l4p_stream s, int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta,
-                      float eps, void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2) {
-    return launch_layernorm_res(dtype, x, x_mod, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, (hipStream_t)s);
+                      float eps, void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2,
+                      const float* x_shared, int x_period, int x_split) {
+    return launch_layernorm_res(dtype, x, x_mod, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, x_shared, x_period,
+                                x_split, (hipStream_t)s);
 }
 int l4p_layernorm_ex(l4p_stream s, int dtype, const float* x, const float* gamma, const float* beta, float eps,
                      void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act) {
@@ -53,8 +56,8 @@ int l4p_track_tokens(l4p_stream s, const float* queries, const float* labels, co
                                feat_emb0, feat_emb1, tokens, N, C, T, H, W, (hipStream_t)s);
 }
 int l4p_track_keys_init(l4p_stream s, int dtype, const float* enc, const float* hist, const float* pos, float* k32,
-                        void* kT, void* kP, int N, int P, int C) {
-    return launch_track_keys_init(dtype, enc, hist, pos, k32, kT, kP, N, P, C, (hipStream_t)s);
+                        void* kT, void* kP, int N, int P, int C, int shared_from, float* k32_shared) {
+    return launch_track_keys_init(dtype, enc, hist, pos, k32, kT, kP, N, P, C, shared_from, k32_shared, (hipStream_t)s);
 }
 int l4p_fill_rows(l4p_stream s, float* out, const float* v, long long rows, int C, long long group_rows,
                   long long group_stride, long long group_off) {

@@ -19,13 +19,14 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
 int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T, int M, int C,
                        int act, hipStream_t stream);
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
-                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, hipStream_t stream);
+                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
+                         int x_period, int x_split, hipStream_t stream);
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
                         int W, hipStream_t stream);
 int launch_track_keys_init(int dtype, const float* enc, const float* hist, const float* pos, float* k32, void* kT,
-                           void* kP, int N, int P, int C, hipStream_t stream);
+                           void* kP, int N, int P, int C, int shared_from, float* k32_shared, hipStream_t stream);
 int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
                      long long group_off, hipStream_t stream);
 int launch_broadcast_block(void* base, long long off, long long bytes, long long stride, int n, hipStream_t stream);
@@ -189,9 +190,12 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
     void* kT = c.T(NP, Cc);
     void* kP = c.T(NP, Cc);
     const bool start_shared = Nk == 1 && N > 1;
+    // half_shared: rows [P/2, P) are formed for track 0 only (proj_half_shared reads no others); their float master, which the
+    // first layer's "keys = norm4(keys + ...)" needs for every track, lives in kh32 (that LayerNorm runs in place over k32)
+    float* kh32 = half_shared ? c.f32(P / 2, Cc) : nullptr;
     if (!c.rc && !c.dry)
         c.rc = launch_track_keys_init(c.dt, enc_last, hist, pos, start_shared ? ks32 : k32, start_shared ? ksT : kT,
-                                      start_shared ? ksP : kP, Nk, P, Cc, c.st);
+                                      start_shared ? ksP : kP, Nk, P, Cc, half_shared ? P / 2 : 0, kh32, c.st);
     float* cur32 = start_shared ? ks32 : k32;  // the key set the next projection reads
     void* curT = start_shared ? ksT : kT;
     void* curP = start_shared ? ksP : kP;
@@ -269,7 +273,7 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
             float* o32 = l + 1 < g.sam_depth ? k32 : nullptr;
             if (!c.rc && !c.dry)
                 c.rc = launch_layernorm_res(c.dt, cur32, shared ? P : 0, delta, c.Wf(lo + "norm4.g"), c.Wf(lo + "norm4.b"), 1e-5f, kT, o32,
-                                            (int)NP, Cc, pos, P, kP, c.st);
+                                            (int)NP, Cc, pos, P, kP, half_shared && l == 0 ? kh32 : nullptr, P, P / 2, c.st);
             if (shared) {  // from here on every track owns its keys
                 Nk = N;
                 curT = kT;
@@ -327,7 +331,10 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         const int half = P / 2;
         const int a_map[3] = {half, P, half}, c_map[3] = {half, P, 0};
         c.gemm(curT, (long long)N * half, Cc, Cc, "history_proj", Cc, true, ACT_NONE, nullptr, 0, hist, nullptr, Cc, a_map, c_map);
-        if (!c.rc && !c.dry) c.rc = launch_fill_rows(hist, c.Wf("history_mask_token"), (long long)N * half, Cc, half, P, half, c.st);
+        // (need_history == 2: the caller guarantees that rows [P/2, P) of every track still hold the mask token - nothing but
+        //  this fill ever writes them - so the 0.13 ms pass per 128-query window is skipped)
+        if (!c.rc && !c.dry && need_history != 2)
+            c.rc = launch_fill_rows(hist, c.Wf("history_mask_token"), (long long)N * half, Cc, half, P, half, c.st);
     }
 
     // --- output up-scaling (mask_decoder.py:58-66,136-137) on channels-last tokens ---

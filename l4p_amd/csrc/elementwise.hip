@@ -22,7 +22,9 @@ template <typename T, int MAXV, bool XT = false, int ROWS = 1, bool RES = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, T* out_T, float* out_f32, int M,
                                                         int C, const float* __restrict__ add, int add_mod, T* out_T2, int act,
-                                                        const T* __restrict__ delta = nullptr, int x_mod = 0) {
+                                                        const T* __restrict__ delta = nullptr, int x_mod = 0,
+                                                        const float* __restrict__ x_shared = nullptr, int x_period = 1,
+                                                        int x_split = 0) {
     // (x and the outputs are NOT restrict-qualified: the tracker normalises its key stream and the up-scaled activation in
     //  place; a wave has its whole row in registers - every store depends on the row statistics - before it writes)
     const int lane = threadIdx.x & 63;
@@ -36,7 +38,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int row = row0 + r < M ? row0 + r : M - 1;  // (a clamped duplicate row is loaded but never stored)
-        const f32x4* xr = (const f32x4*)(x + (long long)(RES && x_mod > 0 ? row % x_mod : row) * C);
+        // (RES, x_shared: rows p = row % x_period >= x_split come from the shared set x_shared[p - x_split] - the part of the
+        //  tracker's key stream that is still the same for every track)
+        const int prow = RES && x_shared ? row % x_period : 0;
+        const f32x4* xr = RES && x_shared && prow >= x_split
+                              ? (const f32x4*)(x_shared + (long long)(prow - x_split) * C)
+                              : (const f32x4*)(x + (long long)(RES && x_mod > 0 ? row % x_mod : row) * C);
         const f32x4* ar = out_T2 ? (const f32x4*)(add + (long long)(row % add_mod) * C) : nullptr;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
@@ -166,7 +173,13 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
 
 // y = LayerNorm(x[row % x_mod] + delta[row]) with the tracker's outputs (see layernorm_kernel RES)
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
-                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, hipStream_t stream) {
+                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
+                         int x_period, int x_split, hipStream_t stream) {
+    if (x_shared && (x_period <= 0 || x_split < 0 || x_split > x_period)) {
+        l4p_set_error("layernorm_res: shared rows need 0 <= x_split <= x_period, x_period > 0");
+        return L4P_E_INVALID;
+    }
+    if (!x_shared) x_period = 1, x_split = 0;
     if (C % 4 || C > 1536 || !delta_T || (out_T2 && (!add || add_mod <= 0))) {
         l4p_set_error("layernorm_res: C=%d must be a multiple of 4 and <= 1536, delta must be given (and out_T2 needs add/add_mod)", C);
         return L4P_E_INVALID;
@@ -176,17 +189,17 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
     if (dtype == L4P_BF16) {
         if (C <= 512)
             hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod);
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split);
         else
             hipLaunchKernelGGL((layernorm_kernel<bf16_t, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod);
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split);
     } else {
         if (C <= 512)
             hipLaunchKernelGGL((layernorm_kernel<float, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod);
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split);
         else
             hipLaunchKernelGGL((layernorm_kernel<float, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod);
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -101,12 +101,18 @@ __global__ void track_tokens_kernel(const float* __restrict__ queries, const flo
 // keys = enc_last (broadcast over queries) + history   (sparse_heads.py:341-346), emitted as
 // float (residual master), T (values) and T(keys + dense PE) (keys of the attention).
 // -------------------------------------------------------------------------------------------------
+// shared8 < per_q8 (later windows, hist_uniform == 2): rows from shared_from on are the same for every track (encoder feature +
+// the learned mask token), so only track 0 forms them - its float rows also go to k32_shared [P - shared_from][C], the residual
+// master l4p_layernorm_res reads for those rows of EVERY track (it normalises the key stream in place, so the shared rows cannot
+// live inside it).  The other tracks' rows past shared_from are neither read (hist) nor written.
 template <typename T>
 __global__ void track_keys_init_kernel(const float* __restrict__ enc, const float* __restrict__ hist,
                                        const float* __restrict__ pos, float* __restrict__ k32, T* __restrict__ kT,
-                                       T* __restrict__ kP, long long per_q8, long long total8) {
+                                       T* __restrict__ kP, long long per_q8, long long total8, long long shared8,
+                                       float* __restrict__ k32_shared) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
-        const long long e = (i % per_q8) * 8;
+        const long long e8 = i % per_q8, e = e8 * 8;
+        if (e8 >= shared8 && i >= per_q8) continue;
         float a[8], h[8], p[8], s[8];
         Vec8<float>::load(enc + e, a);
         Vec8<float>::load(hist + i * 8, h);
@@ -114,6 +120,7 @@ __global__ void track_keys_init_kernel(const float* __restrict__ enc, const floa
 #pragma unroll
         for (int k = 0; k < 8; ++k) a[k] += h[k];
         Vec8<float>::store(k32 + i * 8, a);
+        if (k32_shared && e8 >= shared8) Vec8<float>::store(k32_shared + (e8 - shared8) * 8, a);
         Vec8<T>::store(kT + i * 8, a);
 #pragma unroll
         for (int k = 0; k < 8; ++k) s[k] = a[k] + p[k];
@@ -661,19 +668,21 @@ int launch_track_tokens(const float* queries, const float* labels, const float* 
 }
 
 int launch_track_keys_init(int dtype, const float* enc, const float* hist, const float* pos, float* k32, void* kT,
-                           void* kP, int N, int P, int C, hipStream_t stream) {
-    if (C % 8) {
-        l4p_set_error("track_keys_init: C %% 8 != 0");
+                           void* kP, int N, int P, int C, int shared_from, float* k32_shared, hipStream_t stream) {
+    if (C % 8 || shared_from < 0 || shared_from > P || (shared_from > 0 && !k32_shared)) {
+        l4p_set_error("track_keys_init: C %% 8 != 0, or shared_from outside [0, P], or shared rows without k32_shared");
         return L4P_E_INVALID;
     }
     const long long per_q8 = (long long)P * C / 8, total8 = per_q8 * N;
+    const long long shared8 = shared_from > 0 ? (long long)shared_from * C / 8 : per_q8;  // (0: no shared rows)
+    if (shared_from == 0) k32_shared = nullptr;
     ProfScope prof(PROF_TRACK, stream, "track_keys_init");
     if (dtype == L4P_BF16)
         hipLaunchKernelGGL(track_keys_init_kernel<bf16_t>, dim3(GRID1D(total8, 16384)), dim3(256), 0, stream, enc, hist,
-                           pos, k32, (bf16_t*)kT, (bf16_t*)kP, per_q8, total8);
+                           pos, k32, (bf16_t*)kT, (bf16_t*)kP, per_q8, total8, shared8, k32_shared);
     else
         hipLaunchKernelGGL(track_keys_init_kernel<float>, dim3(GRID1D(total8, 16384)), dim3(256), 0, stream, enc, hist, pos,
-                           k32, (float*)kT, (float*)kP, per_q8, total8);
+                           k32, (float*)kT, (float*)kP, per_q8, total8, shared8, k32_shared);
     HIP_TRY(hipGetLastError());
     return 0;
 }

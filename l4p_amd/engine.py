@@ -136,7 +136,7 @@ class Engine:
         new_pfeat = torch.empty((N, Cc), **f32)
         _lib.check(self.lib.l4p_track_window_forward(
             self.handle, torch.cuda.current_stream().cuda_stream, C.byref(tcfg), enc_last.data_ptr(), hist.data_ptr(),
-            q_off.data_ptr(), labels.data_ptr(), pfeat.data_ptr(), plabel.data_ptr(), N, 1 if need_history else 0,
+            q_off.data_ptr(), labels.data_ptr(), pfeat.data_ptr(), plabel.data_ptr(), N, int(need_history),
             hu, ws.data_ptr(), ws.numel(), traj.data_ptr(), vis.data_ptr(), dep.data_ptr(),
             new_pfeat.data_ptr()), "l4p_track_window_forward")
         return traj, vis, dep, new_pfeat

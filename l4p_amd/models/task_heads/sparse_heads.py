@@ -175,8 +175,11 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         k32 = torch.empty((Nk * P, Cc), **f32)
         kT = torch.empty((Nk * P, Cc), dtype=td, device=dev)
         kP = torch.empty((Nk * P, Cc), dtype=td, device=dev)
-        _lib.check(lib.l4p_track_keys_init(_stream(), dt, _p(enc_last), _p(hist), _p(pos), _p(k32), _p(kT), _p(kP), Nk, P, Cc),
-                   "l4p_track_keys_init")
+        # half_shared: rows [P/2, P) are formed for track 0 only; their float master (read by layer 0's key LayerNorm for every
+        # track) goes to kh32 (csrc/api_trackwin.hip has the same sequence)
+        kh32 = torch.empty((P // 2, Cc), **f32) if half_shared else None
+        _lib.check(lib.l4p_track_keys_init(_stream(), dt, _p(enc_last), _p(hist), _p(pos), _p(k32), _p(kT), _p(kP), Nk, P, Cc,
+                                           P // 2 if half_shared else 0, _p(kh32) if half_shared else None), "l4p_track_keys_init")
 
         q32: Optional[torch.Tensor] = None
         qT, qP = tokT, tokT
@@ -228,7 +231,8 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             # (after the last layer nothing adds to the float keys any more: only the T copies are written)
             _lib.check(lib.l4p_layernorm_res(_stream(), dt, _p(k_res), P if shared else 0, _p(delta), _p(self._w(lo + "norm4.g")),
                                              _p(self._w(lo + "norm4.b")), 1e-5, _p(kT), _p(k32) if l + 1 < cfg.sam_depth else None,
-                                             N * P, Cc, _p(pos), P, _p(kP)), "l4p_layernorm_res")
+                                             N * P, Cc, _p(pos), P, _p(kP), _p(kh32) if (half_shared and l == 0) else None, P, P // 2),
+                       "l4p_layernorm_res")
             del delta, k_res
         # --- final tokens -> image attention (transformer.py:103-109) ---
         fq = self._proj(qP, "final.q", Dh)
@@ -261,8 +265,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             half = P // 2
             _gemm(kT, N * half, Cc, Cc, self._w("history_proj.w"), Cc, bias=self._w("history_proj.b"), out_f32=hist,
                   a_map=(half, P, half), c_map=(half, P, 0))
-            _lib.check(lib.l4p_fill_rows(_stream(), _p(hist), _p(self._w("history_mask_token")), N * half, Cc, half, P, half),
-                       "l4p_fill_rows")
+            if int(need_history) != 2:  # (2: rows [P/2, P) still hold the mask token, see l4p_track_window_forward)
+                _lib.check(lib.l4p_fill_rows(_stream(), _p(hist), _p(self._w("history_mask_token")), N * half, Cc, half, P, half),
+                           "l4p_fill_rows")
 
         # --- output up-scaling (mask_decoder.py:58-66,136-137) on channels-last tokens ---
         nt, nh, nw = cfg.grid
@@ -391,7 +396,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 # previous window's memory update) -> what layer 0 derives from those rows is computed once (L4P_TRACK_HALF_SHARE=0:
                 # every track on its own, the A/B and equality check)
                 hu = 1 if wi == 0 else (2 if os.environ.get("L4P_TRACK_HALF_SHARE", "1") != "0" else 0)
-                w_traj, w_vis, w_dep, new_pfeat = self._window(enc_last, hist, q_off, labels, pfeat, plabel, not last,
+                # (need_history = 2: hist was filled with the mask token above and only this loop writes it - the memory update
+                #  of a window rewrites rows [0, P/2) of each track, nothing touches rows [P/2, P) - so the re-fill is skipped)
+                w_traj, w_vis, w_dep, new_pfeat = self._window(enc_last, hist, q_off, labels, pfeat, plabel, 0 if last else 2,
                                                                hist_uniform=hu)
                 _lib.check(lib.l4p_track_commit(_stream(), _p(w_traj), _p(w_vis), _p(w_dep), _p(valid_t), _p(valid_n),
                                                 traj_b.data_ptr(), vis_b.data_ptr(), dep_b.data_ptr(), T, start, ws, nxt,
