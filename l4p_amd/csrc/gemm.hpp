@@ -102,13 +102,24 @@ __device__ __forceinline__ void gemm_epilogue_maskdot(const GemmParams& p, f32x4
             d1 += x * hv[1][c];
             d2 += x * hv[2][c];
         }
-        d0 += __shfl_xor(d0, 16);
-        d1 += __shfl_xor(d1, 16);
-        d2 += __shfl_xor(d2, 16);
+        // sum over the lane groups that share the 32-column chunk: v_permlane16_swap / v_permlane32_swap (gfx950 VALU lane
+        // exchanges; [0] + [1] = own + partner in every lane, the same two addends as a shuffle) instead of __shfl_xor, which
+        // is a ds_bpermute round trip through the LDS crossbar per value (24 dependent ones per wave and tile)
+        auto xsum16 = [](float d) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(d), __float_as_uint(d), false, false);
+            return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        };
+        auto xsum32 = [](float d) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d), __float_as_uint(d), false, false);
+            return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        };
+        d0 = xsum16(d0);
+        d1 = xsum16(d1);
+        d2 = xsum16(d2);
         if (NV == 8) {
-            d0 += __shfl_xor(d0, 32);
-            d1 += __shfl_xor(d1, 32);
-            d2 += __shfl_xor(d2, 32);
+            d0 = xsum32(d0);
+            d1 = xsum32(d1);
+            d2 = xsum32(d2);
         }
         if (writer && ok) {
             float* op = p.out_f32 + (long long)(nb >> 5) * 3 * p.M + m;  // [chunk][i][m]: 16 consecutive rows per store
