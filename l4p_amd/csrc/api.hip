@@ -21,6 +21,10 @@ void l4p_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
+                         void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
+                         int x_period, int x_split, hipStream_t stream, float* out_sum = nullptr);
+
 extern "C" {
 
 const char* l4p_last_error(void) { return g_err; }
@@ -281,6 +285,16 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
     if (rc) return rc;
 
     const float scale = 1.0f / sqrtf((float)Dh);
+    // Deferred residual sums (bf16 engine): "x = x + proj(...)" and "x = x + fc2(...)" (modeling_finetune.py:247-248) are not formed
+    // in the projections' epilogues - one round of tiles there means every CU reads and writes its slice of the float stream at
+    // the same time with the matrix pipe idle (measured: 27 of proj's 56 us, 38 of fc2's 143 us at batch 4) - but in the LayerNorm
+    // that follows, which reads x anyway (l4p_layernorm_res: y = LN(x + delta), x updated in place).  The projection leaves
+    // bias + product in the engine dtype, which is what the reference's autocast linear returns before the float sum.
+    // L4P_ENC_DEFER_RES=0: the fused-epilogue form (A/B aid).  The float engine keeps the fused form.
+    static const int defer_env = getenv("L4P_ENC_DEFER_RES") ? atoi(getenv("L4P_ENC_DEFER_RES")) : 1;
+    const bool defer = dt == L4P_BF16 && defer_env != 0 && C % 4 == 0 && C <= 1536;
+    void* const delta = w.qk;  // [M][C] engine dtype, in the q / k slot (free between the attention and the next QKV projection)
+    bool pending = false;
     char key[96];
     for (int l = 0; l < last && l < c.depth; ++l) {
 #define BW(var, suffix)                                  \
@@ -300,7 +314,13 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
         BW(fc2b, "fc2.b");
 #undef BW
         // x = x + proj(attn(norm1(x)))            modeling_finetune.py:247, :169-190
-        rc = launch_layernorm(dt, w.x, (const float*)ln1g, (const float*)ln1b, c.ln_eps, w.xn, nullptr, M, C, stream);
+        if (pending) {  // x += the previous block's MLP output (left in the engine dtype), then norm1: one pass over x
+            rc = launch_layernorm_res(dt, w.x, 0, delta, (const float*)ln1g, (const float*)ln1b, c.ln_eps, w.xn, nullptr, M, C, nullptr, 0,
+                                      nullptr, nullptr, 1, 0, stream, w.x);
+            pending = false;
+        } else {
+            rc = launch_layernorm(dt, w.x, (const float*)ln1g, (const float*)ln1b, c.ln_eps, w.xn, nullptr, M, C, stream);
+        }
         if (rc) return rc;
         GemmParams p;
         memset(&p, 0, sizeof(p));
@@ -334,15 +354,23 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
         p.N = C;
         p.K = C;
         p.bias = (const float*)projb;
-        p.res1 = w.x;
-        p.res_f32 = 1;
-        p.ldr = C;
-        p.out_f32 = w.x;
         p.ldc = C;
+        if (defer) {  // (q / k are dead once the attention has run: their slot takes the projection's output)
+            p.out_T = delta;
+        } else {
+            p.res1 = w.x;
+            p.res_f32 = 1;
+            p.ldr = C;
+            p.out_f32 = w.x;
+        }
         rc = launch_gemm(dt, 0, p, stream);
         if (rc) return rc;
         // x = x + fc2(gelu(fc1(norm2(x))))         modeling_finetune.py:248, :62-69
-        rc = launch_layernorm(dt, w.x, (const float*)ln2g, (const float*)ln2b, c.ln_eps, w.xn, nullptr, M, C, stream);
+        if (defer)
+            rc = launch_layernorm_res(dt, w.x, 0, delta, (const float*)ln2g, (const float*)ln2b, c.ln_eps, w.xn, nullptr, M, C, nullptr, 0,
+                                      nullptr, nullptr, 1, 0, stream, w.x);
+        else
+            rc = launch_layernorm(dt, w.x, (const float*)ln2g, (const float*)ln2b, c.ln_eps, w.xn, nullptr, M, C, stream);
         if (rc) return rc;
         memset(&p, 0, sizeof(p));
         p.A = w.xn;
@@ -367,13 +395,22 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
         p.N = C;
         p.K = c.mlp_hidden;
         p.bias = (const float*)fc2b;
-        p.res1 = w.x;
-        p.res_f32 = 1;
-        p.ldr = C;
-        p.out_f32 = w.x;
         p.ldc = C;
         p.splitk = enc_fc2_splitk(e, (size_t)M);
         p.partial = p.splitk > 1 ? w.sk : nullptr;
+        // the MLP's residual rides into the NEXT block's norm1 unless x itself is needed first (a tap after this block, the last
+        // block) or the split-K finish pass forms the sum anyway
+        bool tap_next = l + 1 >= last;
+        for (int i = 0; i < n_taps; ++i) tap_next = tap_next || tap_layer[i] == l + 1;
+        if (defer && !tap_next && p.splitk <= 1) {
+            p.out_T = delta;
+            pending = true;
+        } else {
+            p.res1 = w.x;
+            p.res_f32 = 1;
+            p.ldr = C;
+            p.out_f32 = w.x;
+        }
         rc = launch_gemm(dt, 0, p, stream);
         if (rc) return rc;
         if (l + 1 < c.depth) {

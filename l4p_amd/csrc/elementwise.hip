@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                                                         int C, const float* __restrict__ add, int add_mod, T* out_T2, int act,
                                                         const T* __restrict__ delta = nullptr, int x_mod = 0,
                                                         const float* __restrict__ x_shared = nullptr, int x_period = 1,
-                                                        int x_split = 0) {
+                                                        int x_split = 0, float* out_sum = nullptr) {
     // (x and the outputs are NOT restrict-qualified: the tracker normalises its key stream and the up-scaled activation in
     //  place; a wave has its whole row in registers - every store depends on the row statistics - before it writes)
     const int lane = threadIdx.x & 63;
@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                     }
                 }
                 if (out_f32) ((f32x4*)(out_f32 + (long long)row * C))[idx] = y;
+                if constexpr (RES) {  // pre-norm residual stream (the encoder): the SUM x + delta is what lives on, y is only xn
+                    if (out_sum) ((f32x4*)(out_sum + (long long)row * C))[idx] = v[r][i];
+                }
                 if (out_T) {
                     if (sizeof(T) == 2) {
                         bf16x4 o;
@@ -171,10 +174,11 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
     return 0;
 }
 
-// y = LayerNorm(x[row % x_mod] + delta[row]) with the tracker's outputs (see layernorm_kernel RES)
+// y = LayerNorm(x[row % x_mod] + delta[row]) with the tracker's outputs (see layernorm_kernel RES); out_sum (may alias x when
+// x_mod = 0): the float sum itself - the encoder's pre-norm residual stream, where y is only the next linear's input
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
                          void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
-                         int x_period, int x_split, hipStream_t stream) {
+                         int x_period, int x_split, hipStream_t stream, float* out_sum) {
     if (x_shared && (x_period <= 0 || x_split < 0 || x_split > x_period)) {
         l4p_set_error("layernorm_res: shared rows need 0 <= x_split <= x_period, x_period > 0");
         return L4P_E_INVALID;
@@ -189,17 +193,17 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
     if (dtype == L4P_BF16) {
         if (C <= 512)
             hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split);
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum);
         else
             hipLaunchKernelGGL((layernorm_kernel<bf16_t, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split);
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum);
     } else {
         if (C <= 512)
             hipLaunchKernelGGL((layernorm_kernel<float, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split);
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum);
         else
             hipLaunchKernelGGL((layernorm_kernel<float, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split);
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum);
     }
     HIP_TRY(hipGetLastError());
     return 0;
