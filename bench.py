@@ -510,7 +510,7 @@ def main():
         mfma = [k for k in ("gemm", "conv3d", "attention") if k in classes]
         dom = max(mfma, key=lambda k: classes[k]["ms_per_step"])
         kern = {"gemm": "gemm8p_kernel<0> / gemm_kernel<bf16,MODE0> (linear / 1x1x1 conv / ConvTranspose GEMM)",
-                "conv3d": "gemm8p_kernel<1> / gemm_kernel<bf16,MODE1> (implicit-GEMM 3x3x3 conv)",
+                "conv3d": "conv3_halo_kernel (LDS-halo 3x3x3 conv) / gemm_kernel<bf16,MODE1> (implicit-GEMM 3x3x3 conv, low-resolution levels)",
                 "attention": "attn_kernel<bf16,96,64>"}
 
         # HBM bytes per launch of the class from the committed PMC passes (profiles/r01_c3_hbm_traffic.*: rocprofv3
