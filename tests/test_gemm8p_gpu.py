@@ -90,6 +90,7 @@ def test_gemm8p_gelu_and_f32_residual_inplace(dev):
 
 
 @pytest.mark.parametrize("M,N,K,sk", [(2048, 1408, 6144, 5),   # the batch-1 MLP-out projection: 48 tiles x 5 slices, 19.2 k-tiles each
+                                        (2048, 1408, 6144, 4),   # as the encoder runs it: 64 tiles of 256x192 x 4 slices = 256 workgroups
                                         (2304, 1416, 4104, 4)])  # ragged M / N / K (64.1 k-tiles: slices of 16, 16, 16, 17)
 def test_gemm8p_splitk_f32_residual_inplace(dev, M, N, K, sk):
     """Split-K on the 8-phase kernel: slices of the 256x256 tiles leave float partials, splitk_finish_kernel sums them in
@@ -115,6 +116,8 @@ def test_gemm8p_splitk_f32_residual_inplace(dev, M, N, K, sk):
         _lib.check(_lib.load().l4p_gemm(torch.cuda.current_stream().cuda_stream, MODE, C.byref(d)), "l4p_gemm")
     tags = [ln[1] for ln in p.lines if ln[0] == "gemm"]
     assert tags and all(f" 8p sk{sk} " in t for t in tags), tags
+    if (M, N, K, sk) == (2048, 1408, 6144, 4):
+        assert all("t256x192" in t for t in tags), tags  # (gemm_launch.inc: the split-K form of the 4 x 6 wave tile)
     check(x, a_ref @ w_ref.t() + bias + res, MODE, False)
     # run-to-run bit-reproducible (fixed summation order of the slices)
     x2 = res.clone().cuda()
