@@ -120,12 +120,12 @@ def read_prof(lib):
     return out
 
 
-def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 4, sample_queries: int = 8):
+def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 0, sample_queries: int = 8):
     """Oracle (plain PyTorch fp32 port of the reference algorithm) on the host cores, 1 clip of the SAME workload, BOUNDED
-    sample: patch embed + ``sample_blocks`` of the ``depth`` identical encoder blocks are timed and the block time is scaled
-    by depth / sample_blocks; the dense heads are timed in full on the features of that shortened encoder; the tracker port
-    is timed on ``sample_queries`` of the clip's queries and scaled by N / sample_queries (tracks are independent: its cost
-    is linear in N)."""
+    sample (~20 s of CPU work): patch embed + EVERY encoder block (``sample_blocks`` = 0; n > 0: the first n of the ``depth``
+    identical blocks are timed and scaled by depth / n) and the dense heads are timed in full; the tracker port is timed on
+    ``sample_queries`` of the clip's queries and scaled by N / sample_queries (tracks are independent: its cost is linear
+    in N)."""
     from oracle import l4p_oracle as orc
 
     threads = min(os.cpu_count() or 1, 64)  # torch CPU ops stop scaling (and regress) far below 256 threads
@@ -138,6 +138,7 @@ def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 4, sample_queri
         t_embed = time.time() - t0
         t0 = time.time()
         x = feats[0]
+        sample_blocks = cfg.depth if sample_blocks <= 0 else min(sample_blocks, cfg.depth)
         for i in range(sample_blocks):
             x = orc.encoder_block(sd, f"video_encoder.blocks.{i}.", x, cfg.heads, cfg.ln_eps)
         t_blocks = (time.time() - t0) / sample_blocks
@@ -159,7 +160,7 @@ def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 4, sample_queri
     dt = t_embed + t_blocks * cfg.depth + t_heads + t_track
     return {"value": round(16.0 / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": (f"1 clip (16x224x224), tasks={'+'.join(tasks)}: oracle (plain PyTorch fp32 port of the reference) on the host CPU; "
-                       f"timed patch-embed {t_embed:.2f}s + {sample_blocks}/{cfg.depth} encoder blocks ({t_blocks:.2f}s each, scaled x{cfg.depth}) "
+                       f"timed patch-embed {t_embed:.2f}s + {sample_blocks}/{cfg.depth} encoder blocks ({t_blocks:.2f}s each{'' if sample_blocks == cfg.depth else f', scaled x{cfg.depth}'}) "
                        f"+ dense heads in full {t_heads:.2f}s{track_note} -> {dt:.1f}s per clip")}
 
 
