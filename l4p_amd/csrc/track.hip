@@ -201,7 +201,48 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, 
     for (int i = tid; i < 6 * hd; i += 256) qs[(i / hd) * 96 + (i % hd)] = (float)qp[(long long)(i / hd) * D + (i % hd)];
     __syncthreads();
     // scores
-    for (int p = tid; p < P; p += 256) {
+    // bf16, head dims in whole 16-byte chunks: a thread requests its WHOLE key row (hd / 8 chunks of 16 bytes) at once and the next
+    // row before it uses the current one - the phase is bound by memory latency (a thread reads its rows alone), so what counts
+    // is bytes in flight per thread: 2 x 176 here against 32 in the batched form below.  Same products in the same order.
+    constexpr int MAXCH = 12;  // (174 VGPRs: two workgroups per CU instead of the three LDS would allow - measured equal to a
+                               //  168-register build with three; the phase is VALU-bound past this point: 112.7 vs 122 us at 64 tracks)
+    const bool whole_rows = sizeof(T) == 2 && (hd & 7) == 0 && (hd >> 3) <= MAXCH;
+    if (whole_rows) {
+        const int nch = hd >> 3;
+        bf16x8 cur[MAXCH], nxt[MAXCH];
+        auto load_row = [&](int p, bf16x8 (&r)[MAXCH]) {
+            const bf16x8* kr = (const bf16x8*)((const bf16_t*)kp + (long long)p * D);
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c)
+                if (c < nch) r[c] = kr[c];
+        };
+        if (tid < P) load_row(tid, cur);
+        for (int p = tid; p < P; p += 256) {
+            if (p + 256 < P) load_row(p + 256, nxt);
+            float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) {
+                if (c < nch) {
+                    float kv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) kv[e] = (float)cur[c][e];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const f32x4 q0 = *(const f32x4*)(qs + i * 96 + 8 * c), q1 = *(const f32x4*)(qs + i * 96 + 8 * c + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i] += q0[e] * kv[e];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i] += q1[e] * kv[4 + e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sc[i * P + p] = acc[i] * scale;
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) cur[c] = nxt[c];
+        }
+    }
+    for (int p = tid; p < P && !whole_rows; p += 256) {
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const T* kr = kp + (long long)p * D;
         // the key row is requested in batches of 4 loads before any is used (a thread reads its row alone: without the
@@ -265,12 +306,12 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, 
         for (int e = 0; e < 4; ++e) o[i][e] = 0.f;
     if (kg < nkg) {
         int p = kg;
-        for (; p + 3 * nkg < P; p += 4 * nkg) {  // four value rows in flight (same summation order as the plain loop)
-            float vv[4][4];
+        for (; p + 7 * nkg < P; p += 8 * nkg) {  // eight value rows in flight (same summation order as the plain loop)
+            float vv[8][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Vec4<T>::load(vp + (long long)(p + u * nkg) * D + cg * 4, vv[u]);
+            for (int u = 0; u < 8; ++u) Vec4<T>::load(vp + (long long)(p + u * nkg) * D + cg * 4, vv[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const float w = sc[i * P + p + u * nkg];
