@@ -395,7 +395,8 @@ int l4p_dpt_forward(l4p_engine* e, l4p_stream stream, const char* task, const l4
  * place for the next window when need_history: the second temporal half of the processed tokens projected into rows
  * [0, P/2), rows [P/2, P) set to the learned mask token; need_history == 2: the caller guarantees that rows [P/2, P) already
  * hold the mask token - true for a buffer that was filled with it once and only ever passed to this function, which writes
- * nothing else there - and the fill is skipped) — or, with hist_uniform (every track still has the same history rows: the
+ * nothing else there - and the fill is skipped; need_history == 3: hist [N][P][C] receives the projection of ALL P processed
+ * tokens of every track, the reference's <task>_enc_features_with_track_history_bnpc of a plain single-window forward) — or, with hist_uniform (every track still has the same history rows: the
  * first window / the plain single-window forward), only its first P rows are read; hist_uniform == 2: rows [P/2, P) of every
  * track's history are identical (the state need_history leaves behind: the learned mask token), so the layer-0 projections
  * of those rows are computed once and copied (l4p_broadcast_block) — same values, half the key-side projection work of

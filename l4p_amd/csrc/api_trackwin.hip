@@ -327,7 +327,11 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
 
     // --- memory tokens for the next window (sparse_heads.py:406-448,660-665): project the 2nd temporal half of the
     //     processed video tokens into the 1st half of the history, pad the rest with the learned mask token ---
-    if (need_history) {
+    if (need_history == 3) {
+        // the plain single-window forward returns the projection of EVERY processed token (sparse_heads.py:560-569, :658-665:
+        // <task>_enc_features_with_track_history_bnpc): hist [N][P][C] receives it, no mask-token rows
+        c.gemm(curT, NP, Cc, Cc, "history_proj", Cc, true, ACT_NONE, nullptr, 0, hist, nullptr, Cc);
+    } else if (need_history) {
         const int half = P / 2;
         const int a_map[3] = {half, P, half}, c_map[3] = {half, P, 0};
         c.gemm(curT, (long long)N * half, Cc, Cc, "history_proj", Cc, true, ACT_NONE, nullptr, 0, hist, nullptr, Cc, a_map, c_map);

@@ -261,7 +261,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
 
         # --- memory tokens for the next window (sparse_heads.py:406-448,660-665): project the 2nd temporal half of the
         #     processed video tokens into the 1st half of the history, pad the rest with the learned mask token ---
-        if need_history:
+        if int(need_history) == 3:  # every processed token projected (the single-window forward's ..._with_track_history_bnpc)
+            _gemm(kT, N * P, Cc, Cc, self._w("history_proj.w"), Cc, bias=self._w("history_proj.b"), out_f32=hist)
+        elif need_history:
             half = P // 2
             _gemm(kT, N * half, Cc, Cc, self._w("history_proj.w"), Cc, bias=self._w("history_proj.b"), out_f32=hist,
                   a_map=(half, P, half), c_map=(half, P, 0))
@@ -451,9 +453,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         the sliding tracker it attends to the raw enc_features[-1] (NO history / mask-token term), takes the caller's point
         labels as they are, starts from zero prompt features unless they are passed in, and returns the window's estimates
         for every frame (no validity masking, no -10 visibility fill).
-        Returned: traj [B,N,2,T], vis [B,N,1,T], depth [B,N,1,T], <task>_prompt_features_bnc [B,N,C].  The reference also
-        returns <task>_enc_features_with_track_history_bnpc ([B,N,2048,1408] floats, 11.5 MB per query) which no consumer of
-        a single-window forward reads; it is not materialised here."""
+        Returned: traj [B,N,2,T], vis [B,N,1,T], depth [B,N,1,T], <task>_prompt_features_bnc [B,N,C] and, as the reference
+        (sparse_heads.py:560-569), <task>_enc_features_with_track_history_bnpc [B,N,P,C] float - the projection of every
+        processed video token (11.5 MB per query at the full geometry: ``self.return_track_history = False`` skips it)."""
         if self._rt is None:
             raise RuntimeError("tracker head has no weights: call load_state_dict on the model first")
         lib = _lib.load()
@@ -469,6 +471,8 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         dep_all = torch.empty(B, N, 1, T, **f32)
         pf_all = torch.empty(B, N, Cc, **f32)
         zero_hist = torch.zeros(P, Cc, **f32)  # keys = enc_features[-1] + 0: one key set shared by all tracks
+        want_hist = bool(getattr(self, "return_track_history", True))
+        hist_all = torch.empty(B, N, P, Cc, **f32) if want_hist else None
         for b in range(B):
             q = track_2d_pointquerries_bn3[b].to(**f32).contiguous()
             labels = track_2d_pointlabels_bn[b].to(**f32).contiguous()
@@ -476,8 +480,18 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                      else track_2d_promptfeatures_bnc[b].to(**f32).contiguous())
             plabel = (torch.zeros(N, **f32) if track_2d_promptfeaturelabels_bn is None
                       else track_2d_promptfeaturelabels_bn[b].to(**f32).contiguous())
-            w_traj, w_vis, w_dep, new_pfeat = self._window(enc[b].contiguous(), zero_hist, q, labels, pfeat, plabel, False,
-                                                           hist_uniform=True)
+            if want_hist:
+                # hist [N*P, C]: its first P rows are the (zero) history the shared keys are built from, the call then
+                # overwrites all of it with the projection of the processed tokens (need_history = 3)
+                hist = hist_all[b].view(N * P, Cc)
+                hist[:P].zero_()
+            else:
+                hist = zero_hist
+            w_traj, w_vis, w_dep, new_pfeat = self._window(enc[b].contiguous(), hist, q, labels, pfeat, plabel,
+                                                           3 if want_hist else 0, hist_uniform=True)
             traj_all[b], vis_all[b, :, 0], dep_all[b, :, 0], pf_all[b] = w_traj, w_vis, w_dep, new_pfeat
-        return {f"{self.task_name}_traj_est_bn2t": traj_all, f"{self.task_name}_vis_est_bn1t": vis_all,
-                f"{self.task_name}_depth_est_bn1t": dep_all, f"{self.task_name}_prompt_features_bnc": pf_all}
+        out = {f"{self.task_name}_traj_est_bn2t": traj_all, f"{self.task_name}_vis_est_bn1t": vis_all,
+               f"{self.task_name}_depth_est_bn1t": dep_all, f"{self.task_name}_prompt_features_bnc": pf_all}
+        if want_hist:
+            out[f"{self.task_name}_enc_features_with_track_history_bnpc"] = hist_all
+        return out

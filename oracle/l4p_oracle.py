@@ -831,7 +831,9 @@ class OracleModel:
                 o = track_single_window(self.sd, cfg, feats[-1], batch["track_2d_pointquerries_bn3"][0],
                                         batch["track_2d_pointlabels_bn"][0], None, None)
                 out.update({"track_2d_traj_est_bn2t": o["traj"][None], "track_2d_vis_est_bn1t": o["vis"][None],
-                            "track_2d_depth_est_bn1t": o["depth"][None], "track_2d_prompt_features_bnc": o["prompt_features"][None]})
+                            "track_2d_depth_est_bn1t": o["depth"][None], "track_2d_prompt_features_bnc": o["prompt_features"][None],
+                            # processed video tokens with the track history, projected (sparse_heads.py:560-569, :658-665)
+                            "track_2d_enc_features_with_track_history_bnpc": o["history"][None]})
             else:
                 out.update(self.dense_single(task, feats, batch["intrinsics_b44t"]))
         return out

@@ -44,7 +44,7 @@ def main():
         oout = om.forward(batch, tasks)
     npz = {}
     for k, v in out.items():
-        if not torch.is_tensor(v) or k.endswith("_bnpc"):
+        if not torch.is_tensor(v):
             continue
         e = rel_err(oout[k], v)
         assert e <= 1e-4, (k, e)
@@ -52,6 +52,7 @@ def main():
         npz[k] = v.reshape(-1)[sample_indices(v.numel())].numpy() if v.numel() > 4096 else v.numpy()
         print(k, tuple(v.shape), f"oracle rel err {e:.2e}")
     assert "track_2d_prompt_features_bnc" in npz and "track_2d_vis_est_bn1t" in npz
+    assert "track_2d_enc_features_with_track_history_bnpc" in npz  # ([1, N, P, C]: 4096 sampled values)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "mini_T16_single_window.npz"), **npz)
 
 
