@@ -136,6 +136,55 @@ def test_batch4_bf16_equals_four_batch1_forwards_and_goldens(dev, full_sd):
     assert not bad, bad
 
 
+def test_batch8_per_gpu_batch_of_configs3(dev, full_sd):
+    """configs[3] runs 8 clips per GPU (what `bench.py --gpus N` gives every rank): batch 8 selects other tile forms than batch 4
+    (256 x 192 tiles for the N = 1408 projections at 512 tiles, 4 attention tiles per persistent workgroup, 1.5-round GEMMs).
+    All heads, bf16: clip 0 (the golden clip) against the reference's goldens at the bf16 gates, clips 3 and 7 against their own
+    batch-1 forwards (integer tracker state identical, floats at rounding level)."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "full_T16_all.npz"))
+    m = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision="bf16")
+    m.l4p_model.task_heads["camray"].use_intrinsics = True
+    m.load_state_dict({"l4p_model." + k: v for k, v in full_sd.items()})
+    head = m.l4p_model.task_heads["track_2d"]
+    bs = [make_batch(16, 8, seed=1234 + i) for i in range(8)]
+    b8 = {k: torch.cat([b[k] for b in bs], dim=0) for k in bs[0]}
+    with torch.no_grad():
+        head.trace = []
+        out8 = m.forward({k: v.clone() for k, v in b8.items()}, ALL)
+        trace8 = head.trace
+        f8 = {li: out8["enc_features_bpc_2dlist"][0].f32(li).float().cpu() for li in (36, 40)}
+        out8 = {k: out8[k].float().cpu() for k in OUT_KEYS}
+        assert len(trace8) == 8
+        report = {}
+        for i in (3, 7):
+            head.trace = []
+            o1 = m.forward({k: v.clone() for k, v in bs[i].items()}, ALL)
+            torch.cuda.synchronize()
+            for li in (36, 40):
+                f1 = o1["enc_features_bpc_2dlist"][0].f32(li).float().cpu()
+                report[(i, f"feat{li}")] = _rel_l2(f8[li].reshape(8, -1)[i], f1.reshape(-1))
+            for k in OUT_KEYS:
+                report[(i, k)] = _rel_l2(out8[k][i], o1[k].float().cpu()[0])
+            assert trace8[i]["clip"] == i and len(head.trace) == 1
+            for name in ("labels", "prompt_labels", "valid_t"):
+                assert torch.equal(trace8[i][name].cpu(), head.trace[0][name].cpu()), (i, name)
+    head.trace = None
+    print("B=8 vs B=1 rel-L2:", {f"{i}:{k}": f"{v:.2e}" for (i, k), v in report.items()})
+    bad = {k: v for k, v in report.items() if v > (BF16_GATE_FEATURES if k[1].startswith("feat") else BF16_GATE_HEADS) / 2}
+    assert not bad, bad
+    rep0 = {}
+    for li in (36, 40):
+        f = f8[li].reshape(8, -1)[0]
+        rep0[f"feat{li}"] = _rel_l2(f[sample_indices(f.numel())], torch.from_numpy(gold[f"feat{li}"]))
+    for k in OUT_KEYS:
+        y = out8[k][0].reshape(-1)
+        g = torch.from_numpy(gold[k]).reshape(-1)
+        rep0[k] = _rel_l2(y[sample_indices(y.numel())] if y.numel() > 4096 else y, g)
+    print("B=8 clip 0 vs goldens:", {k: f"{v:.2e}" for k, v in rep0.items()})
+    bad = {k: v for k, v in rep0.items() if v > bf16_gate(k)}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("precision", ["32-true", "bf16"])
 def test_full_size_two_windows_vs_reference_goldens(dev, full_sd, precision):
     """The windowed path (configs[4]) at the REAL geometry: 24 frames = 2 overlapping windows through the reference itself
