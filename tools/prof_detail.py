@@ -1,5 +1,6 @@
 """Per-shape kernel time table for one bench workload (event profiler, l4p_prof_detail).
-usage: python tools/prof_detail.py [c2|c3|c5|prep|demo] [steps]   (demo: 64 frames, 625 queries, depth+flow+mask+tracks)"""
+usage: python tools/prof_detail.py [c2|c3|c3b8|c5|prep|demo] [steps]   (demo: 64 frames, 625 queries, depth+flow+mask+tracks;
+c3b8: all heads at batch 8, the per-GPU batch of configs[3] / of every rank of `bench.py --gpus N`)"""
 import contextlib
 import ctypes as C
 import os
@@ -60,7 +61,7 @@ def main():
                 return forward_windows_sharded(model.l4p_model, data, tasks, 0, 1, group=4)
     else:
         tasks = ["depth"] if wl == "c2" else list(bench.ALL_TASKS)
-        B = 1 if wl == "c2" else 4
+        B = 1 if wl == "c2" else (8 if wl == "c3b8" else 4)
         model, data, _ = bench.build_workload(tasks, B, 64, dev)
 
         def run():
