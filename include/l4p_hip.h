@@ -130,7 +130,9 @@ typedef struct l4p_gemm_desc {
      * 0 is treated as 1. */
     float q_scale;
     /* tuning aid, normally 0.  bit 0: use the generic run-time-dispatched epilogue even where a lean specialisation exists
-     * (set by the launcher when L4P_EPI_GENERIC=1: in-run A/B of the two forms). */
+     * (set by the launcher when L4P_EPI_GENERIC=1: in-run A/B of the two forms).  bit 1: a split-K launch leaves its float
+     * partials [splitk][M][N] to the caller and runs no finish pass (bias / residual / outputs of the descriptor are ignored):
+     * the encoder sums them in the LayerNorm that follows the batch-1 MLP-out projection. */
     int tuning;
 } l4p_gemm_desc;
 

@@ -23,7 +23,8 @@ void l4p_set_error(const char* fmt, ...) {
 
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
                          void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
-                         int x_period, int x_split, hipStream_t stream, float* out_sum = nullptr);
+                         int x_period, int x_split, hipStream_t stream, float* out_sum = nullptr, const float* part = nullptr,
+                         int nsplit = 0, const float* pbias = nullptr);
 
 extern "C" {
 
@@ -294,7 +295,10 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
     static const int defer_env = getenv("L4P_ENC_DEFER_RES") ? atoi(getenv("L4P_ENC_DEFER_RES")) : 1;
     const bool defer = dt == L4P_BF16 && defer_env != 0 && C % 4 == 0 && C <= 1536;
     void* const delta = w.qk;  // [M][C] engine dtype, in the q / k slot (free between the attention and the next QKV projection)
+    static const int sk_in_ln = getenv("L4P_ENC_SK_IN_LN") ? atoi(getenv("L4P_ENC_SK_IN_LN")) : 1;  // (0: finish pass, A/B aid)
     bool pending = false;
+    int pending_sk = 0;
+    const float* pending_bias = nullptr;
     char key[96];
     for (int l = 0; l < last && l < c.depth; ++l) {
 #define BW(var, suffix)                                  \
@@ -318,6 +322,10 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
             rc = launch_layernorm_res(dt, w.x, 0, delta, (const float*)ln1g, (const float*)ln1b, c.ln_eps, w.xn, nullptr, M, C, nullptr, 0,
                                       nullptr, nullptr, 1, 0, stream, w.x);
             pending = false;
+        } else if (pending_sk > 0) {  // ... left as split-K partials: bias + slices summed here instead of in a finish pass
+            rc = launch_layernorm_res(dt, w.x, 0, nullptr, (const float*)ln1g, (const float*)ln1b, c.ln_eps, w.xn, nullptr, M, C,
+                                      nullptr, 0, nullptr, nullptr, 1, 0, stream, w.x, w.sk, pending_sk, pending_bias);
+            pending_sk = 0;
         } else {
             rc = launch_layernorm(dt, w.x, (const float*)ln1g, (const float*)ln1b, c.ln_eps, w.xn, nullptr, M, C, stream);
         }
@@ -405,6 +413,12 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
         if (defer && !tap_next && p.splitk <= 1) {
             p.out_T = delta;
             pending = true;
+        } else if (defer && sk_in_ln && !tap_next && p.splitk > 1 && p.splitk <= 16) {
+            // batch 1 / 2: the K slices' float partials stay in w.sk and the next norm1 sums them (no finish pass: it read the
+            // partials and read + wrote x only for the LayerNorm to read x again)
+            p.tuning |= 2;
+            pending_sk = p.splitk;
+            pending_bias = (const float*)fc2b;
         } else {
             p.res1 = w.x;
             p.res_f32 = 1;

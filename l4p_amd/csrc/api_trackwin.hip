@@ -20,7 +20,8 @@ int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const flo
                        int act, hipStream_t stream);
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
                          void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
-                         int x_period, int x_split, hipStream_t stream, float* out_sum = nullptr);
+                         int x_period, int x_split, hipStream_t stream, float* out_sum = nullptr, const float* part = nullptr,
+                         int nsplit = 0, const float* pbias = nullptr);
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,

@@ -24,7 +24,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                                                         int C, const float* __restrict__ add, int add_mod, T* out_T2, int act,
                                                         const T* __restrict__ delta = nullptr, int x_mod = 0,
                                                         const float* __restrict__ x_shared = nullptr, int x_period = 1,
-                                                        int x_split = 0, float* out_sum = nullptr) {
+                                                        int x_split = 0, float* out_sum = nullptr,
+                                                        const float* __restrict__ part = nullptr, int nsplit = 0,
+                                                        const float* __restrict__ pbias = nullptr) {
     // (x and the outputs are NOT restrict-qualified: the tracker normalises its key stream and the up-scaled activation in
     //  place; a wave has its whole row in registers - every store depends on the row statistics - before it writes)
     const int lane = threadIdx.x & 63;
@@ -57,7 +59,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                 v[r][i] = in ? xr[idx] : z;
             }
             if constexpr (RES) {
-                if (sizeof(T) == 2) {
+                if (part) {  // the addend is bias + the float partials of a split-K projection, summed in slice order
+                    f32x4 d = pbias ? ((const f32x4*)pbias)[in ? idx : 0] : z;
+                    for (int sl = 0; sl < nsplit; ++sl) {
+                        const f32x4 t = ((const f32x4*)(part + ((long long)sl * M + row) * C))[in ? idx : 0];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[k] += t[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[r][i][k] += in ? d[k] : 0.f;
+                } else if (sizeof(T) == 2) {
                     const bf16x4 t = ((const bf16x4*)((const bf16_t*)delta + (long long)row * C))[in ? idx : 0];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[r][i][k] += in ? (float)t[k] : 0.f;
@@ -175,17 +186,23 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
 }
 
 // y = LayerNorm(x[row % x_mod] + delta[row]) with the tracker's outputs (see layernorm_kernel RES); out_sum (may alias x when
-// x_mod = 0): the float sum itself - the encoder's pre-norm residual stream, where y is only the next linear's input
+// x_mod = 0): the float sum itself - the encoder's pre-norm residual stream, where y is only the next linear's input;
+// part / nsplit / pbias: the addend is bias + nsplit float partials [nsplit][M][C] of a split-K projection instead of delta
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
                          void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
-                         int x_period, int x_split, hipStream_t stream, float* out_sum) {
+                         int x_period, int x_split, hipStream_t stream, float* out_sum, const float* part, int nsplit,
+                         const float* pbias) {
+    if (part && (nsplit < 1 || nsplit > 16)) {
+        l4p_set_error("layernorm_res: 1 <= nsplit <= 16 slices of float partials");
+        return L4P_E_INVALID;
+    }
     if (x_shared && (x_period <= 0 || x_split < 0 || x_split > x_period)) {
         l4p_set_error("layernorm_res: shared rows need 0 <= x_split <= x_period, x_period > 0");
         return L4P_E_INVALID;
     }
     if (!x_shared) x_period = 1, x_split = 0;
-    if (C % 4 || C > 1536 || !delta_T || (out_T2 && (!add || add_mod <= 0))) {
-        l4p_set_error("layernorm_res: C=%d must be a multiple of 4 and <= 1536, delta must be given (and out_T2 needs add/add_mod)", C);
+    if (C % 4 || C > 1536 || (!delta_T && !part) || (out_T2 && (!add || add_mod <= 0))) {
+        l4p_set_error("layernorm_res: C=%d must be a multiple of 4 and <= 1536, delta or partials must be given (and out_T2 needs add/add_mod)", C);
         return L4P_E_INVALID;
     }
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d res T2%d f32%d", M, C, out_T2 != nullptr, out_f32 != nullptr);
@@ -193,17 +210,17 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
     if (dtype == L4P_BF16) {
         if (C <= 512)
             hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum);
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias);
         else
             hipLaunchKernelGGL((layernorm_kernel<bf16_t, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum);
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias);
     } else {
         if (C <= 512)
             hipLaunchKernelGGL((layernorm_kernel<float, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum);
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias);
         else
             hipLaunchKernelGGL((layernorm_kernel<float, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum);
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias);
     }
     HIP_TRY(hipGetLastError());
     return 0;
