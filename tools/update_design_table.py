@@ -1,0 +1,56 @@
+"""Rewrite the round's measurement table in DESIGN.md (between the R3TABLE markers) from profiles/<tag>_*_bench_line.json.
+usage: python tools/update_design_table.py [tag=r03]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+P = os.path.join(ROOT, "profiles")
+
+
+def L(n):
+    return json.load(open(os.path.join(P, f"{tag}_{n}_bench_line.json")))
+
+
+c3, c2, c5, dm, pr = L("c3"), L("c2"), L("c5"), L("demo"), L("prep")
+
+
+def kc(d, k, tf=True):
+    v = d["kernel_classes"].get(k)
+    if not v:
+        return "–"
+    s = f"{v['ms_per_step']:.1f} ms"
+    if tf and v.get("tflops"):
+        s += f" @ {v['tflops']:.0f} TF/s ({v['tflops'] / 25:.0f} %)"
+    return s
+
+
+rows = [("c3: all heads, B=4, 64 queries/clip", c3), ("c2: depth only, B=1", c2),
+        ("c5: one 256-frame video (31 windows), all heads, 1 GPU, windows in groups of 16", c5),
+        ("demo: 64 frames, 625 queries in chunks of 128, depth + flow + mask + tracks", dm)]
+b8 = os.path.join(P, f"{tag}_c3_batch8_bench_line.json")
+if os.path.exists(b8):
+    rows.insert(1, ("c3 at batch 8 (the per-GPU batch of configs[3])", json.load(open(b8))))
+t = ("<!--R3TABLE-BEGIN-->\n| workload | frames/s | ms/step | GEMM class | conv3d class | attention | LayerNorm | elementwise | tracker kernels |\n"
+     "|---|---|---|---|---|---|---|---|---|\n")
+for name, d in rows:
+    t += (f"| {name} | **{d['value']:.0f}** | {d['ms_per_step']:.1f} | {kc(d, 'gemm')} | {kc(d, 'conv3d')} | {kc(d, 'attention')} | "
+          f"{kc(d, 'layernorm', False)} | {kc(d, 'elementwise', False)} | {kc(d, 'track', False)} |\n")
+t += f"| prep: 50 decoded 480×854 frames → [3,64,224,224] | **{pr['value'] / 1000:.0f} k** | {pr['ms_per_step']:.2f} | | | | | | |\n"
+attn = [l for l in open(os.path.join(P, f"{tag}_c3_kernel_stats.md")) if "attn_kernel" in l][0].split("|")
+avg = float(attn[4])
+ra, rg = c3["roofline_attention"], c3["roofline"]
+t += (f"\n`roofline` of the c3 line: GEMM class {rg['achieved']:.0f} TF/s = **{rg['frac']:.3f}** of 2.5 PF ({rg['launches_per_step']:.0f} launches per step, "
+      f"HIP-event-timed); `roofline_attention` {ra['achieved']:.0f} TF/s = **{ra['frac']:.3f}** ({ra['avg_launch_us']:.1f} µs per launch event-timed; "
+      f"rocprofv3 average of the same command {avg:.2f} µs = {94.49 / avg / 2.5:.3f}, `profiles/{tag}_c3_kernel_stats.md`; c5: "
+      f"{c5['roofline_attention']['frac']:.3f} at its batch of 16 windows).  CPU oracle on the same box: {c3['cpu_baseline']['value']:.2f} frames/s on "
+      f"{c3['cpu_baseline']['cores']} cores ({c3['cpu_baseline']['sample'].split(';')[1].strip()}).\n")
+t += (f"c5 phases: phase 1 {c5['phase1_ms']:.0f} ms, phase 3 dense {c5['phase3_dense_ms']:.1f} ms + tracker {c5['phase3_track_ms']:.0f} ms "
+      f"({c5['phase3_track_ms_on_an_eighth_of_the_queries']:.0f} ms on an eighth of the queries): implied 8-GPU speed-up with the query-sharded "
+      f"tracker {c5['implied_8gpu_speedup_query_sharded_tracker']:.1f}×.\n<!--R3TABLE-END-->\n")
+path = os.path.join(ROOT, "DESIGN.md")
+s = open(path).read()
+i, j = s.index("<!--R3TABLE-BEGIN-->"), s.index("<!--R3TABLE-END-->") + len("<!--R3TABLE-END-->\n")
+open(path, "w").write(s[:i] + t + s[j:])
+print(t)
