@@ -76,12 +76,21 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
         const int bid = (int)blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = ntiles >> 3, r = ntiles & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    // order of the blocks: w fastest, then T, then h (round 3; was w, h, t): the ~32 blocks an XCD runs at a time then hold, for a
+    // strip of h, several CONSECUTIVE t blocks - the two halo planes a block shares with its t neighbours (half of its halo)
+    // are read by blocks that are resident at the same time instead of a whole (h x w) plane of blocks later
     int rem = tile;
     const int bw = rem % nbw;
     rem /= nbw;
+#ifdef CONV_HALO_ORDER_WHT
     const int bh = rem % nbh;
     rem /= nbh;
     const int bt = rem % nbt, bb = rem / nbt;
+#else
+    const int bt = rem % nbt;
+    rem /= nbt;
+    const int bh = rem % nbh, bb = rem / nbh;
+#endif
     const int t0 = bt * TT, h0 = bh * TH, w0 = bw * TW;
 
     // ---- W staging: LDS slot s = pass * 512 + tid  ->  (LDS row s >> 2 = colblock * 64 + j * 16 + a, physical chunk s & 3) ----
