@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
     const int li = lane & 15, kg = lane >> 4;
 
     // ---- workgroup -> output block: XCD x (workgroup b runs on XCD b % 8) owns a contiguous range of blocks in the order
-    //      (batch, t block, h block, w block fastest): the ~32 blocks an XCD runs at a time are a compact slab whose halos
+    //      (batch, h block, t block, w block fastest): the ~32 blocks an XCD runs at a time are a compact slab whose halos
     //      overlap in its L2 ----
     const int nbw = p.Wo / TW, nbh = p.Ho / TH, nbt = p.To / TT;
     const int ntiles = (p.M / BM);
