@@ -18,6 +18,15 @@
 // RES: the row normalised is x[row % x_mod] + delta[row] (delta in the engine dtype): the tracker's "keys += attention
 // output; keys = LayerNorm(keys)" (sam/transformer.py:183-185) with the sum formed HERE instead of in the projection's
 // epilogue - the float key stream is read once by this kernel instead of read + written by the GEMM and read again.
+#ifdef LN_NT  // (probe: streaming hints on the LayerNorm's row loads / stores.  Measured, same call: the tracker's 369 MB-per-stream
+              //  key LayerNorms 470 -> 449 us / 581 -> 582 us, the encoder's 8192-row ones 29.3 -> 31.9 us - their output is the
+              //  next GEMM's operand and wants to stay in cache; c3 +-0.4 %: not adopted)
+#define LN_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define LN_LD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define LN_ST(ptr, val) (*(ptr) = (val))
+#define LN_LD(ptr) (*(ptr))
+#endif
 template <typename T, int MAXV, bool XT = false, int ROWS = 1, bool RES = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, T* out_T, float* out_f32, int M,
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[r][i][k] = in ? (float)t[k] : 0.f;
             } else {
-                v[r][i] = in ? xr[idx] : z;
+                v[r][i] = in ? LN_LD(xr + idx) : z;
             }
             if constexpr (RES) {
                 if (part) {  // the addend is bias + the float partials of a split-K projection, summed in slice order
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[r][i][k] += in ? d[k] : 0.f;
                 } else if (sizeof(T) == 2) {
-                    const bf16x4 t = ((const bf16x4*)((const bf16_t*)delta + (long long)row * C))[in ? idx : 0];
+                    const bf16x4 t = LN_LD((const bf16x4*)((const bf16_t*)delta + (long long)row * C) + (in ? idx : 0));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[r][i][k] += in ? (float)t[k] : 0.f;
                 } else {
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                         bf16x4 o;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = (bf16_t)(y[k] + av[r][i][k]);
-                        ((bf16x4*)((bf16_t*)out_T2 + (long long)row * C))[idx] = o;
+                        LN_ST((bf16x4*)((bf16_t*)out_T2 + (long long)row * C) + idx, o);
                     } else {
                         f32x4 o;
 #pragma unroll
@@ -132,16 +141,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                         ((f32x4*)((float*)out_T2 + (long long)row * C))[idx] = o;
                     }
                 }
-                if (out_f32) ((f32x4*)(out_f32 + (long long)row * C))[idx] = y;
+                if (out_f32) LN_ST((f32x4*)(out_f32 + (long long)row * C) + idx, y);
                 if constexpr (RES) {  // pre-norm residual stream (the encoder): the SUM x + delta is what lives on, y is only xn
-                    if (out_sum) ((f32x4*)(out_sum + (long long)row * C))[idx] = v[r][i];
+                    if (out_sum) LN_ST((f32x4*)(out_sum + (long long)row * C) + idx, v[r][i]);
                 }
                 if (out_T) {
                     if (sizeof(T) == 2) {
                         bf16x4 o;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = (bf16_t)y[k];
-                        ((bf16x4*)((bf16_t*)out_T + (long long)row * C))[idx] = o;
+                        LN_ST((bf16x4*)((bf16_t*)out_T + (long long)row * C) + idx, o);
                     } else {
                         ((f32x4*)((float*)out_T + (long long)row * C))[idx] = y;
                     }
