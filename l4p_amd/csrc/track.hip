@@ -547,21 +547,34 @@ __global__ __launch_bounds__(256) void track_readout_kernel(const float* __restr
         const float bot = (1.f - lx) * b[r1 + x0] + lx * b[r1 + x1];
         return (1.f - ly) * top + ly * bot;
     };
-    // pass 1: max of channel 0, sums of channels 1 and 2
-    float mx = -INFINITY, s1 = 0.f, s2 = 0.f;
-    for (int x = tid; x < W; x += 256) {
-        int x0, x1;
-        float lx;
-        src_idx_nc(x, w, W, x0, x1, lx);
-        for (int y = 0; y < H; ++y) {
-            int y0, y1;
-            float ly;
-            src_idx_nc(y, h, H, y0, y1, ly);  // (uniform over the wave: scalar work)
-            const int r0 = y0 * w, r1 = y1 * w;
-            mx = fmaxf(mx, lerp2(lo, r0, r1, x0, x1, lx, ly));
-            s1 += lerp2(lo + hw, r0, r1, x0, x1, lx, ly);
-            s2 += lerp2(lo + 2 * hw, r0, r1, x0, x1, lx, ly);
+    // pass 1: an upper bound of channel 0 and the spatial sums of the up-sampled channels 1 and 2, all from the 64 x 64 source.
+    // Bilinear interpolation is a convex combination, so max(source) bounds the up-sampled maximum - the soft-argmax below only
+    // needs its exponents non-positive (softmax is shift-invariant) -, and the sum of an up-sampled channel is
+    // sum_r b[r] * wy[row(r)] * wx[col(r)] with wx[i] / wy[i] = the total weight source column / row i receives from the W / H
+    // output positions (accumulated per source index in a fixed order).  Replaces a second walk over all H x W samples of
+    // three channels (12 LDS reads + 9 lerps per sample): 171 -> ~90 us per 64-track window.
+    float* wxs = lo + 3 * hw;  // [w]
+    float* wys = wxs + w;      // [h]
+    for (int i = tid; i < w + h; i += 256) {
+        const bool isx = i < w;
+        const int idx = isx ? i : i - w, in = isx ? w : h, out = isx ? W : H;
+        float acc = 0.f;
+        for (int d = 0; d < out; ++d) {
+            int i0, i1;
+            float lam;
+            src_idx_nc(d, in, out, i0, i1, lam);
+            if (i0 == idx) acc += 1.f - lam;
+            if (i1 == idx) acc += lam;
         }
+        (isx ? wxs : wys)[idx] = acc;
+    }
+    __syncthreads();
+    float mx = -INFINITY, s1 = 0.f, s2 = 0.f;
+    for (int r = tid; r < hw; r += 256) {
+        const float wgt = wys[r / w] * wxs[r % w];
+        mx = fmaxf(mx, lo[r]);
+        s1 += lo[hw + r] * wgt;
+        s2 += lo[2 * hw + r] * wgt;
     }
     mx = wave_max(mx);
     s1 = wave_sum(s1);
@@ -587,6 +600,8 @@ __global__ __launch_bounds__(256) void track_readout_kernel(const float* __restr
             int y0, y1;
             float ly;
             src_idx_nc(y, h, H, y0, y1, ly);
+            // (expf, not v_exp_f32: the bare instruction is 13 us per launch faster, but its last-ulp differences moved one
+            //  re-seeded query of the 4-window full-size bf16 run onto another frame - the track then differs by 7e-2 in depth)
             const float e = expf(lerp2(lo, y0 * w, y1 * w, x0, x1, lx, ly) - mx);
             z += e;
             sx += e * xc;
@@ -942,7 +957,9 @@ int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, 
 
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
                          int W, hipStream_t stream) {
-    const size_t lds = (size_t)3 * h * w * 4;
+    const size_t lds = ((size_t)3 * h * w + w + h) * 4;
+    static std::atomic<unsigned long long> attr_done{0};
+    HIP_TRY(lds_attr_once(attr_done, track_readout_kernel, (int)lds));
     ProfScope prof(PROF_TRACK, stream, "track_readout");
     hipLaunchKernelGGL(track_readout_kernel, dim3(N * T), dim3(256), lds, stream, masks, traj, vis, depth, T, h, w, H, W);
     HIP_TRY(hipGetLastError());
