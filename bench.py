@@ -188,7 +188,7 @@ def build_workload(tasks, B, nq, device, rank=0, frames=16, same_data=False, use
     K[0, 2] = K[1, 2] = 112.0
     batch = {"rgb_b3thw": rgb.to(device), "intrinsics_b44t": K[None, :, :, None].repeat(B, 1, 1, frames).to(device)}
     if "track_2d" in tasks:
-        from tests.golden_utils import grid_queries
+        from l4p_amd.data.synthetic import grid_queries
 
         q = grid_queries(nq)
         batch["track_2d_pointquerries_bn3"] = q.repeat(B, 1, 1).to(device)  # every clip tracks its own nq queries
@@ -245,7 +245,7 @@ def bench_prep(args, rank, world, device, lib):
     import numpy as np
 
     from l4p_amd.data import prepare_clip
-    from tests.golden_utils import synthetic_video
+    from l4p_amd.data.synthetic import synthetic_video
 
     T, H, W, T_out = 50, 480, 854, 64
     host = synthetic_video(100 + rank, T, H, W)
@@ -312,7 +312,7 @@ def bench_demo(args, rank, world, device, lib, selftest):
     """--workload demo: large-N tracking at the demo's scale (625 queries over 7 windows, chunks of 128) next to the dense
     heads of a 64-frame clip; one video per GPU per step (weak scaling)."""
     from l4p_amd.data import prepare_clip
-    from tests.golden_utils import synthetic_video
+    from l4p_amd.data.synthetic import synthetic_video
 
     cfg = ModelCfg.full()
     model, _, sd = build_workload(list(DEMO_TASKS), 1, 64, device, rank)

@@ -6,7 +6,7 @@ scope; the outputs are reported (and optionally saved as .npz) instead.
   python demo/demo.py --synthetic                      # no checkpoint / video files here: seeded weights + a seeded video
 
 With --synthetic the weights are the name-seeded random tensors of the test-suite (same 916-key state dict a checkpoint
-holds) and the "video" is tests.golden_utils.synthetic_video: the point is the plumbing and the timing, not the pictures.
+holds) and the "video" is l4p_amd.data.synthetic.synthetic_video: the point is the plumbing and the timing, not the pictures.
 """
 import argparse
 import os
@@ -40,7 +40,7 @@ def main():
     frames = None
     if args.synthetic:
         from l4p_amd.weights import ModelCfg, seeded_state_dict
-        from tests.golden_utils import synthetic_video
+        from l4p_amd.data.synthetic import synthetic_video
 
         model = build_model(args.config, max_queries=args.max_queries, precision=precision)
         model.load_state_dict({"l4p_model." + k: v for k, v in seeded_state_dict(ModelCfg.full()).items()})

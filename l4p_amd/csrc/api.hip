@@ -100,7 +100,14 @@ int l4p_create(int device, int dtype, l4p_engine** out) {
         l4p_set_error("l4p_create: bad arguments");
         return L4P_E_INVALID;
     }
-    HIP_TRY(hipSetDevice(device));
+    // the engine only records its device: the caller's current device is left as it was (every launch goes to the stream the
+    // caller passes, and the host side makes that stream's device current around a call)
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        l4p_set_error("l4p_create: no such device");
+        return L4P_E_INVALID;
+    }
     l4p_engine* e = new l4p_engine();
     e->device = device;
     e->dtype = dtype;

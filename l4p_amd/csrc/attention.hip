@@ -700,7 +700,7 @@ static int launch_attn_t(const void* q, const void* kt, const void* vt, void* ou
     const int grid = persist && ntiles > slots ? slots : ntiles;
     const size_t lds = SPLIT * 2 * (size_t)(DP / 16 * KVB * 2 * 8 * sizeof(T) + DP * 128) + (QS > 1 ? (size_t)128 * QS * DP * sizeof(T) : 0);
     auto kern = attn_kernel<T, DP, KVB, DH, SPLIT, HS, QS>;
-    static std::atomic<unsigned long long> attr_done{0};
+    static lds_attr_state attr_done;
     HIP_TRY(lds_attr_once(attr_done, kern, (int)lds));
     // scale == 0 (L4P_ATTN_PRESCALED): q already carries head_dim^-0.5 * log2(e); the kernels then multiply by exactly 1
     const float c_scale = scale > 0.f ? scale * 1.4426950408889634f : 1.0f;

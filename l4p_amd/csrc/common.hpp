@@ -110,19 +110,28 @@ __device__ __forceinline__ float wave_max(float v) {
 
 #include "prof.hpp"
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, DEVICE): the attribute is a property of
-// the function on one device, and a host may drive several devices, from several threads (the mask is atomic; a lost race
-// only repeats an idempotent call)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) per (kernel instantiation, DEVICE), raised whenever a launch needs more than
+// the largest size set so far: the attribute is a property of the function on one device, a host may drive several devices from
+// several threads, and some kernels' LDS size depends on the geometry (a mini model's launch must not pin the limit below what
+// the full-size model asks for later).  
 #include <atomic>
+#include <mutex>
+struct lds_attr_state {
+    std::atomic<int> set[64] = {};
+    std::mutex mu;  // raising the limit is serialised, so a smaller request can never overwrite a larger one
+};
 template <class K>
-static inline hipError_t lds_attr_once(std::atomic<unsigned long long>& done, K kern, int lds) {
+static inline hipError_t lds_attr_once(lds_attr_state& st, K kern, int lds) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const int want = lds > 0 ? lds : 1;
+    std::atomic<int>& cur = st.set[dev & 63];
+    if (cur.load(std::memory_order_acquire) >= want) return hipSuccess;
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (cur.load(std::memory_order_acquire) >= want) return hipSuccess;
     e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    if (e == hipSuccess) cur.store(want, std::memory_order_release);
     return e;
 }
 

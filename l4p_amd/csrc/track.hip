@@ -958,7 +958,7 @@ int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, 
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
                          int W, hipStream_t stream) {
     const size_t lds = ((size_t)3 * h * w + w + h) * 4;
-    static std::atomic<unsigned long long> attr_done{0};
+    static lds_attr_state attr_done;
     HIP_TRY(lds_attr_once(attr_done, track_readout_kernel, (int)lds));
     ProfScope prof(PROF_TRACK, stream, "track_readout");
     hipLaunchKernelGGL(track_readout_kernel, dim3(N * T), dim3(256), lds, stream, masks, traj, vis, depth, T, h, w, H, W);

@@ -14,6 +14,18 @@ from .packing import PackedWeights
 from .weights import ModelCfg
 
 
+def _on_device(fn):
+    """The engine's GPU is the current device (and its current stream the launch stream) for the duration of a native call."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **kw)
+
+    return wrapped
+
+
 class Engine:
     """One engine per (process, device, dtype)."""
 
@@ -52,6 +64,7 @@ class Engine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    @_on_device
     def dpt_forward(self, task: str, hooks: Sequence[torch.Tensor], out_ch: int, actpost, fusion,
                     out_size: Tuple[int, int, int], post_exp: bool) -> torch.Tensor:
         """DPTOutputAdapter_fix.forward (dpt_head.py:41-86) of head ``task`` as one native call.
@@ -82,6 +95,7 @@ class Engine:
                                             hp, B, ws.data_ptr(), ws.numel(), out.data_ptr()), "l4p_dpt_forward")
         return out
 
+    @_on_device
     def encoder_forward(self, rgb: torch.Tensor, taps_f32: Iterable[int] = (), taps_T: Iterable[int] = ()) -> Tuple[Dict[int, torch.Tensor], Dict[int, torch.Tensor]]:
         """VideoMAEEncoder.forward (l4p_videomae.py:80-122) for the requested feature indices only.
         Returns ({layer: float [B,P,C]}, {layer: T [B,P,C]})."""
@@ -102,6 +116,7 @@ class Engine:
                                                 ws.data_ptr(), ws.numel(), n, lay, pf, pT), "l4p_encoder_forward")
         return out_f, out_T
 
+    @_on_device
     def track_window(self, tcfg: "_lib.TrackCfg", enc_last: torch.Tensor, hist: torch.Tensor, q_off: torch.Tensor,
                      labels: torch.Tensor, pfeat: torch.Tensor, plabel: torch.Tensor, need_history: bool, hist_uniform: int,
                      slot: int = 0):

@@ -53,6 +53,23 @@ class EncoderFeatures:
         return self.f32(i)
 
 
+def _on_own_device(fn):
+    """Run a model entry point with the model's GPU as the current device: kernels are launched on
+    ``torch.cuda.current_stream()`` and allocations land on the current device, so a model pinned to cuda:3 must not depend on
+    what the caller's current device happens to be (round-3 advisor finding)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        dev = getattr(self, "device", None)
+        if dev is None or dev.type != "cuda" or self.engine is None:
+            return fn(self, *a, **kw)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **kw)
+
+    return wrapped
+
+
 def _engine_dtype(name) -> int:
     if name in (L4P_BF16, "bf16", "bf16-mixed", "16-mixed", "bf16-true", "16-true"):
         return L4P_BF16  # the reference's fp16 autocast maps to the bf16 MFMA path (>= its precision class)
@@ -173,6 +190,7 @@ class L4P_VideoMAE(torch.nn.Module):
                 tf.add(self.cfg.depth)  # tracker reads enc_features[-1]  (sparse_heads.py:521)
         return sorted(tf), sorted(tT)
 
+    @_on_own_device
     def video_encoder(self, rgb_b3thw: torch.Tensor, taps_f32: Iterable[int] = (), taps_T: Iterable[int] = ()) -> EncoderFeatures:
         if self.engine is None:
             raise RuntimeError("weights not loaded: call load_state_dict / set_weights first")
@@ -184,6 +202,7 @@ class L4P_VideoMAE(torch.nn.Module):
         tf, tT = self._taps(tasks if tasks is not None else list(self.task_heads.keys()))
         return self.video_encoder(data["rgb_b3thw"], tf, tT)
 
+    @_on_own_device
     def forward_single_window(self, data: Dict[str, Any], tasks: List[str]) -> Dict[str, Any]:
         feats = self.encode_features(data, tasks)
         out: Dict[str, Any] = {"enc_features_bpc_list": feats}
@@ -192,6 +211,7 @@ class L4P_VideoMAE(torch.nn.Module):
         return out
 
     # ---- main entry ------------------------------------------------------------------------------
+    @_on_own_device
     def forward(self, data: Dict[str, Any], tasks: List[str]) -> Dict[str, Any]:
         rgb = data["rgb_b3thw"]
         B, _, T, H, W = rgb.shape
@@ -215,6 +235,7 @@ class L4P_VideoMAE(torch.nn.Module):
     def time_strides(self, T: int) -> torch.Tensor:
         return torch.arange(0, T - self.window_size[0] + 1, self.window_stride_T)
 
+    @_on_own_device
     def stitch_windows(self, feats2d: list, data: Dict[str, Any], tasks: List[str], time_strides: torch.Tensor) -> Dict[str, Any]:
         """Everything after the per-window encoder (l4p_videomae.py:296-329): per-window heads + stitching / alignment /
         track recursion.  ``feats2d`` holds one entry per window: EncoderFeatures, or parallel.DecodedWindow for windows

@@ -471,6 +471,10 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         dep_all = torch.empty(B, N, 1, T, **f32)
         pf_all = torch.empty(B, N, Cc, **f32)
         zero_hist = torch.zeros(P, Cc, **f32)  # keys = enc_features[-1] + 0: one key set shared by all tracks
+        # the reference returns the [B,N,P,C] float history from this entry unconditionally (sparse_heads.py:560-569), so the
+        # default keeps the key; it costs 11.5 MB and one P x C x C projection per query (0.74 GB per clip at 64 queries): a
+        # caller that only wants the trajectories sets ``head.return_track_history = False``.  The sliding-window path
+        # (forward_windowed_core with time strides - what bench.py and the demo run) never materialises it.
         want_hist = bool(getattr(self, "return_track_history", True))
         hist_all = torch.empty(B, N, P, Cc, **f32) if want_hist else None
         for b in range(B):

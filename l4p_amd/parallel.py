@@ -12,13 +12,23 @@ import torch.distributed as dist
 from .packing import PackedWeights
 
 
-def _collectives_on() -> bool:
-    """True when the exchange steps must go through torch.distributed.  A one-rank group skips them unless
-    L4P_FORCE_COLLECTIVES=1: the single-GPU boxes of the test pool then still push the very same tensors (packed arena, decoded
-    windows, query shards) through RCCL's broadcast / all-gather with one rank (tests/test_rccl_one_rank_gpu.py)."""
+def _collectives_on(world: Optional[int] = None) -> bool:
+    """True when the exchange steps must go through torch.distributed.  ``world`` is the number of ranks the CALLER shards
+    over (None: the whole process group).  A caller that works on its own (``world == 1``: L4P_VideoMAE.forward with
+    ``window_batch > 1`` inside a torchrun job of data-parallel clips) never enters a collective, whatever the size of the
+    process group; a one-rank GROUP skips them unless L4P_FORCE_COLLECTIVES=1: the single-GPU boxes of the test pool then still
+    push the very same tensors (packed arena, decoded windows, query shards) through RCCL's broadcast / all-gather with one
+    rank (tests/test_rccl_one_rank_gpu.py)."""
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    return dist.get_world_size() > 1 or os.environ.get("L4P_FORCE_COLLECTIVES", "0") == "1"
+    gsize = dist.get_world_size()
+    if world is None:
+        world = gsize
+    if world > 1:
+        if world != gsize:
+            raise ValueError(f"sharding over {world} ranks inside a process group of {gsize}: pass the group's size")
+        return True
+    return gsize == 1 and os.environ.get("L4P_FORCE_COLLECTIVES", "0") == "1"
 
 
 def env_rank() -> Tuple[int, int, int]:
@@ -105,7 +115,7 @@ def all_gather_windows(local: dict, n_windows: int, rank: int, world: int) -> Li
     """local: {window id: {key: tensor}} for this rank's chunk -> list over ALL windows of {key: tensor}.
     One all_gather per key on a [chunk_max, ...] block (chunks differ by at most one window; the pad slot is ignored)."""
     chunks = window_chunks(n_windows, world)
-    if not _collectives_on():
+    if not _collectives_on(world):
         return [local[w] for w in range(n_windows)]
     cmax = max(e - s for s, e in chunks)
     s0, e0 = chunks[rank]
@@ -137,7 +147,7 @@ def shard_queries(n_queries: int, rank: int, world: int) -> Tuple[int, int]:
 
 def all_gather_queries(x: torch.Tensor, n_queries: int, rank: int, world: int, dim: int = 1) -> torch.Tensor:
     """Inverse of shard_queries along ``dim`` (shards differ by at most one query: padded to the largest)."""
-    if not _collectives_on():
+    if not _collectives_on(world):
         return x
     chunks = window_chunks(n_queries, world)
     cmax = max(e - s for s, e in chunks)
@@ -210,7 +220,7 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
     local = decode_local_windows(net, data, tasks, rank, world, group)
     gathered = all_gather_windows(local, nwin, rank, world)  # the one exchange step of the dense path
     out = stitch_gathered_windows(net, data, tasks, gathered, rank, world)
-    if "track_2d" in tasks and (world > 1 or _collectives_on()):
+    if "track_2d" in tasks and _collectives_on(world):
         nq = data["track_2d_pointquerries_bn3"].shape[1]
         name = net.task_heads["track_2d"].task_name
         for key, shp in ((f"{name}_traj_est_bn2t", 2), (f"{name}_vis_est_bn1t", 1), (f"{name}_depth_est_bn1t", 1)):

@@ -2,6 +2,8 @@
 (randn seed 1234 clip, fx=fy=224 / cx=cy=112 intrinsics, grid point queries.)"""
 import torch
 
+from l4p_amd.data.synthetic import grid_queries, synthetic_video  # noqa: F401  (shared with bench.py / demo.py)
+
 QUERY_TIMES = [0, 0, 3, 10, 0, 18, 7, 25, 1, 12, 0, 21]
 
 
@@ -22,14 +24,6 @@ def make_batch(T: int, nq: int, seed: int = 1234):
         "track_2d_pointquerries_bn3": q,
         "track_2d_pointlabels_bn": torch.ones(1, nq),
     }
-
-
-def grid_queries(nq: int) -> torch.Tensor:
-    """The benchmark's track queries (bench.py): an 8x8 grid x, y in {14 + 28 i} + 0.5 at t = 0.5 -> [1,nq,3]."""
-    q = torch.zeros(1, nq, 3)
-    for i in range(nq):
-        q[0, i] = torch.tensor([0.5, 14.0 + 28.0 * (i % 8) + 0.5, 14.0 + 28.0 * ((i // 8) % 8) + 0.5])
-    return q
 
 
 def sample_indices(numel: int, n: int = 4096) -> torch.Tensor:
@@ -53,20 +47,6 @@ PREPROCESS_CASES = {
     "single_frame": dict(seed=14, T=1, H=64, W=96, crop_size=(16, 224, 224), resize_size=(224, 224), max_frames=192,
                          stride=1, spacing=0.5),
 }
-
-
-def synthetic_video(seed: int, T: int, H: int, W: int):
-    """uint8 frames [T,H,W,3]: smooth moving gradients + blocks + noise, so every filter tap matters."""
-    import numpy as np
-
-    rng = np.random.default_rng(seed)
-    t = np.arange(T)[:, None, None, None]
-    y = np.arange(H)[None, :, None, None]
-    x = np.arange(W)[None, None, :, None]
-    c = np.arange(3)[None, None, None, :]
-    v = 127 + 90 * np.sin(0.07 * x + 0.3 * t + c) * np.cos(0.05 * y - 0.2 * t) + 40 * (((x // 8 + y // 8 + t) % 2) - 0.5)
-    v = v + rng.normal(0, 12, size=(T, H, W, 3))
-    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
 
 
 def single_window_batch():

@@ -120,3 +120,46 @@ def test_collective_selftest_world3():
         assert p.exitcode == 0
     assert all(r[1]["ok"] and r[1]["ranks"] == 3 and r[1]["backend"] == "gloo" and r[1]["windows_gathered"] == 4 for r in res)
     assert len({r[1]["arena_checksum"] for r in res}) == 1
+
+
+def _worker_solo_inside_group(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from l4p_amd import parallel
+    from l4p_amd.parallel import all_gather_queries, all_gather_windows, init_distributed
+
+    init_distributed("gloo")
+    # L4P_VideoMAE.forward(window_batch > 1) calls the sharded path with (rank 0, world 1) from EVERY rank of a data-parallel
+    # job (l4p_videomae.py: forward_windows_sharded(self, data, tasks, 0, 1)): it owns all windows and must not enter a collective
+    nwin = 3
+    local = {w: {"dec.depth": torch.full((1, 1, 2, 2, 2), float(10 * rank + w))} for w in range(nwin)}
+    got = all_gather_windows(local, nwin, 0, 1)
+    ok_w = len(got) == nwin and all(got[w]["dec.depth"] is local[w]["dec.depth"] for w in range(nwin))
+    x = torch.arange(8.0).reshape(1, 4, 2) + rank
+    ok_q = all_gather_queries(x, 4, 0, 1, dim=1) is x
+    ok_flag = (not parallel._collectives_on(1)) and parallel._collectives_on(world) and parallel._collectives_on()
+    try:
+        parallel._collectives_on(world + 1)
+        ok_err = False
+    except ValueError:
+        ok_err = True
+    q.put((rank, bool(ok_w), bool(ok_q), bool(ok_flag), ok_err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_rank_caller_inside_a_larger_group_stays_local():
+    """Round-3 advisor finding: with window_batch > 1 every rank of a 2-rank job runs the window-sharded path on its own
+    (world = 1); the exchange helpers then return the local tensors and never touch the group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_solo_inside_group, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1:] == (True, True, True, True) for r in res), res
