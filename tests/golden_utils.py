@@ -79,3 +79,69 @@ def synthetic_rays(B=2, T=4, h=16, w=16, seed=5, noise=2e-3):
             rays[b, :3, t] = d.T.reshape(3, h, w)
             rays[b, 3:, t] = m.T.reshape(3, h, w)
     return rays, Ks
+
+
+# ---- reference-anchored gates of the bf16 engine (round 4) ---------------------------------------------------------------------
+BF16_MARGIN = 1.25        # per-key allowance over the reference's own figure (one run of each side; sampled values on ours)
+BF16_MARGIN_SMALL = 2.0   # ... for outputs of fewer than 4096 values (4 tracks x 24 frames = 96 numbers: a rel-L2 over so few
+                          # values from ONE run of each side is a noisy statistic; the geometric-mean bar below still holds)
+
+
+def reference_autocast_drift(case: str) -> dict:
+    """tests/golden/reference_autocast_drift.json (tools/gen_golden_full_autocast.py): the imported reference under
+    torch.autocast(bfloat16) against its own fp32 run on the golden inputs -> {key: rel-L2}."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_autocast_drift.json")) as f:
+        rep = json.load(f)[case]
+    assert "autocast_failed" not in rep, rep
+    return {k: v["rel_l2"] for k, v in rep.items() if isinstance(v, dict)} | {k: v for k, v in rep.items() if not isinstance(v, dict)}
+
+
+def assert_bf16_within_reference_drift(report_l2: dict, case: str, keymap=None, what: str = "", small=()) -> dict:
+    """``report_l2``: {key: rel-L2 of the bf16 ENGINE against the reference's fp32 golden}.  The bar is the reference's own
+    mixed-precision drift on the same inputs: every key within BF16_MARGIN x the reference's figure, and the geometric mean of
+    engine / reference over the keys <= 1 (overall the engine is no further from the fp32 reference than the reference's own
+    autocast run is).  Keys whose reference drift is 0 (pass-through values) must be exact to 1e-6.  ``small``: keys of outputs
+    with fewer than 4096 values, held to BF16_MARGIN_SMALL per key.  Returns the ratios."""
+    import math
+
+    ref = reference_autocast_drift(case)
+    ratios = {}
+    for k, v in report_l2.items():
+        rk = (keymap or {}).get(k, k)
+        assert rk in ref, (case, rk, sorted(ref))
+        if ref[rk] == 0.0:
+            assert v <= 1e-6, (what, k, v)
+            continue
+        ratios[k] = v / ref[rk]
+    print(f"bf16 engine drift / reference autocast drift [{case}{' ' + what if what else ''}]:",
+          {k: f"{r:.2f}" for k, r in ratios.items()})
+    bad = {k: r for k, r in ratios.items() if r > (BF16_MARGIN_SMALL if k in small else BF16_MARGIN)}
+    assert not bad, (what, bad)
+    gm = math.exp(sum(math.log(max(r, 1e-12)) for r in ratios.values()) / max(len(ratios), 1))
+    assert gm <= 1.0, (what, gm, ratios)
+    return ratios
+
+
+def integer_state_mismatches(trace, gold, nwin: int, sel=slice(None)) -> torch.Tensor:
+    """Engine trace (VideoMAETrack2DSamHead.trace of ONE clip, window order) against the ``trace{w}_*`` arrays of a golden file
+    (labels / prompt labels / query times from the reference's own run; valid_t / best_vis_id from the oracle on the reference's
+    features, asserted equal to the reference where both exist).  -> bool per track: state differs anywhere in the recursion."""
+    import numpy as np
+
+    assert len(trace) == nwin, (len(trace), nwin)
+    n = trace[0]["labels"].numel()
+    bad = torch.zeros(n, dtype=torch.bool)
+    for w in range(nwin):
+        tr = trace[w]
+        assert tr["window"] == w
+        bad |= torch.from_numpy(tr["labels"].cpu().numpy() != gold[f"trace{w}_labels"][sel])
+        bad |= torch.from_numpy(tr["prompt_labels"].cpu().numpy() != gold[f"trace{w}_prompt_labels"][sel])
+        bad |= torch.from_numpy(tr["queries"][:, 0].cpu().numpy() != gold[f"trace{w}_queries"][sel][:, 0])
+        if f"trace{w}_valid_t" in gold:
+            bad |= torch.from_numpy((tr["valid_t"].cpu().numpy().astype(bool) != gold[f"trace{w}_valid_t"][sel]).any(axis=-1))
+        if f"trace{w}_best_vis_id" in gold and "best_vis_id" in tr:
+            bad |= torch.from_numpy(tr["best_vis_id"].cpu().numpy().astype(np.int64) != gold[f"trace{w}_best_vis_id"][sel])
+    return bad

@@ -1,9 +1,16 @@
 """GPU parity at the FULL geometry (VideoMAE-v2-giant: 1408 wide, 40 blocks, all five heads) against the
 golden vectors produced by the real reference (tests/golden/full_T16_all.npz).
 
-L4P_F32 engine: 1e-3 relative-to-max on the sampled values (north_star).  L4P_BF16 engine: 40 residual blocks in bf16
-cannot meet 1e-3 (SURVEY.md §7 "hard parts"); its drift is bounded at ~2x what is measured (rel-L2 of the samples:
-encoder features 5e-3 -> gate 1e-2; heads / tracks / poses 0.6..1.2e-2 -> gate 3e-2).
+L4P_F32 engine: 1e-3 relative-to-max on the sampled values (north_star).  L4P_BF16 engine (what bench.py times): 40 residual
+blocks in bf16 cannot meet 1e-3 (SURVEY.md §7 "hard parts") - and neither can the reference's own mixed-precision mode (its demo
+runs "16-mixed", demo.py:22-23).  The bar is therefore the REFERENCE'S OWN DRIFT: the imported reference under
+torch.autocast(bfloat16) against its own fp32 run on the same inputs (tools/gen_golden_full_autocast.py ->
+tests/golden/reference_autocast_drift.json: features 0.9..1.3e-2, depth 1.7e-2, flow / mask 0.9..1.0e-2, poses 1.1e-2, tracks
+0.2..1.0e-2 rel-L2).  The engine's rel-L2 against the fp32 goldens must stay within it key by key (golden_utils.
+assert_bf16_within_reference_drift: <= 1.25 x per key, geometric mean of the ratios <= 1); measured ratios 0.4..1.0.
+Integer / boolean tracker state (labels, prompt labels, validity masks, re-seeded query times, argmax index) is asserted
+BIT-EXACT against the reference's recorded trace for the f32 engine at this geometry over 1, 2 and 4 windows; for the bf16 engine
+the tracks whose state differs are counted and bounded by the count the reference's own autocast run shows (min. 1).
 
 test_batch4_*: the BENCHMARKED configuration (configs[2]: batch 4, bf16).  Batch 4 changes kernel selection (8-phase
 256x256 GEMM / conv instead of 128x128, un-split attention, one tracker stream per clip), so it is tied to the batch-1
@@ -19,7 +26,8 @@ pytestmark = pytest.mark.gpu
 
 from l4p_amd.models.utils import build_model
 from l4p_amd.weights import ModelCfg, seeded_state_dict
-from tests.golden_utils import grid_queries, make_batch, sample_indices
+from tests.golden_utils import (assert_bf16_within_reference_drift, grid_queries, integer_state_mismatches, make_batch,
+                                reference_autocast_drift, sample_indices)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALL = ["flow_2d_backward", "track_2d", "depth", "dyn_mask", "camray"]
@@ -35,16 +43,31 @@ def _run(sd, precision):
     m.l4p_model.task_heads["camray"].use_intrinsics = True
     m.load_state_dict({"l4p_model." + k: v for k, v in sd.items()})
     batch = make_batch(16, 8)
+    head = m.l4p_model.task_heads["track_2d"]
+    head.trace = []
     with torch.no_grad():
         out = m.forward({k: v.clone() for k, v in batch.items()}, ALL)
     torch.cuda.synchronize()
-    return out
+    return out, head.trace
+
+
+def _check_integer_state(trace, gold, nwin, precision, case, sel=slice(None), suffix=""):
+    """f32 engine: bit-exact against the reference's trace.  bf16 engine: tracks whose state differs anywhere in the recursion,
+    bounded by what the reference's own autocast run shows on these inputs (at least one near-tie is allowed)."""
+    bad = integer_state_mismatches(trace, gold, nwin, sel)
+    if precision == "32-true":
+        assert not bool(bad.any()), (case, bad)
+        return
+    ref_count = int(reference_autocast_drift(case)["tracks_with_differing_integer_state" + suffix])
+    print(f"bf16 integer-state mismatches vs the reference's trace ({case}): {int(bad.sum())} of {bad.numel()} tracks "
+          f"(the reference's own autocast run: {ref_count})")
+    assert int(bad.sum()) <= max(1, ref_count), (case, bad)
 
 
 @pytest.mark.parametrize("precision", ["32-true", "bf16"])
 def test_full_size_all_heads_vs_reference_goldens(dev, full_sd, precision):
     gold = np.load(os.path.join(ROOT, "tests", "golden", "full_T16_all.npz"))
-    out = _run(full_sd, precision)
+    out, trace = _run(full_sd, precision)
     feats = out["enc_features_bpc_2dlist"][0]
     report = {}
     for li in (14, 21, 28, 36, 40):
@@ -63,15 +86,16 @@ def test_full_size_all_heads_vs_reference_goldens(dev, full_sd, precision):
         bad = {k: v for k, v in report.items() if v[0] > 1e-3}
         assert not bad, bad
     else:
-        bad = {k: v for k, v in report.items() if v[1] > bf16_gate(k)}
-        assert not bad, bad
+        assert_bf16_within_reference_drift({k: v[1] for k, v in report.items()}, "full_T16_all")
+    _check_integer_state(trace, gold, 1, precision, "full_T16_all")
 
 
-BF16_GATE_FEATURES, BF16_GATE_HEADS = 1e-2, 3e-2
-
-
-def bf16_gate(key):
-    return BF16_GATE_FEATURES if key.startswith("feat") else BF16_GATE_HEADS
+def _self_gate(report, case="full_T16_all", track_case=None):
+    """Two bf16 runs of the engine through different kernels (batch sizes): their distance is gated by the reference's own
+    autocast drift of that output (each run is within that of the fp32 result).  ``track_case``: the fixture whose query set the
+    tracks belong to."""
+    ref, tref = reference_autocast_drift(case), reference_autocast_drift(track_case or case)
+    return {k: v for k, v in report.items() if v > (tref if k[1].startswith("track_2d") else ref)[k[1]]}
 
 
 OUT_KEYS = ["depth_est_b1thw", "flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw", "traj3d_est_b16t", "track_2d_traj_est_bn2t",
@@ -119,9 +143,9 @@ def test_batch4_bf16_equals_four_batch1_forwards_and_goldens(dev, full_sd):
     print("B=4 vs B=1 rel-L2:", {f"{i}:{k}": f"{v:.2e}" for (i, k), v in report.items()})
     # same arithmetic, different tile shapes / summation order: differences at bf16 rounding level, well inside the
     # bf16-vs-f32 drift gates
-    bad = {k: v for k, v in report.items() if v > (BF16_GATE_FEATURES if k[1].startswith("feat") else BF16_GATE_HEADS) / 2}
+    bad = _self_gate(report)
     assert not bad, bad
-    # clip 0 of the batch against the reference's goldens, at the bf16 gates
+    # clip 0 of the batch against the reference's goldens, within the reference's own autocast drift
     rep0 = {}
     for li in (36, 40):
         f = f4[li].reshape(4, -1)[0]
@@ -132,8 +156,8 @@ def test_batch4_bf16_equals_four_batch1_forwards_and_goldens(dev, full_sd):
         g = torch.from_numpy(gold[k]).reshape(-1)
         rep0[k] = _rel_l2(y[sample_indices(y.numel())] if y.numel() > 4096 else y, g)
     print("B=4 clip 0 vs goldens:", {k: f"{v:.2e}" for k, v in rep0.items()})
-    bad = {k: v for k, v in rep0.items() if v > bf16_gate(k)}
-    assert not bad, bad
+    assert_bf16_within_reference_drift(rep0, "full_T16_all", what="batch 4, clip 0")
+    _check_integer_state([trace4[0]], gold, 1, "bf16", "full_T16_all")
 
 
 def test_batch8_per_gpu_batch_of_configs3(dev, full_sd):
@@ -170,7 +194,7 @@ def test_batch8_per_gpu_batch_of_configs3(dev, full_sd):
                 assert torch.equal(trace8[i][name].cpu(), head.trace[0][name].cpu()), (i, name)
     head.trace = None
     print("B=8 vs B=1 rel-L2:", {f"{i}:{k}": f"{v:.2e}" for (i, k), v in report.items()})
-    bad = {k: v for k, v in report.items() if v > (BF16_GATE_FEATURES if k[1].startswith("feat") else BF16_GATE_HEADS) / 2}
+    bad = _self_gate(report)
     assert not bad, bad
     rep0 = {}
     for li in (36, 40):
@@ -181,8 +205,7 @@ def test_batch8_per_gpu_batch_of_configs3(dev, full_sd):
         g = torch.from_numpy(gold[k]).reshape(-1)
         rep0[k] = _rel_l2(y[sample_indices(y.numel())] if y.numel() > 4096 else y, g)
     print("B=8 clip 0 vs goldens:", {k: f"{v:.2e}" for k, v in rep0.items()})
-    bad = {k: v for k, v in rep0.items() if v > bf16_gate(k)}
-    assert not bad, bad
+    assert_bf16_within_reference_drift(rep0, "full_T16_all", what="batch 8, clip 0")
 
 
 @pytest.mark.parametrize("precision", ["32-true", "bf16"])
@@ -190,28 +213,36 @@ def test_full_size_two_windows_vs_reference_goldens(dev, full_sd, precision):
     """The windowed path (configs[4]) at the REAL geometry: 24 frames = 2 overlapping windows through the reference itself
     (tools/gen_golden_full_windows.py -> tests/golden/full_T24_windows.npz): depth with the inverse-depth LstSq seam, backward
     flow, motion mask, and 4 tracks carried across the seam (memory tokens, re-seeding).  f32 engine 1e-3 relative-to-max;
-    bf16 engine rel-L2 at the full-size gates of this file."""
+    bf16 engine within the reference's own autocast drift on these inputs; the tracker's integer state across the seam against
+    the reference's recorded trace (bit-exact in f32)."""
     tasks = ["depth", "flow_2d_backward", "dyn_mask", "track_2d"]
     gold = np.load(os.path.join(ROOT, "tests", "golden", "full_T24_windows.npz"))
     m = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision=precision)
     m.load_state_dict({"l4p_model." + k: v for k, v in full_sd.items()})
     batch = make_batch(24, 4)
+    head = m.l4p_model.task_heads["track_2d"]
+    head.trace = []
     with torch.no_grad():
         out = m.forward({k: v.clone() for k, v in batch.items()}, tasks)
     torch.cuda.synchronize()
     report = {}
     for k in gold.files:
+        if k.startswith("trace"):
+            continue
         y = out[k].float().cpu().reshape(-1)
         g = torch.from_numpy(gold[k]).reshape(-1)
         s = y[sample_indices(y.numel())] if y.numel() > 4096 else y
         assert s.shape == g.shape, (k, tuple(s.shape), tuple(g.shape))
         report[k] = (float((s - g).abs().max() / g.abs().max()), float((s - g).norm() / g.norm()))
     print(report)
-    for k, (emax, el2) in report.items():
-        if precision == "32-true":
+    if precision == "32-true":
+        for k, (emax, el2) in report.items():
             assert emax <= 1e-3, (k, emax)
-        else:
-            assert el2 <= 3e-2, (k, el2)
+    else:
+        assert_bf16_within_reference_drift({k: v[1] for k, v in report.items()}, "full_T24_windows",
+                                           small=[k for k in report if out[k].numel() < 4096])
+    # integer / boolean tracker state over the seam, at the real geometry, against the reference's own trace
+    _check_integer_state(head.trace, gold, 2, precision, "full_T24_windows")
 
 
 def _samples(y, g):
@@ -277,7 +308,7 @@ def test_benchmarked_configuration_itself(dev, full_sd):
     # of any camera: the batch-4 and batch-1 ray maps differ by bf16 rounding and the estimate legitimately lands elsewhere
     # (measured: rel-L2 ~1 between the two K).  Poses / K are therefore NOT tied to the batch-1 path; they are tied, for every
     # clip, to the CPU restatement of the estimator on the very ray map the batch-4 forward decoded (below).
-    bad = {k: v for k, v in report.items() if not k[1].startswith("traj3d") and v > BF16_GATE_HEADS / 2}
+    bad = _self_gate({k: v for k, v in report.items() if not k[1].startswith("traj3d")}, track_case="full_T16_q64")
     assert not bad, bad
     # ---- clip 0 against the reference ----
     rep0 = {}
@@ -287,8 +318,10 @@ def test_benchmarked_configuration_itself(dev, full_sd):
         assert tuple(out4[k][0].shape) == tuple(gq[k][0].shape), k
         rep0[k] = _rel_l2(out4[k][0], torch.from_numpy(gq[k][0]))
     print("bench config, clip 0 vs the reference:", {k: f"{v:.2e}" for k, v in rep0.items()})
-    bad = {k: v for k, v in rep0.items() if v > BF16_GATE_HEADS}
-    assert not bad, bad
+    assert_bf16_within_reference_drift({k: v for k, v in rep0.items() if not k.startswith("track")}, "full_T16_all",
+                                       what="bench config, dense")
+    assert_bf16_within_reference_drift({k: v for k, v in rep0.items() if k.startswith("track")}, "full_T16_q64",
+                                       what="bench config, 64 grid queries")
     # ---- K estimate and what follows from it, every clip ----
     for i in range(4):
         dirs = rays4[i, :3, 0].reshape(3, -1).T.numpy()
@@ -336,7 +369,7 @@ def test_depth_only_full_size_vs_reference_golden(dev, precision):
     if precision == "32-true":
         assert emax <= 1e-3, emax
     else:
-        assert el2 <= BF16_GATE_HEADS, el2
+        assert_bf16_within_reference_drift({"depth_est_b1thw": el2}, "full_T16_all", what="depth only")
 
 
 @pytest.mark.parametrize("precision", ["32-true", "bf16"])
@@ -357,10 +390,16 @@ def test_full_size_four_windows_joint_vs_reference_goldens(dev, full_sd, precisi
     m.l4p_model.task_heads["camray"].use_intrinsics = True
     m.load_state_dict({"l4p_model." + k: v for k, v in full_sd.items()})
     batch = make_batch(40, 8)
+    head = m.l4p_model.task_heads["track_2d"]
+    head.trace = []
     with torch.no_grad():
         out = m.forward({k: v.clone() for k, v in batch.items()}, ALL)
     torch.cuda.synchronize()
+    trace = head.trace
+    head.trace = None
     exact = precision == "32-true"
+    # integer / boolean tracker state over 4 windows / 3 re-seedings at the real geometry, against the reference's own trace
+    _check_integer_state(trace, gold, 4, precision, "full_T40_track24", suffix="[:8]")
     report = {}
     for k in ("flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw", "track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t",
               "track_2d_depth_est_bn1t"):
@@ -371,11 +410,16 @@ def test_full_size_four_windows_joint_vs_reference_goldens(dev, full_sd, precisi
         s, g = _samples(out[k], gold["engine." + k])
         report["engine." + k] = (float((s - g).abs().max() / g.abs().max()), float((s - g).norm() / g.norm()))
     print(precision, {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in report.items()})
-    for k, (emax, el2) in report.items():
-        if exact:
+    if exact:
+        for k, (emax, el2) in report.items():
             assert emax <= 1e-3, (k, emax)
-        elif not k.startswith("engine."):
-            assert el2 <= BF16_GATE_HEADS, (k, el2)
+    else:
+        # the reference's own autocast drift: the stitched flow / mask from its 2-window run, the tracks from its 4-window run of
+        # these very queries (the first 8 of full_T40_track24's)
+        assert_bf16_within_reference_drift({k: report[k][1] for k in ("flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw")},
+                                           "full_T24_windows", what="4 windows, dense")
+        assert_bf16_within_reference_drift({k: report[k][1] for k in report if k.startswith("track_2d")}, "full_T40_track24",
+                                           keymap={k: k + "[:8]" for k in report}, what="4 windows, tracks")
     # frames 0..7 are written by window 0 only: independent of the draws -> the reference's own values (full tensors are not
     # in the fixture; the sampled positions that fall into the first 8 frames are compared)
     for k in joint_keys:
@@ -386,7 +430,10 @@ def test_full_size_four_windows_joint_vs_reference_goldens(dev, full_sd, precisi
         s, g = y.reshape(-1)[idx][sel], torch.from_numpy(gold[k]).reshape(-1)[sel]
         assert int(sel.sum()) > 10
         e = float((s - g).abs().max() / g.abs().max()) if exact else float((s - g).norm() / g.norm())
-        assert e <= (1e-3 if exact else BF16_GATE_HEADS), ("first window", k, e)
+        if exact:
+            assert e <= 1e-3, ("first window", k, e)
+        else:
+            assert_bf16_within_reference_drift({k: e}, "full_T16_all", what="4 windows, first window")
     if exact:
         return
     per_win = []
@@ -403,3 +450,36 @@ def test_full_size_four_windows_joint_vs_reference_goldens(dev, full_sd, precisi
     for key, ek in (("depth_est_b1thw", "depth"), ("traj3d_est_b16t", "camray"), ("traj3d_intrinsics_est_b16t", "camray_intrinsics_est")):
         y, r = out[key].float().cpu(), est[ek]
         assert (y - r).abs().max() <= 1e-3 * r.abs().max(), (key, float((y - r).abs().max() / r.abs().max()), log)
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_full_size_24_tracks_four_windows_integer_state(dev, full_sd, precision):
+    """24 tracks with mixed start frames over 40 frames = 4 windows = 3 memory updates / re-seedings, tracker only, at the real
+    geometry, against the reference's own run (tools/gen_golden_full_autocast.py -> tests/golden/full_T40_track24.npz: complete
+    outputs + the per-window integer / boolean state).  f32 engine: floats 1e-3 relative-to-max, state bit-exact.  bf16 engine:
+    the reference's own autocast run flips the state of 3 of these 24 tracks (a re-seed argmax over 8 visibilities is a
+    near-tie for some): the engine is bounded by that count, and on the tracks whose state it reproduces its floats are within
+    the reference's drift."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "full_T40_track24.npz"))
+    m = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision=precision)
+    m.load_state_dict({"l4p_model." + k: v for k, v in full_sd.items()})
+    head = m.l4p_model.task_heads["track_2d"]
+    head.trace = []
+    batch = make_batch(40, 24)
+    with torch.no_grad():
+        out = m.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+    torch.cuda.synchronize()
+    trace, head.trace = head.trace, None
+    _check_integer_state(trace, gold, 4, precision, "full_T40_track24")
+    same = ~integer_state_mismatches(trace, gold, 4)
+    rep = {}
+    for k in ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"):
+        y, g = out[k].float().cpu(), torch.from_numpy(gold[k])
+        assert y.shape == g.shape, k
+        if precision == "32-true":
+            assert (y - g).abs().max() <= 1e-3 * g.abs().max(), (k, float((y - g).abs().max() / g.abs().max()))
+        else:
+            rep[k] = _rel_l2(y[:, same], g[:, same])
+    if rep:
+        print("24 tracks, 4 windows, bf16, tracks with the reference's state:", int(same.sum()), {k: f"{v:.2e}" for k, v in rep.items()})
+        assert_bf16_within_reference_drift(rep, "full_T40_track24", what="24 tracks")

@@ -38,6 +38,7 @@ def test_three_window_stitch_vs_reference_goldens(dev, precision):
         out = model.forward({k: v.clone() for k, v in batch.items()}, DENSE)
         ref = OracleModel(sd, cfg).forward(batch, DENSE)
     torch.cuda.synchronize()
+    drift = {}
     for key in KEYS:
         y = out[key].float().cpu()
         assert tuple(y.shape) == tuple(ref[key].shape) and y.shape[2] == 32, key
@@ -47,8 +48,13 @@ def test_three_window_stitch_vs_reference_goldens(dev, precision):
             assert (s - g).abs().max() <= 1e-3 * g.abs().max(), (key, float((s - g).abs().max() / g.abs().max()))
             assert (y - ref[key]).abs().max() <= 1e-3 * ref[key].abs().max(), key
         else:
-            assert rel_l2(s, g) <= 3e-2, (key, rel_l2(s, g))
-            assert rel_l2(y, ref[key]) <= 3e-2, (key, rel_l2(y, ref[key]))
+            drift[key] = rel_l2(y, ref[key])
+            assert abs(rel_l2(s, g) - drift[key]) <= 0.1 * drift[key], (key, rel_l2(s, g), drift[key])  # samples ~ full tensor
+    if drift:
+        # the bf16 engine against the reference's OWN autocast drift over these 3 windows (tools/gen_golden_full_autocast.py)
+        from tests.golden_utils import assert_bf16_within_reference_drift
+
+        assert_bf16_within_reference_drift(drift, "mini_T32_stitch")
 
 
 def _safe_inverse(x):

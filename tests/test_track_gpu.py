@@ -2,11 +2,12 @@
 single window and 3-window sliding tracking (memory tokens, prompt-feature carry, query re-seeding)
 against the oracle run live and the reference's golden vectors.
 
-Float outputs: L4P_F32 engine 1e-3 relative-to-max (north_star); L4P_BF16 engine rel-L2 <= 2e-2 (bf16
-drift through 4 encoder blocks + 2 two-way layers: 1e-3 .. 7e-3 measured).  Integer / boolean window state (labels,
+Float outputs: L4P_F32 engine 1e-3 relative-to-max (north_star); L4P_BF16 engine: within the reference's OWN mixed-precision
+drift on the same inputs (the imported reference under torch.autocast(bfloat16) vs its fp32 run, tests/golden/
+reference_autocast_drift.json; golden_utils.assert_bf16_within_reference_drift).  Integer / boolean window state (labels,
 prompt labels, validity masks, re-seeded query times = argmax index) is asserted BIT-EXACT in f32 mode
 against both the oracle trace and the reference's recorded trace; in bf16 mode the tracks whose state differs
-from the f32 trace are counted and bounded (<= 1 per fixture)."""
+from the f32 trace are counted and bounded by the count the reference's own autocast run shows (min. 1)."""
 import os
 
 import numpy as np
@@ -45,6 +46,7 @@ def test_tracker_vs_oracle_and_golden(dev, mini, precision, case, T, nq):
         oout = OracleModel(sd, cfg).forward(batch, ["track_2d"], trace=otrace)
     torch.cuda.synchronize()
     exact = precision == "32-true"
+    drift = {}
     for key in ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]:
         y, ref = out[key].float().cpu(), oout[key]
         assert y.shape == ref.shape
@@ -53,7 +55,11 @@ def test_tracker_vs_oracle_and_golden(dev, mini, precision, case, T, nq):
             g = torch.from_numpy(gold[key])
             assert (y - g).abs().max() <= 1e-3 * g.abs().max(), key
         else:
-            assert rel_l2(y, ref) <= 2e-2, (key, rel_l2(y, ref))  # measured 1e-3 .. 7e-3: ~2x the drift
+            drift[key] = rel_l2(y, ref)
+    if drift:
+        from tests.golden_utils import assert_bf16_within_reference_drift
+
+        assert_bf16_within_reference_drift(drift, case)
     nwin = (T - 16) // 8 + 1
     assert len(head.trace) == nwin == len(otrace)
     if exact:
@@ -81,8 +87,12 @@ def test_tracker_vs_oracle_and_golden(dev, mini, precision, case, T, nq):
             differing |= tr["queries"][:, 0].cpu() != otrace[w]["queries"][:, 0]
             if "best_vis_id" in otrace[w]:
                 differing |= tr["best_vis_id"].cpu().long() != otrace[w]["best_vis_id"]
-        print(f"bf16 integer-state mismatches vs f32 trace ({case}): {int(differing.sum())} of {nq} tracks")
-        assert int(differing.sum()) <= 1, differing
+        from tests.golden_utils import reference_autocast_drift
+
+        ref_count = int(reference_autocast_drift(case)["tracks_with_differing_integer_state"])
+        print(f"bf16 integer-state mismatches vs f32 trace ({case}): {int(differing.sum())} of {nq} tracks "
+              f"(the reference's own autocast run: {ref_count})")
+        assert int(differing.sum()) <= max(1, ref_count), differing
 
 
 @pytest.mark.parametrize("precision", ["32-true", "bf16"])
@@ -174,6 +184,7 @@ def test_single_window_entry_vs_reference_golden(dev, mini, precision):
     torch.cuda.synchronize()
     from tests.golden_utils import sample_indices
 
+    drift = {}
     for k in gold.files:
         y = out[k].float().cpu().reshape(-1)
         g = torch.from_numpy(gold[k]).reshape(-1)
@@ -181,7 +192,11 @@ def test_single_window_entry_vs_reference_golden(dev, mini, precision):
         if precision == "32-true":
             assert (s - g).abs().max() <= 1e-3 * g.abs().max(), (k, float((s - g).abs().max() / g.abs().max()))
         else:
-            assert rel_l2(s, g) <= 5e-2, (k, rel_l2(s, g))
+            drift[k] = rel_l2(s, g)
+    if drift:
+        from tests.golden_utils import assert_bf16_within_reference_drift
+
+        assert_bf16_within_reference_drift(drift, "mini_T16_single_window")
     for k in ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t", "track_2d_prompt_features_bnc"):
         assert torch.equal(out[k], again[k]), k
     # unmasked: frames before the query time carry estimates, not the -10 / 0 fill of the sliding tracker
