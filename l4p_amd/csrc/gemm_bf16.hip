@@ -2,5 +2,6 @@
 #define GEMM_FN launch_gemm_bf16
 #define GEMM_HAS_8P 1
 #include "gemm8p.hpp"
+#include "gemm4w.hpp"
 #include "conv3_halo.hpp"
 #include "gemm_launch.inc"

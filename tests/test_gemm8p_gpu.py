@@ -21,6 +21,7 @@ from l4p_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_DENSE, EPI_MASKDOT, L
 from tests.test_kernels_gpu import as_mode, check, rnd
 
 MODE = L4P_BF16
+FORM_TAG = " 8p "  # the kernel form every test here asserts (tests/test_gemm4w_gpu.py re-runs some of them on the " 4w " form)
 
 
 class prof_tags:
@@ -46,7 +47,7 @@ class prof_tags:
 
     def assert_8p(self, cls="gemm", n=1):
         tags = [ln[1] for ln in self.lines if ln[0] == cls]
-        assert len(tags) >= n and all(" 8p " in t for t in tags), f"expected the 8-phase kernel, launches were: {self.lines}"
+        assert len(tags) >= n and all(FORM_TAG in t for t in tags), f"expected the{FORM_TAG}kernel, launches were: {self.lines}"
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 6144, 1408),   # fc1 (+ GELU below)

@@ -33,8 +33,8 @@ def _usage(src):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_hot_kernels_do_not_spill():
     gemm = _usage("gemm_bf16.hip")
-    hot = [k for k in gemm if "gemm8p_kernel" in k or ("gemm_kernel" in k and "ELb1E" in k)]
-    assert len(hot) >= 4, sorted(gemm)
+    hot = [k for k in gemm if "gemm8p_kernel" in k or "gemm4w_kernel" in k or ("gemm_kernel" in k and "ELb1E" in k)]
+    assert len(hot) >= 5 and any("gemm4w_kernel" in k for k in hot), sorted(gemm)
     for k in hot:
         assert gemm[k]["ScratchSize [bytes/lane]"] == 0, (k, gemm[k])
         assert gemm[k]["VGPRs"] <= 256

@@ -13,6 +13,7 @@ void l4p_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprin
 #define GEMM_HAS_8P 1
 #include <type_traits>
 #include "../../l4p_amd/csrc/gemm8p.hpp"
+#include "../../l4p_amd/csrc/gemm4w.hpp"
 #define GEMM_T bf16_t
 #define GEMM_FN launch_gemm_bf16
 #include "../../l4p_amd/csrc/gemm_launch.inc"
