@@ -7,42 +7,50 @@
 // share vmcnt and retire in order; measured slower).  Here a workgroup is HALF a CU's worth of waves:
 //
 //  * 256 threads = 4 waves (one per SIMD), workgroup tile 256 x 128, wave tile 128 x 64 (the 8-phase kernel's: 8 x 4 MFMA tiles,
-//    the same fragment reads per MFMA), 72 KB of LDS, <= 256 VGPRs: TWO workgroups are resident per CU and share each SIMD's
-//    matrix pipe.  They are independent - own barrier, own tile - and the SIMD arbitrates by age: the older workgroup's waves
+//    the same fragment reads per MFMA), 80 KB of LDS, <= 256 VGPRs: TWO workgroups are resident per CU and share each SIMD's
+//    matrix pipe.  They are independent - own barriers, own tile - and the SIMD arbitrates by age: the older workgroup's waves
 //    win the pipe, finish first, and their epilogue (and the next workgroup's prologue in that slot) runs under the younger
-//    workgroup's main loop.  After the first tile the two slots of a CU stay about half a tile apart by themselves.
-//  * k-step = 32 (one 16x16x32 MFMA deep), three LDS stages of 24 KB (A 256 rows + W 128 rows of 64 bytes), two in flight.
-//    One raw s_barrier per k-step (32 MFMAs per wave): wait (counted vmcnt) for the own pieces of stage t -> barrier (everyone's
-//    stage t landed, everyone has finished reading stage t - 1) -> stage t + 2 into the slot stage t - 1 used, its six LDS-DMA
-//    pieces spread behind the MFMAs -> 12 ds_read_b128 (inline asm, hand-counted lgkmcnt) + 32 MFMAs.
+//    workgroup's main loop.
+//  * k-tile = 64 with 128-byte LDS rows, i.e. every LDS-DMA piece (1 KB per wave instruction) is EIGHT FULL 128-byte lines.  A
+//    first form of this kernel used 32-deep stages of 64-byte rows (three stages fit the 80 KB): a piece then touches sixteen
+//    half lines, and the CU's address / tag path - not L2, not the piece count - bounded the main loop: 1085 -> 1423 TF/s by
+//    fetching whole lines in an otherwise identical loop (tools/probes/gemm4w_probe.hip, M131072 N2816 K1408).
+//  * 80 KB = A double-buffered (2 x 256 rows x 128 B) + W SINGLE-buffered (128 rows x 128 B).  A k-tile:
+//        wait vmcnt(0) (own pieces of k-tile t) | barrier 1 (everyone's landed; everyone is done with A(t-1))
+//        8 W fragment reads (all of W(t) a wave needs: 32 VGPRs, held for the k-tile) + the first A fragments
+//        MFMAs 0-3 | barrier 2 (every wave holds W(t) in registers: the W buffer is free)
+//        MFMAs 4-63 with, behind them: the remaining A fragment reads (a 6-slot register ring, one read per 4 MFMAs, inline asm
+//        with hand-counted lgkmcnt) and the 12 LDS-DMA pieces of k-tile t+1 (8 A into the other A buffer, 4 W), one per
+//        PSTEP MFMAs so that the last is issued well before the k-tile ends.
 //  * staging by buffer_load ... lds (LDS-DMA through a buffer descriptor): the per-lane byte offset of a piece is loop invariant
-//    (one VGPR), the k offset is the instruction's SCALAR offset - no vector address arithmetic in the loop at all (the
-//    global_load_lds form of the other kernels re-derives a 64-bit address per piece and k-tile).  K % 32 == 0 is required
-//    (the launcher sends other shapes to the 8-phase kernel).
-//  * 64-byte LDS rows: chunk c of row r sits at c ^ (((r >> 2) & 1) << 1) in the A tile and at c ^ (((r >> 5) & 1) << 1) in
-//    the W tile (whose fragment rows are the permuted 16 q + 4 j + r of the epilogue's column order): both conflict-free for the
-//    four 16-lane groups of ds_read_b128; the swizzle is applied to the per-lane SOURCE chunk of the LDS-DMA.
+//    (one VGPR), the k offset is the instruction's SCALAR offset - no vector address arithmetic in the loop (the global_load_lds
+//    form of the other kernels re-derives a 64-bit address per piece and k-tile).  Chunks past K (K % 8 == 0; last k-tile only)
+//    read as zero through the descriptor's range check: the lane's offset is moved past num_records (soffset is not checked).
+//  * swizzles as gemm.hpp: A chunk ^= (row >> 1) & 7; W (natural n order in LDS, fragment rows 16 q + 4 j + r) chunk ^=
+//    (q << 1) | ((row >> 1) & 1): conflict-free ds_read_b128; applied to the per-lane SOURCE chunk of the LDS-DMA.
 //
 // L2 -> LDS bytes per output are 1.5x the 256 x 256 tile's (A 256 + W 128 rows per 32 768 outputs against 512 per 65 536).
 #pragma once
 #include "gemm.hpp"
 
 struct Gemm4wCfg {
-    static constexpr int BM = 256, BN = 128, BK = 32, STAGES = 3;
-    static constexpr int A_STAGE = BM * 64, W_STAGE = BN * 64, STAGE = A_STAGE + W_STAGE;
-    static constexpr int LDS_BYTES = STAGES * STAGE;
+    static constexpr int BM = 256, BN = 128, BK = 64;
+    static constexpr int A_BUF = BM * 128, W_BUF = BN * 128;
+    static constexpr int LDS_BYTES = 2 * A_BUF + W_BUF;
 };
 
-template <bool SPLITK = false>
+// DBG (tools/probes/gemm4w_probe.hip only; 0 in the library): 1 no epilogue, 2 no LDS-DMA in the loop, 4 no fragment reads,
+// 8 no s_setprio
+template <bool SPLITK = false, int DBG = 0, int PSTEP = 3>
 __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const GemmParams p) {
     typedef bf16_t T;
     typedef Gemm4wCfg Cfg;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, TM = 8, TN = 4;
-    constexpr int A_ST = Cfg::A_STAGE, ST = Cfg::STAGE;
-    constexpr int NLD = 6;  // LDS-DMA pieces per wave and stage (4 A passes + 2 W passes of 64 rows)
+    constexpr int A_BUF = Cfg::A_BUF;
+    constexpr int NPA = 8, NPW = 4, NLD = NPA + NPW;  // LDS-DMA pieces per wave and k-tile (passes of 32 rows)
     typedef __attribute__((address_space(3))) void* lptr_t;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][A 256 x 64 B | W 128 x 64 B]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [A buffer 0 | A buffer 1 | W]
 
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,23 +83,27 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const GemmParams p) {
         m0 = mt * BM, n0 = nt_ * BN;
     }
 
-    // ---- staging: lane (srow, slot) of a 64-row pass fetches source chunk cs of its row ----
-    const int srow = tid >> 2, slot = tid & 3;
-    const int cs_a = slot ^ (((srow >> 2) & 1) << 1), cs_w = slot ^ (((srow >> 5) & 1) << 1);
-    constexpr unsigned OOB = 0x80000000u;  // num_records of both descriptors (every offset is below it: checked by the launcher)
-    unsigned a_vo[4], w_vo[2];
+    // ---- staging: lane (crow, cc) of a 32-row pass fetches source chunk cs of its row ----
+    const int crow = tid >> 3, cc = tid & 7;
+    const int cs_a = cc ^ ((crow >> 1) & 7);
+    constexpr unsigned OOB = 0x80000000u;  // num_records of both descriptors (every valid offset is below it: the launcher checks)
+    unsigned a_vo[NPA], w_vo[NPW];
+    auto cs_w = [&](int i) {  // W rows are read through the permuted fragment row map: their own XOR phase (gemm.hpp, sww)
+        const int row = i * 32 + crow;
+        return cc ^ (((((row & 63) >> 4) & 3) << 1) | ((row >> 1) & 1));
+    };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + i * 64 + srow;
+    for (int i = 0; i < NPA; ++i) {
+        int m = m0 + i * 32 + crow;
         if (m >= p.M) m = p.M - 1;  // rows past M are computed on a clamped row and never stored
         const long long pm = p.a_gr > 0 ? (long long)(m / p.a_gr) * p.a_gs + p.a_go + (m % p.a_gr) : m;
-        a_vo[i] = (unsigned)(pm * p.lda * 2 + cs_a * 16);  // (< 2^31: checked by the launcher)
+        a_vo[i] = (unsigned)(pm * p.lda * 2 + cs_a * 16);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int n = n0 + i * 64 + srow;
+    for (int i = 0; i < NPW; ++i) {
+        int n = n0 + i * 32 + crow;
         if (n >= p.N) n = p.N - 1;
-        w_vo[i] = (unsigned)((long long)n * p.ldw * 2 + cs_w * 16);
+        w_vo[i] = (unsigned)((long long)n * p.ldw * 2 + cs_w(i) * 16);
     }
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)OOB, 0x00020000);
@@ -100,23 +112,36 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const GemmParams p) {
     const int kt0 = SPLITK ? (int)((long long)nk_all * ksplit / nsplit) : 0;
     const int nk = SPLITK ? (int)((long long)nk_all * (ksplit + 1) / nsplit) - kt0 : nk_all;
 
-    // one piece (q = 0..3: A pass q, 4..5: W pass q - 4) of k-step kt into stage slot sl
-    auto stage_piece = [&](auto q_, int kt, auto sl_) {
-        constexpr int q = decltype(q_)::value, sl = decltype(sl_)::value;
+    // piece q (0..7: A pass q, 8..11: W pass q - 8) of k-tile kt; A pieces go to A buffer ab.  or_a / or_w[q & 1]: zero, or - in
+    // the matrix's last, partial k-tile - bit 31 for the lanes whose chunk lies at or past K: the offset then falls outside the
+    // descriptor's range and the piece reads as zero there (tail_or below; the XOR phase of a W row depends on the pass parity only)
+    unsigned or_a = 0u, or_w[2] = {0u, 0u};
+    auto tail_or = [&](int kt) {
+        const int krem = p.K - (kt0 + kt) * BK;  // valid k in this k-tile (>= 64 except in the tail tile)
+        or_a = cs_a * 8 >= krem ? OOB : 0u;
+        or_w[0] = cs_w(0) * 8 >= krem ? OOB : 0u;
+        or_w[1] = cs_w(1) * 8 >= krem ? OOB : 0u;
+    };
+    auto stage_piece = [&](auto q_, int kt, auto ab_) {
+        constexpr int q = decltype(q_)::value, ab = decltype(ab_)::value;
         const int kabs = kt0 + kt;
-        const unsigned vo = q < 4 ? a_vo[q < 4 ? q : 0] : w_vo[q >= 4 ? q - 4 : 0];
-        char* dst = smem + sl * ST + (q < 4 ? q * 64 * 64 : A_ST + (q - 4) * 64 * 64) + wave * (16 * 64);
-        if (q < 4)
+        const unsigned vo = q < NPA ? (a_vo[q < NPA ? q : 0] | or_a) : (w_vo[q >= NPA ? q - NPA : 0] | or_w[q & 1]);
+        char* dst = smem + (q < NPA ? ab * A_BUF + q * 4096 : 2 * A_BUF + (q - NPA) * 4096) + wave * 1024;
+        if (q < NPA)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)dst, 16, vo, kabs * (BK * 2), 0, 0);
         else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)dst, 16, vo, kabs * (BK * 2), 0, 0);
     };
-    auto stage_all = [&](int kt, auto sl_) { static_for_<0, NLD>([&](auto q_) { stage_piece(q_, kt, sl_); }); };
 
-    // ---- fragment read addresses (LDS byte addresses; stage, A tile i and W tile j are instruction offsets) ----
+    // ---- fragment read addresses (LDS byte addresses; buffer, A tile i and W tile j are instruction offsets) ----
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
-    const unsigned a_ad = lds0 + (wr * 128 + li) * 64 + ((kg ^ (((li >> 2) & 1) << 1)) << 4);
-    const unsigned w_ad = lds0 + A_ST + (wc * 64 + 16 * (li >> 2) + (li & 3)) * 64 + ((kg ^ (((li >> 3) & 1) << 1)) << 4);
+    const int swa = (li >> 1) & 7, swq = (((li >> 2) & 3) << 1) | ((li >> 1) & 1);
+    unsigned a_ad[2], w_ad[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        a_ad[kk] = lds0 + (wr * 128 + li) * 128 + (((kk * 4 + kg) ^ swa) << 4);                                  // + i * 2048
+        w_ad[kk] = lds0 + 2 * A_BUF + (wc * 64 + 16 * (li >> 2) + (li & 3)) * 128 + (((kk * 4 + kg) ^ swq) << 4);  // + j * 512
+    }
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -124,64 +149,69 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: stages 0 and 1 ----
-    stage_all(0, std::integral_constant<int, 0>{});
-    if (nk > 1) stage_all(1, std::integral_constant<int, 1>{});
+    // ---- prologue: k-tile 0 ----
+    const bool ktail = (p.K & (BK - 1)) != 0;  // the matrix's last k-tile is partial
+    if (ktail && kt0 + 1 == nk_all) tail_or(0);
+    static_for_<0, NLD>([&](auto q_) { stage_piece(q_, 0, std::integral_constant<int, 0>{}); });
 
-    // One k-step on stage slot SL.  Reads (in order): A_0, W_0..W_3, A_1..A_7; MFMAs i-major; MFMA m may issue once the only
-    // outstanding reads are those requested after its operands (LDS reads return in order).  All 12 reads are requested up front
-    // - the other workgroup's wave on this SIMD owns the matrix pipe meanwhile -, the six pieces of stage t + 2 follow behind
-    // MFMAs 2, 7, 12, ... (an LDS-DMA issue is ~60 cycles of this wave's issue time: inside the MFMA shadow it is free).
-#ifndef GEMM4W_PRE
-#define GEMM4W_PRE 12
-#endif
-#ifndef GEMM4W_PRIO
-#define GEMM4W_PRIO 1
-#endif
-    auto kstep = [&](int t, auto sl_) {
-        constexpr int SL = decltype(sl_)::value, NXT = (SL + 2) % 3;
-        constexpr int NR = TM + TN, NM = TM * TN, PRE = GEMM4W_PRE < NR ? GEMM4W_PRE : NR;
-        if (t + 1 < nk)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");  // own pieces of stage t landed (stage t + 1 may fly)
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // One k-tile on A buffer AB.  LDS reads in issue order: W(kk, j) (8), then A fragment g = kk * 8 + i (16); before MFMA 0 the W
+    // reads and PREA A fragments are requested, fragment g + PREA behind the first MFMA of fragment g.  MFMA m: kk = m / 32,
+    // i = (m % 32) / 4, j = m % 4.  LDS reads return in order: MFMA 4 g may issue once at most (issued - 9 - g) reads are outstanding.
+    constexpr int PREA = 4, RA = PREA + 2;  // A fragments requested ahead; register ring (a slot is rewritten two fragments later)
+    auto ktile = [&](int t, auto ab_) {
+        constexpr int AB = decltype(ab_)::value;
+        constexpr bool PRIO = !(DBG & 8);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of k-tile t have landed
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const bool more = t + 2 < nk;
-        u32x4 fr[NR];
-        auto rd = [&fr, a_ad, w_ad](auto r_) {
-            constexpr int r = decltype(r_)::value;
-            if constexpr (r == 0)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[r]) : "v"(a_ad), "n"(SL * ST) : "memory");
-            else if constexpr (r <= TN)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[r]) : "v"(w_ad), "n"(SL * ST + (r - 1) * 256) : "memory");
+        const bool more = t + 1 < nk && !(DBG & 2);
+        if (ktail && kt0 + t + 2 == nk_all) tail_or(t + 1);  // (wave-uniform; once per tile)
+        u32x4 fw[2][TN], fa[RA];
+        auto rd_w = [&fw, &w_ad](auto r_) {
+            constexpr int r = decltype(r_)::value, kk = r / TN, j = r % TN;
+            if constexpr ((DBG & 4) != 0)
+                asm volatile("v_mov_b32 %0, 0x3f803f80\n\tv_mov_b32 %1, 0x3f803f80\n\tv_mov_b32 %2, 0x3f803f80\n\tv_mov_b32 %3, 0x3f803f80"
+                             : "=v"(fw[kk][j][0]), "=v"(fw[kk][j][1]), "=v"(fw[kk][j][2]), "=v"(fw[kk][j][3]));
             else
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[r]) : "v"(a_ad), "n"(SL * ST + (r - TN) * 1024) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[kk][j]) : "v"(w_ad[kk]), "n"(j * 512) : "memory");
         };
-        static_for_<0, PRE>(rd);
-        if (GEMM4W_PRIO) __builtin_amdgcn_s_setprio(1);
-        static_for_<0, NM>([&](auto m_) {
-            constexpr int m = decltype(m_)::value, i = m / TN, j = m % TN;
-            constexpr int ra = i == 0 ? 0 : TN + i, rw = 1 + j;
-            constexpr int need = ra > rw ? ra : rw;
-            constexpr int issued = (PRE + m < NR) ? PRE + m : NR;
-            static_assert(need < issued, "operand requested before use");
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(issued - need - 1 > 15 ? 15 : issued - need - 1) : "memory");
+        auto rd_a = [&fa, &a_ad](auto g_) {
+            constexpr int g = decltype(g_)::value, kk = g / TM, i = g % TM;
+            if constexpr ((DBG & 4) != 0)
+                asm volatile("v_mov_b32 %0, 0x3f803f80\n\tv_mov_b32 %1, 0x3f803f80\n\tv_mov_b32 %2, 0x3f803f80\n\tv_mov_b32 %3, 0x3f803f80"
+                             : "=v"(fa[g % RA][0]), "=v"(fa[g % RA][1]), "=v"(fa[g % RA][2]), "=v"(fa[g % RA][3]));
+            else
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[g % RA]) : "v"(a_ad[kk]), "n"(AB * A_BUF + i * 2048) : "memory");
+        };
+        static_for_<0, 2 * TN>(rd_w);
+        static_for_<0, PREA>(rd_a);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        static_for_<0, 2 * TM * TN>([&](auto m_) {
+            constexpr int m = decltype(m_)::value, kk = m / (TM * TN), i = (m % (TM * TN)) / TN, j = m % TN, g = m / TN;
+            if constexpr (j == 0) {  // first MFMA of fragment g: reads issued so far = 8 + min(16, PREA + g), fragment g is read 8 + g
+                constexpr int issued = 2 * TN + (PREA + g < 2 * TM ? PREA + g : 2 * TM);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(issued - (2 * TN + g) - 1) : "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
-            acc[i][j] = mma16(__builtin_bit_cast(bf16x8, fr[rw]), __builtin_bit_cast(bf16x8, fr[ra]), acc[i][j]);
+            acc[i][j] = mma16(__builtin_bit_cast(bf16x8, fw[kk][j]), __builtin_bit_cast(bf16x8, fa[g % RA]), acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PRE + m < NR) rd(std::integral_constant<int, PRE + m>{});
-            if constexpr (m % 5 == 2 && m / 5 < NLD) {
-                if (more) stage_piece(std::integral_constant<int, m / 5>{}, t + 2, std::integral_constant<int, NXT>{});
+            if constexpr (j == 0 && g + PREA < 2 * TM) rd_a(std::integral_constant<int, (g + PREA < 2 * TM ? g + PREA : 0)>{});
+            if constexpr (m == TN - 1) {  // every wave holds W(t) in registers (the wait of MFMA 0 covered the eight W reads)
+                if (PRIO) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+                if (PRIO) __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (m >= TN && (m - TN) % PSTEP == PSTEP - 1 && (m - TN) / PSTEP < NLD) {
+                if (more) stage_piece(std::integral_constant<int, (m - TN) / PSTEP>{}, t + 1, std::integral_constant<int, AB ^ 1>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
-        if (GEMM4W_PRIO) __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
-    for (int t = 0; t < nk; t += 3) {
-        kstep(t, std::integral_constant<int, 0>{});
-        if (t + 1 < nk) kstep(t + 1, std::integral_constant<int, 1>{});
-        if (t + 2 < nk) kstep(t + 2, std::integral_constant<int, 2>{});
+    for (int t = 0; t < nk; t += 2) {
+        ktile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nk) ktile(t + 1, std::integral_constant<int, 1>{});
     }
 
     const int mw = m0 + wr * (TM * 16), nw = n0 + wc * (TN * 16);
@@ -198,16 +228,14 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const GemmParams p) {
         }
         return;
     } else {
-#ifdef GEMM_DBG_NOEPI  // (tools/probes: main-loop-only timing)
+        if constexpr ((DBG & 1) != 0) {  // main-loop-only timing
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
-#else
-        if (p.epi == EPI_MASKDOT)
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else if (p.epi == EPI_MASKDOT)
             gemm_epilogue_maskdot<T, TM, TN>(p, acc, mw, nw, li, kg);
         else if (!gemm_epilogue_dense_dispatch<T, TM, TN>(p, acc, mw, nw, li, kg))
             gemm_epilogue<T, TM, TN, true>(p, acc, mw, nw, li, kg);
-#endif
     }
 }
