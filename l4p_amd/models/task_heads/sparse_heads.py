@@ -357,9 +357,16 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                     f"{self.task_name}_depth_est_bn1t": torch.zeros(B, 0, 1, T, **z)}
         P, Cc = cfg.tokens, cfg.dim
         f32 = dict(dtype=torch.float32, device=dev)
-        traj_all = torch.zeros(B, N, 2, T, **f32)
-        vis_all = torch.full((B, N, 1, T), -10.0, **f32)
-        dep_all = torch.zeros(B, N, 1, T, **f32)
+        def output_buffers():
+            return (torch.zeros(B, N, 2, T, **f32), torch.full((B, N, 1, T), -10.0, **f32), torch.zeros(B, N, 1, T, **f32))
+
+        # (start_event: the clip streams wait for that event only, not for what the launching stream has queued since - the fills
+        #  of the output buffers must then run on a clip stream too, or they would land behind that queue and wipe the results)
+        early = (getattr(self, "start_event", None) is not None and bool(getattr(self, "own_stream", False)) and dev.type == "cuda"
+                 and os.environ.get("L4P_TRACK_STREAMS", "1") != "0")
+        traj_all = vis_all = dep_all = None
+        if not early:
+            traj_all, vis_all, dep_all = output_buffers()
         nwin = len(time_strides)
         # Clips are independent (the reference asserts B == 1, sparse_heads.py:241).  Each clip's tracker runs on its own
         # HIP stream: its many token-side launches are tiny (M = 6N rows -> a few dozen workgroups) and leave most CUs
@@ -380,7 +387,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             valid_t = torch.empty(N, ws, dtype=torch.uint8, device=dev)
             valid_n = torch.empty(N, dtype=torch.uint8, device=dev)
             best = torch.zeros(N, dtype=torch.int32, device=dev)
-            traj_b, vis_b, dep_b = traj_all[b], vis_all[b, :, 0], dep_all[b, :, 0]
+            traj_b, vis_b, dep_b = traj_all[b], vis_all[b, :, 0], dep_all[b, :, 0]  # (late binding: set before any clip runs)
             for wi in range(nwin):
                 start = int(time_strides[wi])
                 last = wi == nwin - 1
@@ -409,15 +416,26 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 if self.trace is not None and not last:
                     self.trace[-1]["best_vis_id"] = best.clone()
 
-        use_streams = B > 1 and dev.type == "cuda" and os.environ.get("L4P_TRACK_STREAMS", "1") != "0"
+        # (own_stream: a single clip goes to a stream of its own as well - parallel.forward_windows_sharded starts the recursion
+        #  of a long video before the dense decoders and joins it before the seam alignment)
+        use_streams = ((B > 1 or bool(getattr(self, "own_stream", False))) and dev.type == "cuda"
+                       and os.environ.get("L4P_TRACK_STREAMS", "1") != "0")
         if use_streams:
             main = torch.cuda.current_stream()
             pool = getattr(self, "_clip_streams", None)
             if pool is None or len(pool) < B:
                 pool = [torch.cuda.Stream(device=dev) for _ in range(B)]
                 self._clip_streams = pool
+            start = getattr(self, "start_event", None) if early else None  # what the clip streams wait for: an event of the
+            if start is not None:                       # launching stream (parallel.forward_windows_sharded), else everything
+                pool[0].wait_event(start)               # queued on it so far
+                with torch.cuda.stream(pool[0]):
+                    traj_all, vis_all, dep_all = output_buffers()
             for b in range(B):
-                pool[b].wait_stream(main)
+                if start is None:
+                    pool[b].wait_stream(main)
+                elif b > 0:
+                    pool[b].wait_stream(pool[0])
                 with torch.cuda.stream(pool[b]):
                     self._ws_slot = b + 1  # concurrent clips: one native workspace each
                     run_clip(b)

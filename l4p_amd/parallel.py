@@ -75,11 +75,11 @@ def shard(n_items: int, rank: int, world: int) -> List[int]:
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Config 5: one long video -> overlapping 16-frame windows sharded over the ranks.
-# The expensive, window-local work (encoder + DPT decoders) runs on the rank that owns the window; ONE exchange step
-# (all-gather of the decoded windows and of the last-layer features) follows; the cheap sequential part (overlap alignment,
-# stitching, pose chaining) then runs replicated on every rank from identical inputs, and the tracker - a recursion over
-# windows that is independent per query - runs on a shard of the queries whose results are all-gathered.
-# The stitched outputs are therefore bit-identical to the single-GPU windowed forward.
+# The expensive, window-local work (encoder + DPT decoders) runs on the rank that owns the window; two exchange steps (all-gather
+# of the last-layer features right after the encoders, of the decoded windows after the decoders); the cheap sequential part
+# (overlap alignment, stitching, pose chaining) then runs replicated on every rank from identical inputs, and the tracker - a
+# recursion over windows that is independent per query - runs on a shard of the queries, beside the decoders, and its results
+# are all-gathered.  The stitched outputs are therefore bit-identical to the single-GPU windowed forward.
 # ---------------------------------------------------------------------------------------------------------------------
 def window_chunks(n_windows: int, world: int) -> List[Tuple[int, int]]:
     """Contiguous [start, end) window ranges per rank, sizes differing by at most one (31 windows, 8 ranks -> 4,4,4,4,4,4,4,3)."""
@@ -160,31 +160,69 @@ def all_gather_queries(x: torch.Tensor, n_queries: int, rank: int, world: int, d
     return full.movedim(0, dim).contiguous()
 
 
-def decode_local_windows(net, data: dict, tasks: List[str], rank: int, world: int, group: int = 1) -> dict:
-    """Phase 1 (sharded, all the FLOPs): encoder + DPT decoders of this rank's windows -> {window id: {key: tensor}}."""
+def encode_local_windows(net, data: dict, tasks: List[str], rank: int, world: int, group: int = 1) -> list:
+    """Phase 1a (sharded): the encoder of this rank's windows, ``group`` windows per launch group.
+    Returns [(window ids, EncoderFeatures of that group)] - the hook features the DPT decoders read stay on the device until
+    decode_encoded_windows has run (23 MB per window in bf16), the float last-layer features are what the tracker reads."""
     rgb = data["rgb_b3thw"]
     ws = net.window_size[0]
     strides = net.time_strides(rgb.shape[2])
     s0, e0 = window_chunks(len(strides), world)[rank]
     tf, tT = net._taps(tasks)
-    img_info = tuple(data.get("img_info", net.window_size))
-    dense = [t for t in tasks if t != "track_2d"]
-    local = {}
-    B = rgb.shape[0]
+    groups = []
     # group > 1: that many windows ride through the encoder / decoders as one batch (better filled GEMM tiles: +20 % at
     # group 4).  The batch size selects kernels (split-K of the small convs, the KV split of attention), so the result then
     # equals the window-by-window one only up to summation order (1e-5 relative in f32 mode); group = 1 is bit-identical.
     for g0 in range(s0, e0, group):
         ws_ids = list(range(g0, min(g0 + group, e0)))
         clip = torch.cat([rgb[:, :, int(strides[w]):int(strides[w]) + ws] for w in ws_ids], dim=0)
-        feats = net.video_encoder(clip, tf, tT)
-        dec = {t: net.task_heads[t]._decode(feats, img_info) for t in dense}
-        last = feats.f32(-1) if "track_2d" in tasks else None
+        groups.append((ws_ids, net.video_encoder(clip, tf, tT)))
+    return groups
+
+
+def local_last_features(groups: list, batch: int) -> dict:
+    """{window id: {"last": float last-layer features [B, P, C]}} of the encoded groups (what the tracker's exchange moves)."""
+    local = {}
+    for ws_ids, feats in groups:
+        last = feats.f32(-1)
         for j, w in enumerate(ws_ids):
-            item = {"dec." + t: dec[t][j * B:(j + 1) * B].contiguous() for t in dense}
-            if last is not None:
-                item["last"] = last[j * B:(j + 1) * B].contiguous()
-            local[w] = item
+            local[w] = {"last": last[j * batch:(j + 1) * batch].contiguous()}
+    return local
+
+
+def decode_encoded_windows(net, data: dict, tasks: List[str], groups: list) -> dict:
+    """Phase 1b (sharded): the DPT decoders of the encoded groups -> {window id: {"dec.<task>": tensor}}."""
+    img_info = tuple(data.get("img_info", net.window_size))
+    dense = [t for t in tasks if t != "track_2d"]
+    B = data["rgb_b3thw"].shape[0]
+    local = {}
+    for ws_ids, feats in groups:
+        dec = {t: net.task_heads[t]._decode(feats, img_info) for t in dense}
+        for j, w in enumerate(ws_ids):
+            local[w] = {"dec." + t: dec[t][j * B:(j + 1) * B].contiguous() for t in dense}
+    return local
+
+
+def decode_local_windows(net, data: dict, tasks: List[str], rank: int, world: int, group: int = 1) -> dict:
+    """Phase 1 in one piece (encoder + DPT decoders of this rank's windows) -> {window id: {key: tensor}} with the decoded
+    dense outputs and, when the tracker is asked for, the last-layer features.  forward_windows_sharded runs the two halves
+    apart (the tracker starts between them); this form serves the phase-by-phase measurements and the emulated-rank tests."""
+    local = {}
+    B = data["rgb_b3thw"].shape[0]
+    # (group by group, so that only one group's hook features are alive at a time)
+    rgb = data["rgb_b3thw"]
+    strides = net.time_strides(rgb.shape[2])
+    s0, e0 = window_chunks(len(strides), world)[rank]
+    ws = net.window_size[0]
+    tf, tT = net._taps(tasks)
+    for g0 in range(s0, e0, group):
+        ws_ids = list(range(g0, min(g0 + group, e0)))
+        clip = torch.cat([rgb[:, :, int(strides[w]):int(strides[w]) + ws] for w in ws_ids], dim=0)
+        grp = [(ws_ids, net.video_encoder(clip, tf, tT))]
+        local.update(decode_encoded_windows(net, data, tasks, grp))
+        if "track_2d" in tasks:
+            for w, item in local_last_features(grp, B).items():
+                local[w].update(item)
     return local
 
 
@@ -197,30 +235,98 @@ def stitch_gathered_windows(net, data: dict, tasks: List[str], gathered: List[di
     d = dict(data)
     local_tasks = list(tasks)
     if "track_2d" in tasks:
-        nq = data["track_2d_pointquerries_bn3"].shape[1]
-        q0, q1 = shard_queries(nq, rank, world)
-        d["track_2d_pointquerries_bn3"] = data["track_2d_pointquerries_bn3"][:, q0:q1].contiguous()
-        d["track_2d_pointlabels_bn"] = data["track_2d_pointlabels_bn"][:, q0:q1].contiguous()
-        if q1 == q0:
+        d, nq_local = shard_track_inputs(data, rank, world)
+        if nq_local == 0:
             local_tasks.remove("track_2d")
     return net.stitch_windows(windows, d, local_tasks, strides)
+
+
+def shard_track_inputs(data: dict, rank: int, world: int) -> Tuple[dict, int]:
+    """The caller's batch with the track queries cut down to this rank's shard; second value: the shard's size."""
+    d = dict(data)
+    nq = data["track_2d_pointquerries_bn3"].shape[1]
+    q0, q1 = shard_queries(nq, rank, world)
+    d["track_2d_pointquerries_bn3"] = data["track_2d_pointquerries_bn3"][:, q0:q1].contiguous()
+    d["track_2d_pointlabels_bn"] = data["track_2d_pointlabels_bn"][:, q0:q1].contiguous()
+    return d, q1 - q0
 
 
 def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[int] = None, world: Optional[int] = None,
                             group: int = 1) -> dict:
     """L4P_VideoMAE.forward for a long clip with its windows sharded over the ranks (see the block comment above).
-    ``net``: l4p_amd.models.l4p_videomae.L4P_VideoMAE with weights set on every rank (broadcast_weights)."""
+    ``net``: l4p_amd.models.l4p_videomae.L4P_VideoMAE with weights set on every rank (broadcast_weights).
+
+    Order of the work on a rank (round 4):
+      1a  encoder of its windows                                         (sharded)
+      x1  all-gather of the float last-layer features (11.5 MB per window and clip) - only when the tracker is asked for
+      1b  DPT decoders of its windows, queued on the main stream         (sharded)
+      T   the tracker recursion over ALL windows on this rank's query shard, queued on the tracker's own streams, which wait for
+          x1 only: a chain of ~31 x 130 small dependent launches (host-issue-bound at 8 queries per rank) that runs BESIDE 1b
+      x2  all-gather of the decoded dense windows
+      J   join the tracker streams
+      3   dense stitching / seam alignment / pose chaining               (replicated, identical inputs on every rank)
+      x3  all-gather of the query shards
+    The arithmetic is that of decode_local_windows + stitch_gathered_windows (the emulated-rank tests compare against those);
+    only the order in which independent work is issued differs: the tracker no longer waits for the decoders.
+    Why J comes before 3 (L4P_TRACK_BESIDE_STITCH=1 moves it behind): with the recursion still running on its stream, the seam
+    alignment's small kernels were NOT reproducible - one quarter wave (lanes 48-63) of l4p_point_map_samples' broadcast loads
+    of a pose row read zeros, a few times per hundred launches, which moved RANSAC inlier sets (tests/test_sharded_windows_gpu.py
+    caught it: depth / pose of the 31-window stitch differed run to run).  Not reproduced beside any single tracker kernel family,
+    beside torch kernels or beside hipMemset traffic, and the tracker writes no byte outside its own buffers (canary test over
+    the whole allocator pool): tools/probes/race_c5*.py hold the diagnosis so far.  Until it is explained the alignment runs
+    with the GPU to itself, as it always did; the large decoder kernels beside the tracker are what the c3 step has run since
+    round 2 (bit-identical to the serial order in every comparison made)."""
     if rank is None or world is None:
         on = dist.is_available() and dist.is_initialized()
         rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     data = {k: (v.to(net.device) if torch.is_tensor(v) else v) for k, v in data.items()}
     T = data["rgb_b3thw"].shape[2]
     assert T % net.window_stride_T == 0 and T >= net.window_size[0]
-    nwin = len(net.time_strides(T))
-    local = decode_local_windows(net, data, tasks, rank, world, group)
-    gathered = all_gather_windows(local, nwin, rank, world)  # the one exchange step of the dense path
-    out = stitch_gathered_windows(net, data, tasks, gathered, rank, world)
-    if "track_2d" in tasks and _collectives_on(world):
+    strides = net.time_strides(T)
+    nwin = len(strides)
+    B = data["rgb_b3thw"].shape[0]
+    track = "track_2d" in tasks
+    dense = [t for t in tasks if t != "track_2d"]
+    groups = encode_local_windows(net, data, tasks, rank, world, group)
+    trk, trk_out = None, None
+    try:
+        lasts, ready = None, None
+        if track:
+            lasts = all_gather_windows(local_last_features(groups, B), nwin, rank, world)
+            if net.device.type == "cuda":
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream())
+        # The decoders are QUEUED first and the tracker second: issuing the recursion takes the host ~1.7 ms per window (130
+        # launches) whatever the query count - at 8 queries per rank that is all it costs - so the GPU works through the decoders
+        # while the host is still feeding the tracker's stream.  The tracker's streams wait for `ready` (the gathered features),
+        # not for the decoders queued behind it.
+        local = decode_encoded_windows(net, data, tasks, groups) if dense else None
+        del groups
+        if track:
+            d_trk, nq_local = shard_track_inputs(data, rank, world)
+            if nq_local > 0:
+                trk = net.task_heads["track_2d"]
+                if hasattr(trk, "join_streams"):
+                    trk.defer_join = trk.own_stream = os.environ.get("L4P_TRACK_DEFER", "1") != "0"
+                    trk.start_event = ready if trk.own_stream else None
+                wins_t = [DecodedWindow(net.cfg.depth, {}, g["last"]) for g in lasts]
+                trk_out = trk.forward_windowed(enc_features_bpc_2dlist=wins_t, time_strides=strides, **d_trk)
+        out: dict = {}
+        if dense:
+            gathered = all_gather_windows(local, nwin, rank, world)  # the exchange step of the dense path
+            windows = [DecodedWindow(net.cfg.depth, {k[4:]: v for k, v in g.items() if k.startswith("dec.")}, None)
+                       for g in gathered]
+            if trk is not None and hasattr(trk, "join_streams") and os.environ.get("L4P_TRACK_BESIDE_STITCH", "0") != "1":
+                trk.join_streams()
+            out = net.stitch_windows(windows, data, dense, strides)
+    finally:
+        if trk is not None and hasattr(trk, "join_streams"):
+            trk.join_streams()
+            trk.defer_join = trk.own_stream = False
+            trk.start_event = None
+    if trk_out is not None:
+        out.update(trk_out)
+    if track and _collectives_on(world):
         nq = data["track_2d_pointquerries_bn3"].shape[1]
         name = net.task_heads["track_2d"].task_name
         for key, shp in ((f"{name}_traj_est_bn2t", 2), (f"{name}_vis_est_bn1t", 1), (f"{name}_depth_est_bn1t", 1)):

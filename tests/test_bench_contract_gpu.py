@@ -52,12 +52,17 @@ def test_prep_workload_line(dev):
 
 def test_c5_workload_line_at_full_length(dev):
     """configs[4] on one GPU at its own length: 256 frames = 31 windows, all heads, on-GPU alignment.  Property checks at full
-    size: the line carries the replicated phase-3 time (stitch + alignment + tracker recursion: the Amdahl term of the only
-    strong-scaling configuration) and the ceiling it implies for 8 GPUs."""
+    size: the line carries the pieces of the step (encoders, decoders, replicated dense stitch, tracker recursion in full and on
+    an eighth of the queries) and what they imply for 8 GPUs with the tracker after / beside the decoders."""
     r = _run(["--workload", "c5", "--steps", "1", "--warmup", "1"])
     _check_common(r, 1, 1)
     assert r["scaling"] == "strong" and "31 overlapping" in r["config"]["workload"]
     assert abs(r["value"] - 256 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-2
     assert 0 < r["phase3_ms"] < r["ms_per_step"] and 0 < r["phase1_ms"] < r["ms_per_step"]
-    s = r["phase3_ms"] / (r["phase1_ms"] + r["phase3_ms"])
-    assert abs(r["implied_8gpu_speedup_ceiling"] - 1.0 / (s + (1.0 - s) / 8.0)) < 0.05
+    assert abs(r["phase1_ms"] - (r["phase1a_encoder_ms"] + r["phase1b_decoders_ms"])) < 0.01
+    # the tracker runs beside the decoders in the timed step: the step is shorter than the pieces one after the other
+    assert r["ms_per_step"] < r["serial_sum_ms"] * 1.02
+    t8 = r["phase1a_encoder_ms"] / 8 + max(r["phase3_track_ms_on_an_eighth_of_the_queries"], r["phase1b_decoders_ms"] / 8) + r["phase3_dense_ms"]
+    assert abs(r["implied_8gpu_ms_tracker_beside_decoders"] - t8) < 0.01
+    assert abs(r["implied_8gpu_speedup_tracker_beside_decoders"] - r["ms_per_step"] / t8) < 0.01
+    assert r["implied_8gpu_speedup_tracker_beside_decoders"] >= r["implied_8gpu_speedup_tracker_after_decoders"]
