@@ -424,7 +424,10 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             main = torch.cuda.current_stream()
             pool = getattr(self, "_clip_streams", None)
             if pool is None or len(pool) < B:
-                pool = [torch.cuda.Stream(device=dev) for _ in range(B)]
+                # (L4P_TRACK_PRIO=1: high-priority clip streams.  Measured, round 4, same call: c3 832 -> 654 frames/s - at 64 queries
+                #  the tracker's kernels are chip-sized themselves and pre-empt the decoders' rounds -, configs[4] 414 -> 415: off)
+                prio = -1 if os.environ.get("L4P_TRACK_PRIO", "0") == "1" else 0
+                pool = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(B)]
                 self._clip_streams = pool
             start = getattr(self, "start_event", None) if early else None  # what the clip streams wait for: an event of the
             if start is not None:                       # launching stream (parallel.forward_windows_sharded), else everything
