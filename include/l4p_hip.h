@@ -41,7 +41,7 @@ typedef void* l4p_stream; /* hipStream_t */
 typedef struct l4p_engine l4p_engine;
 
 const char* l4p_last_error(void);
-int l4p_abi_version(void);
+int l4p_abi_version(void); /* 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs, l4p_split_hilo, l4p_transpose_pad */
 
 /* Optional per-kernel-class timing: when enabled every kernel launch is bracketed by a HIP event pair
  * recorded on the launch stream (bench.py's live roofline numbers).  Classes: gemm, conv3d, attention,
@@ -134,6 +134,14 @@ typedef struct l4p_gemm_desc {
      * partials [splitk][M][N] to the caller and runs no finish pass (bias / residual / outputs of the descriptor are ignored):
      * the encoder sums them in the LayerNorm that follows the batch-1 MLP-out projection. */
     int tuning;
+    /* Row-grouped weights (0 = off; dense GEMM without split-K, w_gr a multiple of 128): rows [g * w_gr, (g + 1) * w_gr) of A
+     * multiply their OWN weight matrix W + g * w_gs (elements, same ldw) and add their own bias row bias + g * b_gs (b_gs = 0: one
+     * bias for all groups).  The tracker's image -> token attention with the projections folded into the token side
+     * (sparse_heads.py / sam/transformer.py:180-185, see l4p_amd/models/task_heads/sparse_heads.py): every track's 2048 key rows
+     * meet that track's 48 x 1408 folded key matrix, then its 1408 x 48 folded value matrix. */
+    int w_gr;
+    long long w_gs;
+    int b_gs;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
@@ -325,6 +333,21 @@ int l4p_mask_product(l4p_stream stream, int dtype, const void* up, const float* 
  * the (1,2,2) ConvTranspose over M = N*T*h*w rows: row m = ((n*T + t)*h + y/2)*w + x/2, tap = (y%2)*2 + x%2, chunks_per_tap
  * chunks each. */
 int l4p_mask_gather(l4p_stream stream, const float* partial, float* masks, int N, int T, int h, int w, int chunks_per_tap);
+
+/* Folded image -> token attention of the tracker (sam/transformer.py:180-185,223-245; the projections of the 2048 x N image
+ * tokens are folded into the 6 prompt tokens of each track, l4p_amd/models/task_heads/sparse_heads.py "folded i2t"):
+ * l4p_i2t_probs: scores float [M][ld_scores], column t * heads + h = scaled score of image token m against prompt token t in head h
+ *   (pairs != 0: columns tokens * heads + t * heads + h hold a second addend - the scores against the low halves of the folded key
+ *   matrix; cbias != NULL: + cbias[(m / rows_per_group) * tokens * heads + t * heads + h], the track's query-bias term)
+ *   -> probs T [M][ld_probs]: softmax over t for every h, same column order, columns tokens * heads .. ld_probs - 1 zero.
+ * l4p_split_hilo: in float [G][R][C] -> out T [G][2 R][C], rows [0, R) = T(x), rows [R, 2 R) = T(x - T(x)): a folded key matrix as a
+ *   PAIR of engine-dtype matrices (an option for its 1408-term products with the keys; off by default: no measurable effect).
+ * l4p_transpose_pad: in T [G][R][C] -> out T [G][C][Rp] (k index padded with zeros): a track's folded value matrix in the
+ *   k-contiguous form l4p_gemm reads weights in. */
+int l4p_i2t_probs(l4p_stream stream, int dtype, const float* scores, long long ld_scores, int pairs, const float* cbias, int rows_per_group,
+                  void* probs_T, int ld_probs, long long M, int heads, int tokens);
+int l4p_split_hilo(l4p_stream stream, int dtype, const float* in, void* out_T, int G, int R, long long C);
+int l4p_transpose_pad(l4p_stream stream, int dtype, const void* in_T, void* out_T, int G, int R, int C, int Rp);
 
 /* Fused read-out (sparse_heads.py:572-589,645-647): trilinear (align_corners=False) resize of masks
  * [N][3][T][h][w] to H x W, soft-argmax of channel 0 (traj [N][2][T]), spatial mean of channel 1

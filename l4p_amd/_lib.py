@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int), ("partial", C.c_void_p),
         ("hyper", C.c_void_p), ("hyper_rows", C.c_int),
         ("q_scale", C.c_float), ("tuning", C.c_int),
+        ("w_gr", C.c_int), ("w_gs", C.c_longlong), ("b_gs", C.c_int),
     ]
 
 
@@ -120,6 +121,9 @@ SIGNATURES = {
     "l4p_small_attn": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I]),
     "l4p_mask_product": (_I, [_VP, _I, _VP, _VP, _VP, _I, _LL, _I]),
     "l4p_mask_gather": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
+    "l4p_i2t_probs": (_I, [_VP, _I, _VP, _LL, _I, _VP, _I, _VP, _I, _LL, _I, _I]),
+    "l4p_split_hilo": (_I, [_VP, _I, _VP, _VP, _I, _I, _LL]),
+    "l4p_transpose_pad": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I]),
     "l4p_layernorm_t": (_I, [_VP, _I, _VP, _VP, _VP, C.c_float, _VP, _I, _I, _I]),
     "l4p_pil_coeffs": (_I, [_I, _I, _VP, _VP, _I, C.POINTER(_I)]),
     "l4p_pil_resample_u8": (_I, [_VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _VP, _VP, _I]),

@@ -22,6 +22,10 @@ int launch_broadcast_block(void* base, long long off, long long bytes, long long
 int launch_small_attn(int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P, int D,
                       int heads, hipStream_t stream);
 int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, int w, int cpt, hipStream_t stream);
+int launch_i2t_probs(int dtype, const float* s, long long lds_, int pairs, const float* cbias, int rows_per_group, void* p, int ldp,
+                     long long M, int heads, int tokens, hipStream_t stream);
+int launch_split_hilo(int dtype, const float* in, void* out, int G, int R, long long C, hipStream_t stream);
+int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int C, int Rp, hipStream_t stream);
 int launch_mask_product(int dtype, const void* up, const float* hyper, float* masks, int N, long long vox, int Cc,
                         hipStream_t stream);
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
@@ -74,6 +78,16 @@ int l4p_small_attn(l4p_stream s, int dtype, int kind, const void* q, const void*
 int l4p_mask_product(l4p_stream s, int dtype, const void* up, const float* hyper, float* masks, int N, long long vox,
                      int C) {
     return launch_mask_product(dtype, up, hyper, masks, N, vox, C, (hipStream_t)s);
+}
+int l4p_i2t_probs(l4p_stream s, int dtype, const float* scores, long long ld_scores, int pairs, const float* cbias, int rows_per_group,
+                  void* probs_T, int ld_probs, long long M, int heads, int tokens) {
+    return launch_i2t_probs(dtype, scores, ld_scores, pairs, cbias, rows_per_group, probs_T, ld_probs, M, heads, tokens, (hipStream_t)s);
+}
+int l4p_split_hilo(l4p_stream s, int dtype, const float* in, void* out_T, int G, int R, long long C) {
+    return launch_split_hilo(dtype, in, out_T, G, R, C, (hipStream_t)s);
+}
+int l4p_transpose_pad(l4p_stream s, int dtype, const void* in_T, void* out_T, int G, int R, int C, int Rp) {
+    return launch_transpose_pad(dtype, in_T, out_T, G, R, C, Rp, (hipStream_t)s);
 }
 int l4p_mask_gather(l4p_stream s, const float* partial, float* masks, int N, int T, int h, int w, int chunks_per_tap) {
     return launch_mask_gather(partial, masks, N, T, h, w, chunks_per_tap, (hipStream_t)s);

@@ -7,6 +7,7 @@
 // graph, selectable with L4P_TRACK_PYTHON=1, and is asserted bit-identical in tests/test_track_gpu.py).  What it buys: the
 // host issues one call per clip and window instead of ~125 ctypes calls with their tensor allocations — with 8 ranks
 // sharing one host's cores that is what keeps the step from becoming launch-bound.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -34,6 +35,10 @@ int launch_broadcast_block(void* base, long long off, long long bytes, long long
 int launch_small_attn(int dtype, int kind, const void* q, const void* k, const void* v, void* out, int N, int P, int D,
                       int heads, hipStream_t stream);
 int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, int w, int cpt, hipStream_t stream);
+int launch_i2t_probs(int dtype, const float* s, long long lds_, int pairs, const float* cbias, int rows_per_group, void* p, int ldp,
+                     long long M, int heads, int tokens, hipStream_t stream);
+int launch_split_hilo(int dtype, const float* in, void* out, int G, int R, long long C, hipStream_t stream);
+int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int C, int Rp, hipStream_t stream);
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
                          int W, hipStream_t stream);
 
@@ -256,20 +261,86 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         // --- image -> tokens (transformer.py:180-185): keys are updated in place ---
         mark = c.ws.off;
         {
-            void* iq = half_shared && l == 0 ? proj_half_shared(curP, lo + "i2t.q", Dh)
-                                             : c.proj(curP, (long long)Nk * P, Cc, lo + "i2t.q", Dh);
             void *ik = c.T(6ll * N, Dh), *iv = c.T(6ll * N, Dh);
             const GemmParams kv[2] = {c.desc(qP, 6ll * N, Cc, Cc, lo + "i2t.k", Dh, true, ACT_NONE, nullptr, 0, nullptr, ik, Dh),
                                       c.desc(qT, 6ll * N, Cc, Cc, lo + "i2t.v", Dh, true, ACT_NONE, nullptr, 0, nullptr, iv, Dh)};
             c.group(kv, 2);
-            void* ia = c.T(NP, Dh);
-            c.attn(shared ? 4 : 2, iq, ik, iv, ia, N, P, Dh, g.sam_heads);
-            // keys = norm4(keys + out_proj(attention)): the projection leaves its result in the engine dtype and the LayerNorm
-            // forms the sum (l4p_layernorm_res): the float key stream is read once per layer instead of read + written by the
-            // projection's epilogue and read again (1.48 GB per launch at 64 tracks; that GEMM was two serial phases, MFMA then
-            // HBM).  While the keys are still common to all tracks the float residual is row m % P of the common set.
+            // keys = norm4(keys + out_proj(attention)): the update leaves the projection in the engine dtype (`delta`) and the
+            // LayerNorm forms the sum (l4p_layernorm_res): the float key stream is read once per layer instead of read + written
+            // by the projection's epilogue and read again.  While the keys are still common to all tracks the float residual is
+            // row m % P of the common set.
             void* delta = c.T(NP, Cc);
-            c.gemm(ia, NP, Dh, Dh, lo + "i2t.out", Cc, true, ACT_NONE, nullptr, 0, nullptr, delta, Cc);
+            const int HT = 6 * g.sam_heads;               // (token, head) pairs of a track: the folded k dimension
+            const int HTp = (HT + 63) / 64 * 64;
+            // Folded form (packing.py fold_i2t; every track owns its keys, all rows of kP exist): the 2048 x N image tokens never
+            // pass through i2t.q / i2t.out.  Token side: K' = k_tok x qfold^T [N][HT][C], c = k_tok x cfold^T [N][HT],
+            // V' = v_tok x ofold^T [N][HT][C] (three small GEMMs), V'^T [N][C][HTp].  Image side: scores = kP x K'^T + c (row-grouped
+            // weights: a track's rows meet that track's K'), softmax over the tokens of each head, delta = P x V' + b_out.
+            // Per 64 tracks: 0.37 GB read + 0.37 GB written and 35 GFLOP, where the projections moved 1.3 GB and 520 GFLOP.
+            static const bool fold_env = !(getenv("L4P_TRACK_FOLD_I2T") && atoi(getenv("L4P_TRACK_FOLD_I2T")) == 0);
+            // (keys still common to all tracks: the same GEMM on row m % P of the common set; later windows, layer 0: the second
+            //  temporal half of every track is track 0's - two launches over the half blocks, row-mapped like proj_half_shared)
+            const bool hs0 = half_shared && l == 0;
+            const bool fold = fold_env && P % 256 == 0 && HT <= 64;
+            if (fold) {
+                const long long KW = (long long)g.sam_heads * Cc;  // columns of K' / V' per token row
+                // optional (bf16 engine): K' as a PAIR of bf16 matrices (rows [0, HT) = hi, [HT, 2 HT) = lo per track; l4p_split_hilo)
+                // for its 1408-term products with the keys; the two score halves and c are summed in l4p_i2t_probs.
+                // MEASURED (tools/probes/fold_precision.py, per-track distance of the bf16 engine from the f32 engine over 4 - 6 windows):
+                // with K' rounded ONCE to bf16 the folded form is already as close to f32 as the projected form (traj 3e-4, depth
+                // 6e-3 per track, both forms) - the pair changes nothing and is off (L4P_TRACK_FOLD_PAIR=1 turns it on).
+                static const bool pair_env = getenv("L4P_TRACK_FOLD_PAIR") && atoi(getenv("L4P_TRACK_FOLD_PAIR")) == 1;
+                const bool pair = pair_env && c.dt == L4P_BF16;
+                const int NS = pair ? 2 * HT : HT;               // score columns
+                float* kf32 = pair ? c.f32(6ll * N, (int)KW) : nullptr;
+                void* kf = c.T((long long)N * NS + 128, Cc);     // K' [N][NS][C] (+ slack rows under the last tile)
+                void* vf = c.T(6ll * N * g.sam_heads, Cc);
+                float* cf = c.f32(6ll * N, g.sam_heads);
+                void* vt = c.T((long long)N * Cc + 128, HTp);    // V'^T [N][C][HTp] (+ slack rows)
+                const GemmParams tk[3] = {
+                    c.desc(ik, 6ll * N, Dh, Dh, lo + "i2t.qfold", (int)KW, false, ACT_NONE, nullptr, 0, pair ? kf32 : nullptr, pair ? nullptr : kf, KW),
+                    c.desc(iv, 6ll * N, Dh, Dh, lo + "i2t.ofold", (int)KW, false, ACT_NONE, nullptr, 0, nullptr, vf, KW),
+                    c.desc(ik, 6ll * N, Dh, Dh, lo + "i2t.cfold", g.sam_heads, false, ACT_NONE, nullptr, 0, cf, nullptr, g.sam_heads)};
+                c.group(tk, 3);
+                if (pair && !c.rc && !c.dry) c.rc = launch_split_hilo(c.dt, kf32, kf, N, HT, Cc, c.st);
+                if (!c.rc && !c.dry) c.rc = launch_transpose_pad(c.dt, vf, vt, N, HT, Cc, HTp, c.st);
+                float* sc = c.f32(NP, NS);
+                void* pr = c.T(NP, HTp);
+                if (!c.rc && !c.dry) {
+                    GemmParams p;
+                    memset(&p, 0, sizeof(p));
+                    p.A = curP, p.lda = Cc, p.W = kf, p.ldw = Cc, p.M = (int)NP, p.N = NS, p.K = Cc;
+                    p.out_f32 = sc, p.ldc = NS, p.epi = EPI_DENSE;
+                    p.w_gr = P, p.w_gs = (long long)NS * Cc, p.b_gs = 0;
+                    if (shared) {
+                        p.a_gr = P, p.a_gs = 0, p.a_go = 0;  // every track reads the common key rows
+                        c.rc = launch_gemm(c.dt, 0, p, c.st);
+                    } else if (hs0) {
+                        const int half = P / 2;
+                        p.M = N * half, p.w_gr = half;
+                        p.a_gr = half, p.a_gs = P, p.a_go = 0, p.c_gr = half, p.c_gs = P, p.c_go = 0;  // first halves: every track's own
+                        c.rc = launch_gemm(c.dt, 0, p, c.st);
+                        p.a_gs = 0, p.a_go = half, p.c_go = half;                                      // second halves: track 0's rows
+                        if (!c.rc) c.rc = launch_gemm(c.dt, 0, p, c.st);
+                    } else {
+                        c.rc = launch_gemm(c.dt, 0, p, c.st);
+                    }
+                    if (!c.rc) c.rc = launch_i2t_probs(c.dt, sc, NS, pair ? 1 : 0, cf, P, pr, HTp, NP, g.sam_heads, 6, c.st);
+                    if (!c.rc) {
+                        memset(&p, 0, sizeof(p));
+                        p.A = pr, p.lda = HTp, p.W = vt, p.ldw = HTp, p.M = (int)NP, p.N = Cc, p.K = HTp;
+                        p.bias = c.Wf(lo + "i2t.out.b"), p.out_T = delta, p.ldc = Cc, p.epi = EPI_DENSE;
+                        p.w_gr = P, p.w_gs = (long long)Cc * HTp, p.b_gs = 0;
+                        c.rc = launch_gemm(c.dt, 0, p, c.st);
+                    }
+                }
+            } else {
+                void* iq = half_shared && l == 0 ? proj_half_shared(curP, lo + "i2t.q", Dh)
+                                                 : c.proj(curP, (long long)Nk * P, Cc, lo + "i2t.q", Dh);
+                void* ia = c.T(NP, Dh);
+                c.attn(shared ? 4 : 2, iq, ik, iv, ia, N, P, Dh, g.sam_heads);
+                c.gemm(ia, NP, Dh, Dh, lo + "i2t.out", Cc, true, ACT_NONE, nullptr, 0, nullptr, delta, Cc);
+            }
             // (after the last layer nothing adds to the float keys any more: only the T copies are written)
             float* o32 = l + 1 < g.sam_depth ? k32 : nullptr;
             if (!c.rc && !c.dry)

@@ -715,9 +715,23 @@ __device__ __forceinline__ bool gemm_epilogue_dense_dispatch(const GemmParams& p
 // reading tile kt-1) -> issue tile kt+2 into the buffer tile kt-1 used -> MFMAs on tile kt.
 // (the kernel body is a device function of (descriptor, workgroup index): gemm_kernel runs it for one problem,
 //  gemm_group_kernel for up to four problems in ONE launch, see below)
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS, int STAGES = 2>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, const int wg_index) {
+// GROUPW: row-grouped weights (l4p_gemm_desc.w_gr): the tile's row group selects the weight matrix and the bias row.  Its own
+// instantiation - the descriptor is copied and patched per workgroup, which the plain kernels must not pay for.
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS, int STAGES = 2, bool GROUPW = false>
+__device__ __forceinline__ void gemm_body(const GemmParams& p_in, const int wg_index) {
     static_assert(STAGES == 2 || (STAGES >= 3 && STAGES <= 5 && GLDS), "deeper pipelines need LDS-DMA staging");
+    static_assert(!GROUPW || MODE == 0, "row-grouped weights: dense GEMM");
+    GemmParams patched;
+    const GemmParams* pp = &p_in;
+    if constexpr (GROUPW) {
+        const int ntn_ = (p_in.N + BN - 1) / BN;
+        const int grp = ((wg_index / ntn_) * BM) / p_in.w_gr;  // (no split-K, no XCD remap in MODE 0: tile = wg_index, m-major)
+        patched = p_in;
+        patched.W = (const T*)p_in.W + (long long)grp * p_in.w_gs;
+        if (p_in.bias) patched.bias = p_in.bias + (long long)grp * p_in.b_gs;
+        pp = &patched;
+    }
+    const GemmParams& p = *pp;
     constexpr int NT = WM * WN * 64;
     constexpr int ES = sizeof(T);
     constexpr int BK = 128 / ES;   // 64 bf16 / 32 f32 per LDS row
@@ -1074,9 +1088,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int wg_inde
     gemm_epilogue<T, TM, TN>(p, acc, m0 + wm * (TM * 16), n0 + wn * (TN * 16), li, kg);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS, int STAGES = 2>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool GLDS, int STAGES = 2, bool GROUPW = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
-    gemm_body<T, BM, BN, WM, WN, MODE, GLDS, STAGES>(p, (int)blockIdx.x);
+    gemm_body<T, BM, BN, WM, WN, MODE, GLDS, STAGES, GROUPW>(p, (int)blockIdx.x);
 }
 
 // Up to L4P_GEMM_GROUP_MAX independent dense GEMMs as ONE launch: workgroups [first[g], first[g + 1]) run problem g.  For the

@@ -708,9 +708,122 @@ __global__ void masked_rows_copy_kernel(float* __restrict__ dst, const float* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// Image -> token attention with the projections folded into the token side (sam/transformer.py:180-185, 223-245; see
+// sparse_heads.py / api_trackwin.hip "folded i2t"): the scores of an image token against the 6 prompt tokens of its track arrive
+// as a float row [tokens][heads] (column t * heads + h; scale and the query-bias term already inside), the softmax over the
+// tokens of every head leaves as a row of the engine dtype padded to `ldp` columns - the A operand of P x V'.
+// One thread per (row, head); same exponential and normalisation order as i2t_attn_kernel (expf, one reciprocal).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void i2t_probs_kernel(const float* __restrict__ s, long long lds_, int pairs, const float* __restrict__ cb, int rows_per_group,
+                                 T* __restrict__ p, int ldp, long long M, int heads, int tokens) {
+    const long long total = M * heads;
+    const int HT = heads * tokens;
+    for (long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+        const long long row = w / heads;
+        const int h = (int)(w - row * heads);
+        const float* sr = s + row * lds_ + h;
+        const float* cr = cb ? cb + (row / rows_per_group) * HT + h : nullptr;  // the track's query-bias term per (token, head)
+        float e[8];
+        float m = -INFINITY;
+        for (int t = 0; t < tokens; ++t) {
+            float v = sr[t * heads];
+            if (pairs) v += sr[HT + t * heads];  // scores against the low halves of the folded key matrix (bf16 engine)
+            if (cr) v += cr[t * heads];
+            e[t] = v;
+            m = fmaxf(m, v);
+        }
+        float z = 0.f;
+        for (int t = 0; t < tokens; ++t) {
+            e[t] = expf(e[t] - m);
+            z += e[t];
+        }
+        const float iz = 1.f / z;
+        T* pr = p + row * ldp + h;
+        for (int t = 0; t < tokens; ++t) pr[t * heads] = from_f32<T>(e[t] * iz);
+        if (h == 0)
+            for (int c = HT; c < ldp; ++c) pr[c] = from_f32<T>(0.f);  // padding columns of the k dimension
+    }
+}
+// in float [G][R][C] -> out T [G][2 R][C]: rows [0, R) = T(x), rows [R, 2 R) = T(x - float(T(x))).  The folded key matrix of a track
+// as a pair of bf16 matrices, for its 1408-term dot products with the keys (an option of the folded image -> token attention:
+// measured to make no difference to the tracker's distance from the f32 engine, so it is off by default).
+template <typename T>
+__global__ void split_hilo_kernel(const float* __restrict__ in, T* __restrict__ out, int G, int R, long long C) {
+    const long long total = (long long)G * R * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long c = i % C, gr = i / C;
+        const long long g = gr / R, r = gr % R;
+        const float x = in[i];
+        const T hi = from_f32<T>(x);
+        out[((g * 2 * R) + r) * C + c] = hi;
+        out[((g * 2 * R) + R + r) * C + c] = from_f32<T>(x - to_f32<T>(hi));
+    }
+}
+// in [G][R][C] -> out [G][C][Rp] (rows R .. Rp-1 of the k dimension zero): the folded value matrix of a track, transposed into
+// the k-contiguous form the GEMM reads weights in.  Small (G * R * C elements = 4.3 M for 64 tracks): one thread per output element.
+template <typename T>
+__global__ void transpose_pad_kernel(const T* __restrict__ in, T* __restrict__ out, int G, int R, int C, int Rp) {
+    const long long total = (long long)G * C * Rp;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i % Rp);
+        const long long gc = i / Rp;
+        const int c = (int)(gc % C);
+        const long long g = gc / C;
+        out[i] = r < R ? in[(g * R + r) * C + c] : from_f32<T>(0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 #define GRID1D(total, cap) ((int)(((total) + 255) / 256 < (cap) ? ((total) + 255) / 256 : (cap)))
+
+int launch_i2t_probs(int dtype, const float* s, long long lds_, int pairs, const float* cbias, int rows_per_group, void* p, int ldp,
+                     long long M, int heads, int tokens, hipStream_t stream) {
+    if (tokens < 1 || tokens > 8 || heads < 1 || ldp < tokens * heads || lds_ < (pairs ? 2 : 1) * tokens * heads || (cbias && rows_per_group < 1)) {
+        l4p_set_error("i2t_probs: 1 <= tokens <= 8, ldp >= tokens * heads, score row stride >= (pairs ? 2 : 1) * tokens * heads");
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_TRACK, stream, "i2t_probs");
+    const int grid = GRID1D(M * heads, 16384);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(i2t_probs_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, s, lds_, pairs, cbias, rows_per_group, (bf16_t*)p, ldp, M,
+                           heads, tokens);
+    else
+        hipLaunchKernelGGL(i2t_probs_kernel<float>, dim3(grid), dim3(256), 0, stream, s, lds_, pairs, cbias, rows_per_group, (float*)p, ldp, M, heads,
+                           tokens);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_split_hilo(int dtype, const float* in, void* out, int G, int R, long long C, hipStream_t stream) {
+    if (G < 1 || R < 1 || C < 1) {
+        l4p_set_error("split_hilo: bad shape");
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_TRACK, stream, "split_hilo");
+    const int grid = GRID1D((long long)G * R * C, 16384);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(split_hilo_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, in, (bf16_t*)out, G, R, C);
+    else
+        hipLaunchKernelGGL(split_hilo_kernel<float>, dim3(grid), dim3(256), 0, stream, in, (float*)out, G, R, C);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int C, int Rp, hipStream_t stream) {
+    if (G < 1 || R < 1 || C < 1 || Rp < R) {
+        l4p_set_error("transpose_pad: bad shape");
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_TRACK, stream, "transpose_pad");
+    const int grid = GRID1D((long long)G * C * Rp, 16384);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(transpose_pad_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, (bf16_t*)out, G, R, C, Rp);
+    else
+        hipLaunchKernelGGL(transpose_pad_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)in, (float*)out, G, R, C, Rp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,

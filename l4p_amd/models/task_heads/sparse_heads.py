@@ -17,13 +17,14 @@ from typing import Dict, List, Literal, Optional, Tuple
 import torch
 
 from ... import _lib, ops
-from ..._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, EPI_MASKDOT, GemmDesc
+from ..._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, EPI_MASKDOT, L4P_BF16, GemmDesc
 from ...ops import _p, _stream
 
 
 def _gemm(a: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, n: int, *, bias=None, act=ACT_NONE, res1=None,
           out_f32: Optional[torch.Tensor] = None, out_T: Optional[torch.Tensor] = None, ldc: Optional[int] = None,
-          a_map=None, c_map=None, a_off: int = 0, f32_off: int = 0, res_mod: int = 0) -> None:
+          a_map=None, c_map=None, a_off: int = 0, f32_off: int = 0, res_mod: int = 0, wgroup=None,
+          ldw: Optional[int] = None) -> None:
     """Raw l4p_gemm call with explicit strides / row maps (see include/l4p_hip.h)."""
     d = GemmDesc()
     es = a.element_size()
@@ -40,6 +41,9 @@ def _gemm(a: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, n: int, *,
         d.a_gr, d.a_gs, d.a_go = a_map
     if c_map is not None:
         d.c_gr, d.c_gs, d.c_go = c_map
+    if wgroup is not None:  # row-grouped weights: (rows per group, W elements between groups, bias elements between groups)
+        d.w_gr, d.w_gs, d.b_gs = wgroup
+        d.ldw = K if ldw is None else ldw
     _lib.check(_lib.load().l4p_gemm(_stream(), ops.code_of(a.dtype), C.byref(d)), "l4p_gemm")
 
 
@@ -209,19 +213,63 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                   out_f32=x32)
             q32, qT, qP = self._ln(x32, lo + "norm3", tok32, 6 * N, out32=torch.empty_like(x32))
             # --- image -> tokens (transformer.py:180-185): keys are updated in place ---
-            iq = proj_half_shared(kP, lo + "i2t.q", Dh) if hs else self._proj(kP, lo + "i2t.q", Dh)
             ik = self._proj(qP, lo + "i2t.k", Dh)
             iv = self._proj(qT, lo + "i2t.v", Dh)
-            ia = torch.empty((N * P, Dh), dtype=td, device=dev)
-            _lib.check(lib.l4p_small_attn(_stream(), dt, 4 if shared else 2, _p(iq), _p(ik), _p(iv), _p(ia), N, P, Dh,
-                                          cfg.sam_heads), "l4p_small_attn")
-            del iq
-            # keys = norm4(keys + out_proj(attention)): the projection leaves its result in the engine dtype, the LayerNorm forms
-            # the sum (l4p_layernorm_res; csrc/api_trackwin.hip has the same sequence).  While the keys are still common to all
-            # tracks the float residual is row m % P of the common set; from here on every track owns its keys.
+            # keys = norm4(keys + out_proj(attention)): the update leaves the projection in the engine dtype (delta), the LayerNorm
+            # forms the sum (l4p_layernorm_res; csrc/api_trackwin.hip has the same sequence).  While the keys are still common to
+            # all tracks the float residual is row m % P of the common set; from here on every track owns its keys.
             delta = torch.empty((N * P, Cc), dtype=td, device=dev)
-            _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), out_T=delta)
-            del ia
+            heads = cfg.sam_heads
+            HT = 6 * heads
+            HTp = (HT + 63) // 64 * 64
+            fold = os.environ.get("L4P_TRACK_FOLD_I2T", "1") != "0" and P % 256 == 0 and HT <= 64
+            if fold:
+                # folded form (packing.py fold_i2t; csrc/api_trackwin.hip): the projections of the image tokens are folded into
+                # the 6 prompt tokens of each track - scores = kP x K'^T + c, softmax over the tokens of each head, delta = P x V' + b
+                KW = heads * Cc
+                # optional (bf16 engine): K' as a pair of bf16 matrices (hi, lo; l4p_split_hilo); the two score halves and c are
+                # summed in l4p_i2t_probs
+                pair = dt == L4P_BF16 and os.environ.get("L4P_TRACK_FOLD_PAIR") == "1"  # (measured: no accuracy effect; off)
+                NS = 2 * HT if pair else HT
+                kf = torch.empty((N * NS + 128, Cc), dtype=td, device=dev)  # K' [N][NS][C] (+ slack rows under the last tile)
+                vf = torch.empty((N * HT, Cc), dtype=td, device=dev)        # V' [N][HT][C]
+                cf = torch.empty((6 * N, heads), **f32)                     # c  [N][HT]
+                if pair:
+                    kf32 = torch.empty((6 * N, KW), **f32)
+                    _gemm(ik, 6 * N, Dh, Dh, self._w(lo + "i2t.qfold.w"), KW, out_f32=kf32, ldc=KW)
+                else:
+                    _gemm(ik, 6 * N, Dh, Dh, self._w(lo + "i2t.qfold.w"), KW, out_T=kf, ldc=KW)
+                _gemm(iv, 6 * N, Dh, Dh, self._w(lo + "i2t.ofold.w"), KW, out_T=vf, ldc=KW)
+                _gemm(ik, 6 * N, Dh, Dh, self._w(lo + "i2t.cfold.w"), heads, out_f32=cf, ldc=heads)
+                if pair:
+                    _lib.check(lib.l4p_split_hilo(_stream(), dt, _p(kf32), _p(kf), N, HT, Cc), "l4p_split_hilo")
+                    del kf32
+                vt = torch.empty((N * Cc + 128, HTp), dtype=td, device=dev)  # V'^T [N][C][HTp]
+                _lib.check(lib.l4p_transpose_pad(_stream(), dt, _p(vf), _p(vt), N, HT, Cc, HTp), "l4p_transpose_pad")
+                sc = torch.empty((N * P, NS), **f32)
+                if shared:    # the keys are still common to all tracks: every track reads row m % P of the common set
+                    _gemm(kP, N * P, Cc, Cc, kf, NS, out_f32=sc, ldc=NS, wgroup=(P, NS * Cc, 0), ldw=Cc, a_map=(P, 0, 0))
+                elif hs:      # later windows, layer 0: the second temporal half of every track's keys is track 0's
+                    half = P // 2
+                    _gemm(kP, N * half, Cc, Cc, kf, NS, out_f32=sc, ldc=NS, wgroup=(half, NS * Cc, 0), ldw=Cc,
+                          a_map=(half, P, 0), c_map=(half, P, 0))
+                    _gemm(kP, N * half, Cc, Cc, kf, NS, out_f32=sc, ldc=NS, wgroup=(half, NS * Cc, 0), ldw=Cc,
+                          a_map=(half, 0, half), c_map=(half, P, half))
+                else:
+                    _gemm(kP, N * P, Cc, Cc, kf, NS, out_f32=sc, ldc=NS, wgroup=(P, NS * Cc, 0), ldw=Cc)
+                pr = torch.empty((N * P, HTp), dtype=td, device=dev)
+                _lib.check(lib.l4p_i2t_probs(_stream(), dt, _p(sc), NS, 1 if pair else 0, _p(cf), P, _p(pr), HTp, N * P, heads, 6),
+                           "l4p_i2t_probs")
+                _gemm(pr, N * P, HTp, HTp, vt, Cc, bias=self._w(lo + "i2t.out.b"), out_T=delta, ldc=Cc, wgroup=(P, Cc * HTp, 0), ldw=HTp)
+                del kf, vf, cf, vt, sc, pr
+            else:
+                iq = proj_half_shared(kP, lo + "i2t.q", Dh) if hs else self._proj(kP, lo + "i2t.q", Dh)
+                ia = torch.empty((N * P, Dh), dtype=td, device=dev)
+                _lib.check(lib.l4p_small_attn(_stream(), dt, 4 if shared else 2, _p(iq), _p(ik), _p(iv), _p(ia), N, P, Dh,
+                                              cfg.sam_heads), "l4p_small_attn")
+                del iq
+                _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), out_T=delta)
+                del ia
             k_res = k32
             if shared:
                 k32 = torch.empty((N * P, Cc), **f32)

@@ -173,11 +173,39 @@ def pack_track(pk: Packer, sd: Dict[str, torch.Tensor], c: ModelCfg, task: str =
         pk.F(dst + ".g", sd[src + ".weight"])
         pk.F(dst + ".b", sd[src + ".bias"])
 
+    def fold_i2t(src: str, dst: str):
+        """Image -> token attention with its image-side projections folded into the token side (sam/transformer.py:180-185,
+        223-245; used from sparse_heads._window / csrc/api_trackwin.hip once every track owns its keys):
+          scores[p, t, h] = scale * (kP[p] Wq^T + bq)_h . k_t,h  =  kP[p] . K'[t, h]  +  c[t, h]
+          out[p]          = sum_{t,h} softmax_t(scores)[p, t, h] * (Wout_h v_t,h)  + bout  =  P[p] . V'  + bout
+        K' = k_tok x qfold^T, c = k_tok x cfold^T, V' = v_tok x ofold^T are three small GEMMs on the 6 tokens of a track, with
+        block-diagonal weights (head h of the token operand only meets head h's rows): qfold [(h, ch)][j] = scale * Wq[j, ch] for
+        j in head h, else 0; cfold [h][j] = scale * bq[j] likewise; ofold [(h, ch)][j] = Wout[ch, j] likewise.  The image-side
+        i2t.q (P x C x C/2 MACs per track) and i2t.out projections and their [P, C/2] intermediates disappear."""
+        wq, bq = sd[f"{src}.q_proj.weight"].float(), sd[f"{src}.q_proj.bias"].float()
+        wo = sd[f"{src}.out_proj.weight"].float()
+        inner, C_ = wq.shape
+        heads = c.sam_heads
+        hd = inner // heads
+        scale = hd ** -0.5
+        qf = torch.zeros(heads * C_, inner)
+        cf = torch.zeros(heads, inner)
+        of = torch.zeros(heads * C_, inner)
+        for h in range(heads):
+            js = slice(h * hd, (h + 1) * hd)
+            qf[h * C_:(h + 1) * C_, js] = scale * wq[js].t()
+            cf[h, js] = scale * bq[js]
+            of[h * C_:(h + 1) * C_, js] = wo[:, js]
+        pk.T(f"{dst}.qfold.w", qf)
+        pk.T(f"{dst}.cfold.w", cf)
+        pk.T(f"{dst}.ofold.w", of)
+
     for l in range(c.sam_depth):
         lp, lo = f"{t}layers.{l}.", f"{o}l{l}."
         attn(lp + "self_attn", lo + "self")
         attn(lp + "cross_attn_token_to_image", lo + "t2i")
         attn(lp + "cross_attn_image_to_token", lo + "i2t")
+        fold_i2t(lp + "cross_attn_image_to_token", lo + "i2t")
         for k in (1, 2, 3, 4):
             norm(f"{lp}norm{k}", f"{lo}norm{k}")
         pk.T(lo + "mlp1.w", sd[lp + "mlp.lin1.weight"])

@@ -371,3 +371,122 @@ def test_more_queries_than_max_queries_vs_oracle(dev, mini):
         assert torch.equal(tr["valid_t"].cpu().bool(), ot["valid_t"])
         assert torch.equal(tr["queries"][:, 0].cpu(), ot["queries"][:, 0])
     head.trace = None
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_row_grouped_weights_gemm_and_folded_i2t_kernels(dev, precision):
+    """l4p_gemm with row-grouped weights (l4p_gemm_desc.w_gr: every track's key rows meet that track's own weight matrix and
+    bias row), l4p_i2t_probs and l4p_transpose_pad - the kernels of the tracker's folded image -> token attention - against
+    plain torch on the same rounded operands."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+    from l4p_amd._lib import EPI_DENSE, L4P_BF16, L4P_F32, GemmDesc
+    from l4p_amd.ops import _p, _stream
+
+    lib = _lib.load()
+    dt = L4P_BF16 if precision == "bf16" else L4P_F32
+    td = torch.bfloat16 if precision == "bf16" else torch.float32
+    N, P, Cc, heads = 3, 256, 704, 8
+    HT, HTp = 6 * heads, 64
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    keys = r(N * P, Cc).to(td).cuda()
+    kf = torch.zeros(N * HT + 64, Cc, dtype=td, device="cuda")
+    kf[:N * HT] = (r(N * HT, Cc) * Cc ** -0.5).to(td).cuda()
+    cf = r(N, HT).cuda()
+    sc = torch.empty(N * P, HT, device="cuda")
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = _p(keys), Cc, _p(kf), Cc
+    d.M, d.N, d.K = N * P, HT, Cc
+    d.bias, d.out_f32, d.ldc, d.epi = _p(cf), _p(sc), HT, EPI_DENSE
+    d.w_gr, d.w_gs, d.b_gs = P, HT * Cc, HT
+    _lib.check(lib.l4p_gemm(_stream(), dt, C.byref(d)), "l4p_gemm(grouped W)")
+    ref = torch.einsum("npc,nkc->npk", keys.float().cpu().view(N, P, Cc), kf[:N * HT].float().cpu().view(N, HT, Cc)) + cf.cpu()[:, None]
+    torch.cuda.synchronize()
+    assert float((sc.cpu().view(N, P, HT) - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+    # softmax over the 6 tokens of every head (column t * heads + h)
+    pr = torch.empty(N * P, HTp, dtype=td, device="cuda")
+    lo_half = (0.01 * r(N * P, HT)).cuda()
+    cb = r(N, HT).cuda()
+    sc2 = torch.cat([sc, lo_half], dim=1).contiguous()  # second addend per column (scores against the low halves) + per-track bias
+    _lib.check(lib.l4p_i2t_probs(_stream(), dt, _p(sc2), 2 * HT, 1, _p(cb), P, _p(pr), HTp, N * P, heads, 6), "l4p_i2t_probs")
+    tot = (sc + lo_half).cpu().view(N, P, HT) + cb.cpu()[:, None]
+    pref = torch.softmax(tot.view(N * P, 6, heads), dim=1).reshape(N * P, HT)
+    torch.cuda.synchronize()
+    assert float((pr[:, :HT].float().cpu() - pref).abs().max()) <= (4e-3 if precision == "bf16" else 1e-6)
+    assert float(pr[:, HT:].float().abs().max()) == 0.0
+    # V' -> V'^T, then delta = P x V' + b with the value matrix of each track
+    x32 = r(N * HT, 40).cuda()
+    hl = torch.empty(N * 2 * HT, 40, dtype=td, device="cuda")
+    _lib.check(lib.l4p_split_hilo(_stream(), dt, _p(x32), _p(hl), N, HT, 40), "l4p_split_hilo")
+    torch.cuda.synchronize()
+    hv = hl.float().cpu().view(N, 2, HT, 40)
+    xc = x32.cpu().view(N, HT, 40)
+    assert torch.equal(hv[:, 0], xc.to(td).float()) and float((hv[:, 0] + hv[:, 1] - xc).abs().max()) <= (2e-5 if precision == "bf16" else 0.0) * float(xc.abs().max())
+    vf = (r(N * HT, Cc) * 0.2).to(td).cuda()
+    vt = torch.zeros(N * Cc + 128, HTp, dtype=td, device="cuda")
+    _lib.check(lib.l4p_transpose_pad(_stream(), dt, _p(vf), _p(vt), N, HT, Cc, HTp), "l4p_transpose_pad")
+    torch.cuda.synchronize()
+    want_vt = torch.zeros(N, Cc, HTp)
+    want_vt[:, :, :HT] = vf.float().cpu().view(N, HT, Cc).transpose(1, 2)
+    assert torch.equal(vt[:N * Cc].float().cpu().view(N, Cc, HTp), want_vt)
+    bias = r(Cc).cuda()
+    delta = torch.empty(N * P, Cc, dtype=td, device="cuda")
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = _p(pr), HTp, _p(vt), HTp
+    d.M, d.N, d.K = N * P, Cc, HTp
+    d.bias, d.out_T, d.ldc, d.epi = _p(bias), _p(delta), Cc, EPI_DENSE
+    d.w_gr, d.w_gs, d.b_gs = P, Cc * HTp, 0
+    _lib.check(lib.l4p_gemm(_stream(), dt, C.byref(d)), "l4p_gemm(grouped W, K = 64)")
+    dref = torch.einsum("npk,nkc->npc", pr[:, :HT].float().cpu().view(N, P, HT), vf.float().cpu().view(N, HT, Cc)) + bias.cpu()
+    torch.cuda.synchronize()
+    tol = 1e-2 if precision == "bf16" else 1e-5
+    assert float((delta.float().cpu().view(N, P, Cc) - dref).abs().max()) <= tol * float(dref.abs().max())
+
+
+def test_folded_i2t_equals_projected_form(dev, mini, monkeypatch):
+    """The tracker with the image -> token attention folded into the token side (default) against the form that projects every
+    image token through i2t.q / i2t.out (L4P_TRACK_FOLD_I2T=0): the same function of the same weights with the products
+    associated differently.  f32 engine: equal to rounding over a 4-window recursion with 9 tracks (1e-4 of the maximum),
+    integer-valued outputs identical.  bf16 engine: two evaluation orders in bf16 are as far from each other as each is from the
+    f32 result, so the folded form is held to the PROJECTED form's own per-track distance from the f32 engine: the median track must
+    not be further from f32 than 1.5x the projected form's, and at most one of the nine tracks may have taken another branch (the
+    recursion re-seeds queries at an argmax; measured: track 4 does, every other track sits at 3e-4 / 6e-3 in both forms).
+    Switched in the Python composition (the native call reads the switch once per process); the native window must equal the
+    Python composition bit for bit in the default form."""
+    cfg, sd = mini
+    batch = make_batch(40, 9)
+    keys = ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]
+    res = {}
+    for precision in ("32-true", "bf16"):
+        model = build(cfg, sd, precision)
+        monkeypatch.setenv("L4P_TRACK_PYTHON", "1")
+        with torch.no_grad():
+            monkeypatch.setenv("L4P_TRACK_FOLD_I2T", "1")
+            a = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+            monkeypatch.setenv("L4P_TRACK_FOLD_I2T", "0")
+            b = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+            monkeypatch.delenv("L4P_TRACK_PYTHON")
+            monkeypatch.setenv("L4P_TRACK_FOLD_I2T", "1")
+            c = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+        torch.cuda.synchronize()
+        res[precision] = (a, b)
+        for k in keys:
+            assert torch.equal(a[k], c[k]), (precision, k, "native", float((a[k] - c[k]).abs().max()))
+            assert torch.equal(a[k] == -10.0, b[k] == -10.0) and torch.equal(a[k] == 0.0, b[k] == 0.0), (precision, k)
+        del model
+    def per_track(x, y):  # rel-L2 of every track of clip 0
+        return ((x - y)[0].flatten(1).norm(dim=1) / y[0].flatten(1).norm(dim=1).clamp_min(1e-9)).cpu()
+
+    for k in keys:
+        fa, fb = res["32-true"]
+        ha, hb = res["bf16"]
+        err = float((fa[k] - fb[k]).abs().max() / fb[k].abs().max())
+        d_fold, d_proj = per_track(ha[k].float(), fb[k]), per_track(hb[k].float(), fb[k])
+        print(k, f"f32 folded vs projected: max {err:.2e}; bf16 vs f32 per track (median, max): folded {float(d_fold.median()):.1e} "
+                 f"{float(d_fold.max()):.1e}, projected {float(d_proj.median()):.1e} {float(d_proj.max()):.1e}")
+        assert err <= 1e-4, (k, err)
+        # the typical track is as close to f32 in either form; at most one track of the nine may have taken another branch
+        assert float(d_fold.median()) <= 1.5 * float(d_proj.median()) + 1e-4, (k, d_fold, d_proj)
+        assert int((d_fold > 5 * d_proj.max() + 1e-3).sum()) <= 1, (k, d_fold, d_proj)
