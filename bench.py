@@ -92,17 +92,29 @@ def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int, n_windows: int = 1):
         vo = osz[0] * osz[1] * osz[2]
         conv += 2.0 * vo * 27 * (F_ // 2) * cfg.last_dim
     # tracker: 73.81 GFLOP per query and window in the reference graph, all but ~1 % of it in projections / up-scaling
-    # ConvTransposes that run through the GEMM kernel.  Two corrections, so that only work whose result is USED is credited:
+    # ConvTransposes that run through the GEMM kernel.  Three corrections, so that only work whose result is USED is credited:
     #  * processed_video_features_proj (sparse_heads.py:660-663, 2*S*D*D = 8.12 GF per query) feeds the NEXT window's
     #    memory tokens only, and only its second temporal half survives (sparse_heads.py:406-448): the last (or only)
     #    window needs none of it, every other window half of it;
-    #  * in a first window every track starts from the same keys, so the first layer's three image-side projections
-    #    (t2i.k, t2i.v, i2t.q: 2*S*D*(D/2) each) are one computation per clip, not one per track; in later windows the
-    #    second temporal half of the keys is still common to all tracks: half of those projections is one computation.
+    #  * in a first window every track starts from the same keys, so the first layer's image-side projections of the
+    #    token -> image attention (t2i.k, t2i.v: 2*S*D*(D/2) each) are one computation per clip, not one per track; in later
+    #    windows the second temporal half of the keys is still common to all tracks: half of those projections is one computation;
+    #  * round 4: the image -> token attention is evaluated in its FOLDED form (packing.py fold_i2t: the projections of the S image
+    #    tokens folded into the 6 prompt tokens of a track) - per layer the i2t.q and i2t.out projections (2*S*D*(D/2) each) and
+    #    the attention between them (4*S*6*(D/2)) are replaced by scores = keys x K'^T and delta = P x V' (2*S*D*6*heads each) and
+    #    the token-side products K' = k W_q, V' = W_out v (2*6*(D/2)*D each, block-diagonal over the heads).  The folded form
+    #    is what an implementation needs to execute, so it is what is credited: 14.8 GF per query and window less, and 7.6 GF
+    #    more for the two folded key projections of the token -> image attentions (layer 1 and the final one).
     if "track_2d" in tasks and n_queries > 0:
         hist_full = 2.0 * S * D * D
-        per_qw = TRACK_FLOPS_PER_QUERY_WINDOW - hist_full
-        shared = 3 * 2.0 * S * D * (D // 2)
+        HT = 6 * cfg.sam_heads
+        i2t_projected = 2 * (2.0 * S * D * (D // 2)) + 4.0 * S * 6 * (D // 2)
+        i2t_folded = 2 * (2.0 * S * D * HT) + 2 * (2.0 * 6 * (D // 2) * D)
+        # likewise the keys' projection of the token -> image attentions from layer 1 on and of the final one (fold_t2i): 2*S*D*(D/2)
+        # + the q.k products 2*S*6*(D/2) become scores = keys x Q'^T (2*S*D*6*heads) + Q' = q W_k (2*6*(D/2)*D)
+        t2i_saving = (2.0 * S * D * (D // 2) + 2.0 * S * 6 * (D // 2)) - (2.0 * S * D * HT + 2.0 * 6 * (D // 2) * D)
+        per_qw = TRACK_FLOPS_PER_QUERY_WINDOW - hist_full - cfg.sam_depth * (i2t_projected - i2t_folded) - cfg.sam_depth * t2i_saving
+        shared = 2 * 2.0 * S * D * (D // 2)
         total = n_windows * per_qw * n_queries                       # every window, every query
         total += (n_windows - 1) * 0.5 * hist_full * n_queries       # memory tokens for the windows that have a successor
         total -= shared * (n_queries - 1)                            # first window: shared image-side projections

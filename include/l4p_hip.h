@@ -41,7 +41,7 @@ typedef void* l4p_stream; /* hipStream_t */
 typedef struct l4p_engine l4p_engine;
 
 const char* l4p_last_error(void);
-int l4p_abi_version(void); /* 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs, l4p_split_hilo, l4p_transpose_pad */
+int l4p_abi_version(void); /* 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs, l4p_t2i_attn_scores, l4p_split_hilo, l4p_transpose_pad */
 
 /* Optional per-kernel-class timing: when enabled every kernel launch is bracketed by a HIP event pair
  * recorded on the launch stream (bench.py's live roofline numbers).  Classes: gemm, conv3d, attention,
@@ -347,6 +347,12 @@ int l4p_mask_gather(l4p_stream stream, const float* partial, float* masks, int N
 int l4p_i2t_probs(l4p_stream stream, int dtype, const float* scores, long long ld_scores, int pairs, const float* cbias, int rows_per_group,
                   void* probs_T, int ld_probs, long long M, int heads, int tokens);
 int l4p_split_hilo(l4p_stream stream, int dtype, const float* in, void* out_T, int G, int R, long long C);
+/* Token -> image attention (l4p_small_attn kind 1) from scores formed elsewhere: scores float [N * P][ld_scores], column t * heads + h
+ * = scaled score of prompt token t against image token p in head h (the keys' projection folded into the tokens: scores = kP x Q'^T,
+ * Q' = q W_k per head; the key bias shifts all P scores of a (t, h) alike and drops out of the softmax); v T [N][P][D];
+ * out T [N][6][D] = softmax over p, then P.V. */
+int l4p_t2i_attn_scores(l4p_stream stream, int dtype, const float* scores, long long ld_scores, const void* v_T, void* out_T, int N, int P,
+                        int D, int heads);
 int l4p_transpose_pad(l4p_stream stream, int dtype, const void* in_T, void* out_T, int G, int R, int C, int Rp);
 
 /* Fused read-out (sparse_heads.py:572-589,645-647): trilinear (align_corners=False) resize of masks

@@ -123,6 +123,7 @@ SIGNATURES = {
     "l4p_mask_gather": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I]),
     "l4p_i2t_probs": (_I, [_VP, _I, _VP, _LL, _I, _VP, _I, _VP, _I, _LL, _I, _I]),
     "l4p_split_hilo": (_I, [_VP, _I, _VP, _VP, _I, _I, _LL]),
+    "l4p_t2i_attn_scores": (_I, [_VP, _I, _VP, _LL, _VP, _VP, _I, _I, _I, _I]),
     "l4p_transpose_pad": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I]),
     "l4p_layernorm_t": (_I, [_VP, _I, _VP, _VP, _VP, C.c_float, _VP, _I, _I, _I]),
     "l4p_pil_coeffs": (_I, [_I, _I, _VP, _VP, _I, C.POINTER(_I)]),

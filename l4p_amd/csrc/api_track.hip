@@ -25,6 +25,8 @@ int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, 
 int launch_i2t_probs(int dtype, const float* s, long long lds_, int pairs, const float* cbias, int rows_per_group, void* p, int ldp,
                      long long M, int heads, int tokens, hipStream_t stream);
 int launch_split_hilo(int dtype, const float* in, void* out, int G, int R, long long C, hipStream_t stream);
+int launch_t2i_attn_scores(int dtype, const float* scores, long long ld_scores, const void* v, void* out, int N, int P, int D, int heads,
+                           hipStream_t stream);
 int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int C, int Rp, hipStream_t stream);
 int launch_mask_product(int dtype, const void* up, const float* hyper, float* masks, int N, long long vox, int Cc,
                         hipStream_t stream);
@@ -82,6 +84,10 @@ int l4p_mask_product(l4p_stream s, int dtype, const void* up, const float* hyper
 int l4p_i2t_probs(l4p_stream s, int dtype, const float* scores, long long ld_scores, int pairs, const float* cbias, int rows_per_group,
                   void* probs_T, int ld_probs, long long M, int heads, int tokens) {
     return launch_i2t_probs(dtype, scores, ld_scores, pairs, cbias, rows_per_group, probs_T, ld_probs, M, heads, tokens, (hipStream_t)s);
+}
+int l4p_t2i_attn_scores(l4p_stream s, int dtype, const float* scores, long long ld_scores, const void* v_T, void* out_T, int N, int P, int D,
+                        int heads) {
+    return launch_t2i_attn_scores(dtype, scores, ld_scores, v_T, out_T, N, P, D, heads, (hipStream_t)s);
 }
 int l4p_split_hilo(l4p_stream s, int dtype, const float* in, void* out_T, int G, int R, long long C) {
     return launch_split_hilo(dtype, in, out_T, G, R, C, (hipStream_t)s);

@@ -38,6 +38,8 @@ int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, 
 int launch_i2t_probs(int dtype, const float* s, long long lds_, int pairs, const float* cbias, int rows_per_group, void* p, int ldp,
                      long long M, int heads, int tokens, hipStream_t stream);
 int launch_split_hilo(int dtype, const float* in, void* out, int G, int R, long long C, hipStream_t stream);
+int launch_t2i_attn_scores(int dtype, const float* scores, long long ld_scores, const void* v, void* out, int N, int P, int D, int heads,
+                           hipStream_t stream);
 int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int C, int Rp, hipStream_t stream);
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
                          int W, hipStream_t stream);
@@ -219,6 +221,28 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         qT = oT;
         qP = oP;
     };
+    // Token -> image attention with the keys' projection folded into the tokens (packing.py fold_t2i; every track owns all rows of
+    // its keys): Q' = q_tok x kfold^T [N][HT][C], scores = kP x Q'^T (row-grouped weights), softmax over the P keys and P.V in
+    // l4p_t2i_attn_scores.  The [N * P, C/2] key projection (2 * P * C * C/2 FLOP per track, 4.06 GF) and its tensor disappear; the
+    // value projection stays (P.V contracts over the keys: folding it would need the keys transposed).
+    static const bool fold_t2i_env = !(getenv("L4P_TRACK_FOLD_T2I") && atoi(getenv("L4P_TRACK_FOLD_T2I")) == 0);
+    const int HTk = 6 * g.sam_heads;
+    const bool fold_t2i_ok = fold_t2i_env && P % 128 == 0 && HTk <= 64;
+    auto t2i_folded = [&](const void* tq, const std::string& prefix, const void* keysP, const void* tv, void* ta) {
+        const long long KW = (long long)g.sam_heads * Cc;
+        void* qf = c.T((long long)N * HTk + 128, Cc);  // Q' [N][HT][C] (+ slack rows under the last tile)
+        c.gemm(tq, 6ll * N, Dh, Dh, prefix + ".kfold", (int)KW, false, ACT_NONE, nullptr, 0, nullptr, qf, KW);
+        float* sc = c.f32(NP, HTk);
+        if (!c.rc && !c.dry) {
+            GemmParams p;
+            memset(&p, 0, sizeof(p));
+            p.A = keysP, p.lda = Cc, p.W = qf, p.ldw = Cc, p.M = (int)NP, p.N = HTk, p.K = Cc;
+            p.out_f32 = sc, p.ldc = HTk, p.epi = EPI_DENSE;
+            p.w_gr = P, p.w_gs = (long long)HTk * Cc, p.b_gs = 0;
+            c.rc = launch_gemm(c.dt, 0, p, c.st);
+            if (!c.rc) c.rc = launch_t2i_attn_scores(c.dt, sc, HTk, tv, ta, N, P, Dh, g.sam_heads, c.st);
+        }
+    };
     for (int l = 0; l < g.sam_depth; ++l) {
         const std::string lo = "l" + std::to_string(l) + ".";
         const bool shared = Nk == 1 && N > 1;  // keys still common to all tracks (only in layer 0 of a first window)
@@ -242,10 +266,17 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         {
             void* tq = c.proj(qP, 6ll * N, Cc, lo + "t2i.q", Dh);
             const bool hs = half_shared && l == 0;
-            void* tk = hs ? proj_half_shared(curP, lo + "t2i.k", Dh) : c.proj(curP, (long long)Nk * P, Cc, lo + "t2i.k", Dh);
             void* tv = hs ? proj_half_shared(curT, lo + "t2i.v", Dh) : c.proj(curT, (long long)Nk * P, Cc, lo + "t2i.v", Dh);
             void* ta = c.T(6ll * N, Dh);
-            c.attn(shared ? 3 : 1, tq, tk, tv, ta, N, P, Dh, g.sam_heads);
+            // (layer 0 keeps the projected form whatever the keys look like: where its keys are still common to all tracks, or
+            //  half common, the projection of the common rows is one small GEMM - and the per-track evaluation of the same window
+            //  (the equality tests of those shortcuts) stays bit-identical to it)
+            if (fold_t2i_ok && l >= 1 && !shared && !hs) {
+                t2i_folded(tq, lo + "t2i", curP, tv, ta);
+            } else {
+                void* tk = hs ? proj_half_shared(curP, lo + "t2i.k", Dh) : c.proj(curP, (long long)Nk * P, Cc, lo + "t2i.k", Dh);
+                c.attn(shared ? 3 : 1, tq, tk, tv, ta, N, P, Dh, g.sam_heads);
+            }
             c.gemm(ta, 6ll * N, Dh, Dh, lo + "t2i.out", Cc, true, ACT_NONE, q32, 0, x32, nullptr, Cc);
         }
         c.ws.off = mark;
@@ -359,10 +390,14 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
     size_t mark = c.ws.off;
     {
         void* fq = c.proj(qP, 6ll * N, Cc, "final.q", Dh);
-        void* fk = c.proj(curP, (long long)Nk * P, Cc, "final.k", Dh);
         void* fv = c.proj(curT, (long long)Nk * P, Cc, "final.v", Dh);
         void* fa = c.T(6ll * N, Dh);
-        c.attn(1, fq, fk, fv, fa, N, P, Dh, g.sam_heads);
+        if (fold_t2i_ok && Nk == N) {
+            t2i_folded(fq, "final", curP, fv, fa);
+        } else {
+            void* fk = c.proj(curP, (long long)Nk * P, Cc, "final.k", Dh);
+            c.attn(1, fq, fk, fv, fa, N, P, Dh, g.sam_heads);
+        }
         c.gemm(fa, 6ll * N, Dh, Dh, "final.out", Cc, true, ACT_NONE, q32, 0, x32, nullptr, Cc);
     }
     c.ws.off = mark;

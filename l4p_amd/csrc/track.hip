@@ -189,7 +189,8 @@ __global__ __launch_bounds__(64) void self_attn6_kernel(const T* __restrict__ q,
 template <typename T>
 __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, T* __restrict__ out, int P, int D, int hd,
-                                                       float scale, long long kv_stride) {
+                                                       float scale, long long kv_stride, const float* __restrict__ pre = nullptr,
+                                                       long long ld_pre = 0, int heads = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = (float*)smem;      // [6][P]
     float* qs = sc + 6 * P;        // [6][hd]
@@ -198,7 +199,18 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, 
     const T* qp = q + (long long)n * 6 * D + (long long)h * hd;
     const T* kp = k + (long long)n * kv_stride + (long long)h * hd;  // kv_stride = P*D, or 0 when every query shares K / V
     const T* vp = v + (long long)n * kv_stride + (long long)h * hd;
-    for (int i = tid; i < 6 * hd; i += 256) qs[(i / hd) * 96 + (i % hd)] = (float)qp[(long long)(i / hd) * D + (i % hd)];
+    // pre: the scaled scores were formed elsewhere (folded keys: l4p_t2i_attn_scores) - pre[(n * P + p) * ld_pre + i * heads + h]
+    if (pre) {
+        const float* pr = pre + (long long)n * P * ld_pre + h;
+        for (int p = tid; p < P; p += 256) {
+            float sv[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sv[i] = pr[(long long)p * ld_pre + i * heads];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sc[i * P + p] = sv[i];
+        }
+    } else
+        for (int i = tid; i < 6 * hd; i += 256) qs[(i / hd) * 96 + (i % hd)] = (float)qp[(long long)(i / hd) * D + (i % hd)];
     __syncthreads();
     // scores
     // bf16, head dims in whole 16-byte chunks: a thread requests its WHOLE key row (hd / 8 chunks of 16 bytes) at once and the next
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, 
     constexpr int MAXCH = 12;  // (174 VGPRs: two workgroups per CU instead of the three LDS would allow - measured equal to a
                                //  168-register build with three; the phase is VALU-bound past this point: 112.7 vs 122 us at 64 tracks)
     const bool whole_rows = sizeof(T) == 2 && (hd & 7) == 0 && (hd >> 3) <= MAXCH;
-    if (whole_rows) {
+    if (whole_rows && !pre) {
         const int nch = hd >> 3;
         bf16x8 cur[MAXCH], nxt[MAXCH];
         auto load_row = [&](int p, bf16x8 (&r)[MAXCH]) {
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, 
             for (int c = 0; c < MAXCH; ++c) cur[c] = nxt[c];
         }
     }
-    for (int p = tid; p < P && !whole_rows; p += 256) {
+    for (int p = tid; p < P && !whole_rows && !pre; p += 256) {
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const T* kr = kp + (long long)p * D;
         // the key row is requested in batches of 4 loads before any is used (a thread reads its row alone: without the
@@ -779,6 +791,34 @@ __global__ void transpose_pad_kernel(const T* __restrict__ in, T* __restrict__ o
 // ------------------------------------------------------------------------------------------------
 #define GRID1D(total, cap) ((int)(((total) + 255) / 256 < (cap) ? ((total) + 255) / 256 : (cap)))
 
+// tokens -> image attention from scores formed elsewhere (folded keys): softmax over the P keys per (track, token, head), then P.V
+int launch_t2i_attn_scores(int dtype, const float* scores, long long ld_scores, const void* v, void* out, int N, int P, int D, int heads,
+                           hipStream_t stream) {
+    const int hd = heads > 0 ? D / heads : 0;
+    if (heads < 1 || hd * heads != D || hd % 4 || hd > 96 || P % 4 || ld_scores < 6 * heads) {
+        l4p_set_error("t2i_attn_scores: D = heads * hd with hd %% 4 == 0, hd <= 96, P %% 4 == 0, ld_scores >= 6 * heads");
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_TRACK, stream, "small_attn kind5 N%d P%d D%d", N, P, D);
+    const int ncg = hd / 4, nkg = 256 / ncg;
+    size_t lds = (size_t)(6 * P + 6 * 96 + 256) * 4;
+    const size_t need2 = (size_t)nkg * 6 * hd * 4;
+    if (need2 > (size_t)6 * P * 4) lds += need2 - (size_t)6 * P * 4;
+    const long long kv_stride = (long long)P * D;
+    if (dtype == L4P_BF16) {
+        auto kb = t2i_attn_kernel<bf16_t>;
+        HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kb, dim3(N, heads), dim3(256), lds, stream, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)v,
+                           (bf16_t*)out, P, D, hd, 1.f, kv_stride, scores, ld_scores, heads);
+    } else {
+        auto kf = t2i_attn_kernel<float>;
+        HIP_TRY(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kf, dim3(N, heads), dim3(256), lds, stream, (const float*)nullptr, (const float*)nullptr, (const float*)v,
+                           (float*)out, P, D, hd, 1.f, kv_stride, scores, ld_scores, heads);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int launch_i2t_probs(int dtype, const float* s, long long lds_, int pairs, const float* cbias, int rows_per_group, void* p, int ldp,
                      long long M, int heads, int tokens, hipStream_t stream) {
     if (tokens < 1 || tokens > 8 || heads < 1 || ldp < tokens * heads || lds_ < (pairs ? 2 : 1) * tokens * heads || (cbias && rows_per_group < 1)) {
@@ -916,11 +956,11 @@ int launch_small_attn(int dtype, int kind, const void* q, const void* k, const v
         if (dtype == L4P_BF16) {
             HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kb, dim3(N, heads), dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, scale, kv_stride);
+                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, scale, kv_stride, (const float*)nullptr, 0ll, 0);
         } else {
             HIP_TRY(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kf, dim3(N, heads), dim3(256), lds, stream, (const float*)q, (const float*)k,
-                               (const float*)v, (float*)out, P, D, hd, scale, kv_stride);
+                               (const float*)v, (float*)out, P, D, hd, scale, kv_stride, (const float*)nullptr, 0ll, 0);
         }
     } else if (kind == 2 || kind == 4) {  // image -> tokens (4: one query set shared by every track)
         const long long q_stride = kind == 2 ? (long long)P * D : 0;

@@ -185,6 +185,22 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         _lib.check(lib.l4p_track_keys_init(_stream(), dt, _p(enc_last), _p(hist), _p(pos), _p(k32), _p(kT), _p(kP), Nk, P, Cc,
                                            P // 2 if half_shared else 0, _p(kh32) if half_shared else None), "l4p_track_keys_init")
 
+        # token -> image attention with the keys' projection folded into the tokens (packing.py fold_t2i; csrc/api_trackwin.hip has
+        # the same sequence): Q' = q_tok x kfold^T, scores = kP x Q'^T (row-grouped weights), softmax over the keys + P.V
+        HTk = 6 * cfg.sam_heads
+        fold_t2i_ok = os.environ.get("L4P_TRACK_FOLD_T2I", "1") != "0" and P % 128 == 0 and HTk <= 64
+
+        def t2i_folded(tq: torch.Tensor, prefix: str, keysP: torch.Tensor, tv: torch.Tensor) -> torch.Tensor:
+            KW = cfg.sam_heads * Cc
+            qf = torch.empty((N * HTk + 128, Cc), dtype=td, device=dev)  # Q' [N][HT][C] (+ slack rows under the last tile)
+            _gemm(tq, 6 * N, Dh, Dh, self._w(prefix + ".kfold.w"), KW, out_T=qf, ldc=KW)
+            sc = torch.empty((N * P, HTk), **f32)
+            _gemm(keysP, N * P, Cc, Cc, qf, HTk, out_f32=sc, ldc=HTk, wgroup=(P, HTk * Cc, 0), ldw=Cc)
+            ta = torch.empty((6 * N, Dh), dtype=td, device=dev)
+            _lib.check(lib.l4p_t2i_attn_scores(_stream(), dt, _p(sc), HTk, _p(tv), _p(ta), N, P, Dh, cfg.sam_heads),
+                       "l4p_t2i_attn_scores")
+            return ta
+
         q32: Optional[torch.Tensor] = None
         qT, qP = tokT, tokT
         x32 = torch.empty((6 * N, Cc), **f32)
@@ -201,10 +217,14 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             # --- tokens -> image (transformer.py:168-173) ---
             tq = self._proj(qP, lo + "t2i.q", Dh)
             hs = half_shared and l == 0
-            tk = proj_half_shared(kP, lo + "t2i.k", Dh) if hs else self._proj(kP, lo + "t2i.k", Dh)
             tv = proj_half_shared(kT, lo + "t2i.v", Dh) if hs else self._proj(kT, lo + "t2i.v", Dh)
-            ta = self._attn(3 if shared else 1, tq, tk, tv, N, P, Dh)
-            del tk, tv
+            if fold_t2i_ok and l >= 1 and not shared and not hs:  # (layer 0 keeps the projected form: see csrc/api_trackwin.hip)
+                ta = t2i_folded(tq, lo + "t2i", kP, tv)
+            else:
+                tk = proj_half_shared(kP, lo + "t2i.k", Dh) if hs else self._proj(kP, lo + "t2i.k", Dh)
+                ta = self._attn(3 if shared else 1, tq, tk, tv, N, P, Dh)
+                del tk
+            del tv
             _gemm(ta, 6 * N, Dh, Dh, self._w(lo + "t2i.out.w"), Cc, bias=self._w(lo + "t2i.out.b"), res1=q32, out_f32=x32)
             q32, qT, qP = self._ln(x32, lo + "norm2", tok32, 6 * N, out32=torch.empty_like(x32))
             # --- MLP (transformer.py:175-178), ReLU ---
@@ -284,10 +304,14 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             del delta, k_res
         # --- final tokens -> image attention (transformer.py:103-109) ---
         fq = self._proj(qP, "final.q", Dh)
-        fk = self._proj(kP, "final.k", Dh)
         fv = self._proj(kT, "final.v", Dh)
-        fa = self._attn(1, fq, fk, fv, N, P, Dh)
-        del fk, fv, kP
+        if fold_t2i_ok and Nk == N:
+            fa = t2i_folded(fq, "final", kP, fv)
+        else:
+            fk = self._proj(kP, "final.k", Dh)
+            fa = self._attn(1, fq, fk, fv, N, P, Dh)
+            del fk
+        del fv, kP
         _gemm(fa, 6 * N, Dh, Dh, self._w("final.out.w"), Cc, bias=self._w("final.out.b"), res1=q32, out_f32=x32)
         _, hsT, _ = self._ln(x32, "norm_final", None, 0, want_T2=False)
 

@@ -200,12 +200,27 @@ def pack_track(pk: Packer, sd: Dict[str, torch.Tensor], c: ModelCfg, task: str =
         pk.T(f"{dst}.cfold.w", cf)
         pk.T(f"{dst}.ofold.w", of)
 
+    def fold_t2i(src: str, dst: str):
+        """Token -> image attention with the keys' projection folded into the tokens (sam/transformer.py:168-173,103-109):
+        scores[t, h, p] = scale * q_t,h . (kP[p] Wk^T + bk)_h = kP[p] . Q'[t, h] + const(t, h), Q' = q_tok x kfold^T with
+        kfold [(h, ch)][j] = scale * Wk[j, ch] for j in head h, else 0; the constant drops out of the softmax over p."""
+        wk = sd[f"{src}.k_proj.weight"].float()
+        inner, C_ = wk.shape
+        heads = c.sam_heads
+        hd = inner // heads
+        kf = torch.zeros(heads * C_, inner)
+        for h in range(heads):
+            js = slice(h * hd, (h + 1) * hd)
+            kf[h * C_:(h + 1) * C_, js] = hd ** -0.5 * wk[js].t()
+        pk.T(f"{dst}.kfold.w", kf)
+
     for l in range(c.sam_depth):
         lp, lo = f"{t}layers.{l}.", f"{o}l{l}."
         attn(lp + "self_attn", lo + "self")
         attn(lp + "cross_attn_token_to_image", lo + "t2i")
         attn(lp + "cross_attn_image_to_token", lo + "i2t")
         fold_i2t(lp + "cross_attn_image_to_token", lo + "i2t")
+        fold_t2i(lp + "cross_attn_token_to_image", lo + "t2i")
         for k in (1, 2, 3, 4):
             norm(f"{lp}norm{k}", f"{lo}norm{k}")
         pk.T(lo + "mlp1.w", sd[lp + "mlp.lin1.weight"])
@@ -213,6 +228,7 @@ def pack_track(pk: Packer, sd: Dict[str, torch.Tensor], c: ModelCfg, task: str =
         pk.T(lo + "mlp2.w", sd[lp + "mlp.lin2.weight"])
         pk.F(lo + "mlp2.b", sd[lp + "mlp.lin2.bias"])
     attn(t + "final_attn_token_to_image", o + "final")
+    fold_t2i(t + "final_attn_token_to_image", o + "final")
     norm(t + "norm_final_attn", o + "norm_final")
     m = p + "mask_decoder."
     w0 = sd[m + "output_upscaling.0.weight"]

@@ -1,7 +1,8 @@
 """bench.py's algorithmic FLOP model (what `roofline.achieved` is computed from) against what the engine EXECUTES:
-the sum of 2*M*N*K over the per-shape event profile of a c3 step (profiles/r02_c3_per_shape_event_profile.txt, written by
+the sum of 2*M*N*K over the per-shape event profile of a c3 step (profiles/r04_c3_per_shape_event_profile.txt, written by
 tools/prof_detail.py on the GPU), minus the padding the kernels add (head dim 88 -> 96 in the QKV projection, per-tap
-channels 176 -> 192 in the tracker's last up-scaling, patch vector 1176 -> 1216).  The two must agree within 2 %: nothing
+channels 176 -> 192 in the tracker's last up-scaling, patch vector 1176 -> 1216, and in the tracker's folded image -> token
+attention the k dimension 48 -> 64 of P x V' and the structural zeros of the block-diagonal token-side weights).  The two must agree within 2 %: nothing
 that does not run is credited (the history projection of a last window), nothing that runs for padding either."""
 import os
 import re
@@ -10,7 +11,7 @@ import bench
 from l4p_amd.weights import ModelCfg
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROFILE = os.path.join(ROOT, "profiles", "r02_c3_per_shape_event_profile.txt")
+PROFILE = os.path.join(ROOT, "profiles", "r04_c3_per_shape_event_profile.txt")
 LINE = re.compile(r"^(gemm|conv3d)\s+M(\d+) N(\d+) K(\d+) epi(\d) act\d .*?\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s*$")
 
 
@@ -28,6 +29,12 @@ def executed_flops():
                 N = N * 176 // 192          # up1 + mask product: 176 channels per tap padded to 192
             if K == 1216:
                 K = 1176                    # patch vector 3*2*14*14 padded to a multiple of 64
+            if "wgrp" in ln and K == 64:
+                K = 48                      # folded i2t, P x V': 6 tokens x 8 heads, padded to one k-tile
+            if N == 8 * 1408 and K == 704:
+                N = 1408                    # folded i2t, token side: block-diagonal weights, head h meets head h's 1408 rows only
+            if N == 8 and K == 704:
+                N = 1                       # (the query-bias term likewise)
         tot[cls] += 2.0 * M * N * K * n
     return tot
 
@@ -49,7 +56,7 @@ def test_history_projection_is_credited_only_where_it_is_needed():
     # a 3-window clip vs three single-window clips: two windows project the half of the tokens their successor keeps
     # (2 * 0.5 * hist); the FIRST window shares the image-side projections of layer 0 across tracks in full, the two later
     # windows share their track-independent temporal half (2 * 63 * shared lost, 2 * 0.5 * 63 * shared of it recovered)
-    hist, shared = 2.0 * S * D * D, 3 * 2.0 * S * D * (D // 2)
+    hist, shared = 2.0 * S * D * D, 2 * 2.0 * S * D * (D // 2)  # (shared: t2i.k, t2i.v of layer 0; i2t is folded)
     assert abs((3 * three - 3 * one) - (64 * hist + 2 * 63 * shared - 63 * shared)) <= 1e-6 * one
-    # a single window credits less than the reference graph's 73.81 GF per query
+    # a single window credits less than the reference graph's 73.81 GF per query (no history projection, folded i2t)
     assert bench.algorithmic_flops(cfg, ["track_2d"], 64)["gemm"] - bench.algorithmic_flops(cfg, ["track_2d"], 0)["gemm"] < 73.81e9 * 64 - 64 * hist + 1

@@ -446,9 +446,10 @@ def test_row_grouped_weights_gemm_and_folded_i2t_kernels(dev, precision):
 
 
 def test_folded_i2t_equals_projected_form(dev, mini, monkeypatch):
-    """The tracker with the image -> token attention folded into the token side (default) against the form that projects every
-    image token through i2t.q / i2t.out (L4P_TRACK_FOLD_I2T=0): the same function of the same weights with the products
-    associated differently.  f32 engine: equal to rounding over a 4-window recursion with 9 tracks (1e-4 of the maximum),
+    """The tracker with the image-side projections of its cross attentions folded into the token side (default: i2t.q / i2t.out of
+    the image -> token attention, t2i.k / final.k of the token -> image attentions) against the form that projects every image
+    token (L4P_TRACK_FOLD_I2T=0 L4P_TRACK_FOLD_T2I=0): the same function of the same weights with the products associated
+    differently.  f32 engine: equal to rounding over a 4-window recursion with 9 tracks (1e-4 of the maximum),
     integer-valued outputs identical.  bf16 engine: two evaluation orders in bf16 are as far from each other as each is from the
     f32 result, so the folded form is held to the PROJECTED form's own per-track distance from the f32 engine: the median track must
     not be further from f32 than 1.5x the projected form's, and at most one of the nine tracks may have taken another branch (the
@@ -464,11 +465,14 @@ def test_folded_i2t_equals_projected_form(dev, mini, monkeypatch):
         monkeypatch.setenv("L4P_TRACK_PYTHON", "1")
         with torch.no_grad():
             monkeypatch.setenv("L4P_TRACK_FOLD_I2T", "1")
+            monkeypatch.setenv("L4P_TRACK_FOLD_T2I", "1")
             a = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
             monkeypatch.setenv("L4P_TRACK_FOLD_I2T", "0")
+            monkeypatch.setenv("L4P_TRACK_FOLD_T2I", "0")
             b = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
             monkeypatch.delenv("L4P_TRACK_PYTHON")
             monkeypatch.setenv("L4P_TRACK_FOLD_I2T", "1")
+            monkeypatch.setenv("L4P_TRACK_FOLD_T2I", "1")
             c = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
         torch.cuda.synchronize()
         res[precision] = (a, b)
