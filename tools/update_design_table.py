@@ -1,11 +1,11 @@
-"""Rewrite the round's measurement table in DESIGN.md (between the R3TABLE markers) from profiles/<tag>_*_bench_line.json.
-usage: python tools/update_design_table.py [tag=r03]"""
+"""Rewrite the round's measurement table in DESIGN.md (between the R4TABLE markers) from profiles/<tag>_*_bench_line.json.
+usage: python tools/update_design_table.py [tag=r04]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(ROOT, "profiles")
 
 
@@ -32,7 +32,7 @@ rows = [("c3: all heads, B=4, 64 queries/clip", c3), ("c2: depth only, B=1", c2)
 b8 = os.path.join(P, f"{tag}_c3_batch8_bench_line.json")
 if os.path.exists(b8):
     rows.insert(1, ("c3 at batch 8 (the per-GPU batch of configs[3])", json.load(open(b8))))
-t = ("<!--R3TABLE-BEGIN-->\n| workload | frames/s | ms/step | GEMM class | conv3d class | attention | LayerNorm | elementwise | tracker kernels |\n"
+t = ("<!--R4TABLE-BEGIN-->\n| workload | frames/s | ms/step | GEMM class | conv3d class | attention | LayerNorm | elementwise | tracker kernels |\n"
      "|---|---|---|---|---|---|---|---|---|\n")
 for name, d in rows:
     t += (f"| {name} | **{d['value']:.0f}** | {d['ms_per_step']:.1f} | {kc(d, 'gemm')} | {kc(d, 'conv3d')} | {kc(d, 'attention')} | "
@@ -46,11 +46,14 @@ t += (f"\n`roofline` of the c3 line: GEMM class {rg['achieved']:.0f} TF/s = **{r
       f"rocprofv3 average of the same command {avg:.2f} µs = {94.49 / avg / 2.5:.3f}, `profiles/{tag}_c3_kernel_stats.md`; c5: "
       f"{c5['roofline_attention']['frac']:.3f} at its batch of 16 windows).  CPU oracle on the same box: {c3['cpu_baseline']['value']:.2f} frames/s on "
       f"{c3['cpu_baseline']['cores']} cores ({c3['cpu_baseline']['sample'].split(';')[1].strip()}).\n")
-t += (f"c5 phases: phase 1 {c5['phase1_ms']:.0f} ms, phase 3 dense {c5['phase3_dense_ms']:.1f} ms + tracker {c5['phase3_track_ms']:.0f} ms "
-      f"({c5['phase3_track_ms_on_an_eighth_of_the_queries']:.0f} ms on an eighth of the queries): implied 8-GPU speed-up with the query-sharded "
-      f"tracker {c5['implied_8gpu_speedup_query_sharded_tracker']:.1f}×.\n<!--R3TABLE-END-->\n")
+g = c5.get
+t += (f"c5 pieces on one GPU: encoders {g('phase1a_encoder_ms'):.0f} ms, decoders {g('phase1b_decoders_ms'):.0f} ms, dense stitch {g('phase3_dense_ms'):.1f} ms, "
+      f"tracker {g('phase3_track_ms'):.0f} ms ({g('phase3_track_ms_on_an_eighth_of_the_queries'):.0f} ms on an eighth of the queries), exchanges on one rank "
+      f"{g('exchange_last_ms'):.1f} + {g('exchange_decoded_ms'):.1f} ms.  **One of eight ranks, emulated and measured: {g('emulated_rank0_of_8_ms'):.0f} ms "
+      f"= {g('implied_8gpu_speedup_emulated_rank'):.1f}x** implied on 8 GPUs (models: tracker after the decoders "
+      f"{g('implied_8gpu_speedup_tracker_after_decoders'):.1f}x, ideally beside them {g('implied_8gpu_speedup_tracker_beside_decoders'):.1f}x).\n<!--R4TABLE-END-->\n")
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
-i, j = s.index("<!--R3TABLE-BEGIN-->"), s.index("<!--R3TABLE-END-->") + len("<!--R3TABLE-END-->\n")
+i, j = s.index("<!--R4TABLE-BEGIN-->"), s.index("<!--R4TABLE-END-->") + len("<!--R4TABLE-END-->\n")
 open(path, "w").write(s[:i] + t + s[j:])
 print(t)
