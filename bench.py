@@ -104,7 +104,7 @@ def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int, n_windows: int = 1):
     #    the attention between them (4*S*6*(D/2)) are replaced by scores = keys x K'^T and delta = P x V' (2*S*D*6*heads each) and
     #    the token-side products K' = k W_q, V' = W_out v (2*6*(D/2)*D each, block-diagonal over the heads).  The folded form
     #    is what an implementation needs to execute, so it is what is credited: 14.8 GF per query and window less, and 7.6 GF
-    #    more for the two folded key projections of the token -> image attentions (layer 1 and the final one).
+    #    more for the two folded key projections (and again for the two folded value projections, below) of the token -> image attentions (layer 1 and the final one).
     if "track_2d" in tasks and n_queries > 0:
         hist_full = 2.0 * S * D * D
         HT = 6 * cfg.sam_heads
@@ -113,7 +113,9 @@ def algorithmic_flops(cfg: ModelCfg, tasks, n_queries: int, n_windows: int = 1):
         # likewise the keys' projection of the token -> image attentions from layer 1 on and of the final one (fold_t2i): 2*S*D*(D/2)
         # + the q.k products 2*S*6*(D/2) become scores = keys x Q'^T (2*S*D*6*heads) + Q' = q W_k (2*6*(D/2)*D)
         t2i_saving = (2.0 * S * D * (D // 2) + 2.0 * S * 6 * (D // 2)) - (2.0 * S * D * HT + 2.0 * 6 * (D // 2) * D)
-        per_qw = TRACK_FLOPS_PER_QUERY_WINDOW - hist_full - cfg.sam_depth * (i2t_projected - i2t_folded) - cfg.sam_depth * t2i_saving
+        # ... and their VALUE projection (l4p_t2i_context): 2*S*D*(D/2) + the P.V products 2*S*6*(D/2) become ctx = probs x keys
+        # (2*S*6*heads*D) + the 48 context rows through their head's block of W_v (2*6*D*(D/2)/1): the same count again
+        per_qw = TRACK_FLOPS_PER_QUERY_WINDOW - hist_full - cfg.sam_depth * (i2t_projected - i2t_folded) - 2 * cfg.sam_depth * t2i_saving
         shared = 2 * 2.0 * S * D * (D // 2)
         total = n_windows * per_qw * n_queries                       # every window, every query
         total += (n_windows - 1) * 0.5 * hist_full * n_queries       # memory tokens for the windows that have a successor
@@ -587,15 +589,23 @@ def main():
 
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_hbm_traffic.json")))
         tpath = cands[-1] if cands else ""
+        traffic_note = "no PMC traffic file for this workload"
         if args.workload == "c3" and B == 4 and tpath:
             with open(tpath) as f:
-                traffic = {k: v["hbm_total"] for k, v in json.load(f)["per_class_bytes_per_launch"].items()}
+                tj = json.load(f)
+            # only figures measured on THESE kernels: the file carries the hash of the kernel sources it was taken on
+            if tj.get("kernel_tree") == _lib.kernel_tree_hash():
+                traffic = {k: v["hbm_total"] for k, v in tj["per_class_bytes_per_launch"].items()}
+                traffic_note = f"profiles/{os.path.basename(tpath)} (kernel tree {tj['kernel_tree']})"
+            else:
+                traffic_note = (f"profiles/{os.path.basename(tpath)} was measured on kernel tree {tj.get('kernel_tree')}, this is "
+                                f"{_lib.kernel_tree_hash()}: not attached (re-run tools/make_profiles.sh)")
 
         def roof(k):
             a = classes[k]["tflops"]
             return {"kernel": kern[k], "bound": "mfma", "achieved": a, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
                     "frac": round(a / (PEAK_BF16_MFMA / 1e12), 4), "traffic": traffic.get(k),
-                    "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this command: profiles/{os.path.basename(tpath)})",
+                    "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this command): {traffic_note}",
                     "method": "algorithmic FLOPs / HIP-event-bracketed kernel time, second pass of the same K steps",
                     "avg_launch_us": classes[k]["avg_launch_us"], "launches_per_step": classes[k]["launches_per_step"],
                     "algorithmic_flops_per_step": fl[k] * B * nwin_rank0}

@@ -41,7 +41,8 @@ typedef void* l4p_stream; /* hipStream_t */
 typedef struct l4p_engine l4p_engine;
 
 const char* l4p_last_error(void);
-int l4p_abi_version(void); /* 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs, l4p_t2i_attn_scores, l4p_split_hilo, l4p_transpose_pad */
+int l4p_abi_version(void); /* 4: l4p_gemm_desc.o_gs, l4p_i2t_delta, l4p_t2i_probs, l4p_t2i_context; 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs,
+                              * l4p_t2i_attn_scores, l4p_split_hilo, l4p_transpose_pad */
 
 /* Optional per-kernel-class timing: when enabled every kernel launch is bracketed by a HIP event pair
  * recorded on the launch stream (bench.py's live roofline numbers).  Classes: gemm, conv3d, attention,
@@ -142,6 +143,9 @@ typedef struct l4p_gemm_desc {
     int w_gr;
     long long w_gs;
     int b_gs;
+    /* ... and write to out_T / out_f32 + g * o_gs (elements; with the c_* row map rows of all groups can land on the same physical rows
+     * in their own column blocks: the per-head value projection of the folded token -> image attention, l4p_t2i_context) */
+    long long o_gs;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);
@@ -354,6 +358,24 @@ int l4p_split_hilo(l4p_stream stream, int dtype, const float* in, void* out_T, i
 int l4p_t2i_attn_scores(l4p_stream stream, int dtype, const float* scores, long long ld_scores, const void* v_T, void* out_T, int N, int P,
                         int D, int heads);
 int l4p_transpose_pad(l4p_stream stream, int dtype, const void* in_T, void* out_T, int G, int R, int C, int Rp);
+/* Token -> image attention with the value projection folded away as well (sam/transformer.py:168-173,223-245):
+ *   out[t, head h] = sum_p prob[t,h,p] (keys[p] Wv_h^T + bv_h) = (sum_p prob[t,h,p] keys[p]) Wv_h^T + bv_h.
+ * l4p_t2i_probs: scores float [N][P][ld_scores] (column t * heads + h, 48 of them) -> e T [N][P][48] = exp(score - m) with m the column
+ *   maximum over the SPLIT of 256 keys the row belongs to, and stats float [N][ceil(P / 256)][2][48]: those maxima, and the splits'
+ *   sums of e AS ROUNDED to T (the weights the context product applies then sum to one exactly).  (One coalesced pass over 8 x N workgroups; the softmax over all P keys is assembled by l4p_t2i_context: a split's
+ *   terms carry exp(m_split - M) / Z.)
+ * l4p_t2i_context: ctx T [(h * Rg + n * tokens + t)][C] = sum_p softmax_p[n][p][t * heads + h] * keys[n][p][C] (keys T [N][P][C] WITHOUT
+ *   the positional term; rows grouped by head with Rg >= N * tokens rows per group, a multiple of 128, rows past N * tokens untouched):
+ *   the A operand of the row-grouped-weights GEMM against the head blocks of W_v (w_gr = Rg, w_gs = hd * C, b_gs = o_gs = hd, c_gr = Rg).
+ *   heads * tokens == 48, C % 64 == 0, P % 32 == 0, 96 <= P <= 4096.  bf16: MFMA kernel bound by one read of the keys. */
+/* delta = P x V' + b of the folded image -> token attention as a streaming kernel (bf16, K == 64, C % 128 == 0, P % 16 == 0): probs T
+ * [N][P][64] (l4p_i2t_probs), vt T [N][C][64] (l4p_transpose_pad), bias float [C] or NULL -> delta T [N][P][C].  Bit-identical to
+ * l4p_gemm with w_gr = P, w_gs = C * 64 on the same operands, which serves every other shape / dtype. */
+int l4p_i2t_delta(l4p_stream stream, int dtype, const void* probs_T, const void* vt_T, const float* bias, void* delta_T, int N, int P, int C,
+                  int K);
+int l4p_t2i_probs(l4p_stream stream, int dtype, const float* scores, long long ld_scores, void* probs_T, float* stats, int N, int P, int HT);
+int l4p_t2i_context(l4p_stream stream, int dtype, const void* probs_T, const float* stats, const void* keys_T, void* ctx_T, int N, int P,
+                    int C, int heads, int tokens, long long Rg);
 
 /* Fused read-out (sparse_heads.py:572-589,645-647): trilinear (align_corners=False) resize of masks
  * [N][3][T][h][w] to H x W, soft-argmax of channel 0 (traj [N][2][T]), spatial mean of channel 1

@@ -45,7 +45,7 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int), ("partial", C.c_void_p),
         ("hyper", C.c_void_p), ("hyper_rows", C.c_int),
         ("q_scale", C.c_float), ("tuning", C.c_int),
-        ("w_gr", C.c_int), ("w_gs", C.c_longlong), ("b_gs", C.c_int),
+        ("w_gr", C.c_int), ("w_gs", C.c_longlong), ("b_gs", C.c_int), ("o_gs", C.c_longlong),
     ]
 
 
@@ -125,6 +125,9 @@ SIGNATURES = {
     "l4p_split_hilo": (_I, [_VP, _I, _VP, _VP, _I, _I, _LL]),
     "l4p_t2i_attn_scores": (_I, [_VP, _I, _VP, _LL, _VP, _VP, _I, _I, _I, _I]),
     "l4p_transpose_pad": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I]),
+    "l4p_i2t_delta": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I]),
+    "l4p_t2i_probs": (_I, [_VP, _I, _VP, _LL, _VP, _VP, _I, _I, _I]),
+    "l4p_t2i_context": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _LL]),
     "l4p_layernorm_t": (_I, [_VP, _I, _VP, _VP, _VP, C.c_float, _VP, _I, _I, _I]),
     "l4p_pil_coeffs": (_I, [_I, _I, _VP, _VP, _I, C.POINTER(_I)]),
     "l4p_pil_resample_u8": (_I, [_VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _VP, _VP, _I]),
@@ -174,6 +177,23 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def kernel_tree_hash() -> str:
+    """sha1 over the kernel sources and the C header (file names + contents, sorted): ties a measurement artefact (the PMC traffic
+    file under profiles/) to the kernels it was taken on - bench.py attaches `roofline.traffic` only when the hashes agree."""
+    import hashlib
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(os.path.join(root, "csrc", f) for f in os.listdir(os.path.join(root, "csrc"))
+                   if f.endswith((".hip", ".hpp", ".inc")))
+    files.append(os.path.join(os.path.dirname(root), "include", "l4p_hip.h"))
+    h = hashlib.sha1()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc: int, what: str = "") -> None:

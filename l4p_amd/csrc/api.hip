@@ -29,7 +29,7 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
 extern "C" {
 
 const char* l4p_last_error(void) { return g_err; }
-int l4p_abi_version(void) { return 3; }
+int l4p_abi_version(void) { return 4; }
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d) {
     if (!d) {

@@ -28,6 +28,11 @@ int launch_split_hilo(int dtype, const float* in, void* out, int G, int R, long 
 int launch_t2i_attn_scores(int dtype, const float* scores, long long ld_scores, const void* v, void* out, int N, int P, int D, int heads,
                            hipStream_t stream);
 int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int C, int Rp, hipStream_t stream);
+int launch_i2t_delta(int dtype, const void* probs, const void* vt, const float* bias, void* delta, int N, int P, int C, int K,
+                     hipStream_t stream);
+int launch_t2i_probs(int dtype, const float* scores, long long ld_scores, void* probs, float* stats, int N, int P, int HT, hipStream_t stream);
+int launch_t2i_context(int dtype, const void* probs, const float* stats, const void* keys, void* ctx, int N, int P, int C, int heads,
+                       int tokens, long long Rg, hipStream_t stream);
 int launch_mask_product(int dtype, const void* up, const float* hyper, float* masks, int N, long long vox, int Cc,
                         hipStream_t stream);
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
@@ -94,6 +99,16 @@ int l4p_split_hilo(l4p_stream s, int dtype, const float* in, void* out_T, int G,
 }
 int l4p_transpose_pad(l4p_stream s, int dtype, const void* in_T, void* out_T, int G, int R, int C, int Rp) {
     return launch_transpose_pad(dtype, in_T, out_T, G, R, C, Rp, (hipStream_t)s);
+}
+int l4p_i2t_delta(l4p_stream s, int dtype, const void* probs_T, const void* vt_T, const float* bias, void* delta_T, int N, int P, int C, int K) {
+    return launch_i2t_delta(dtype, probs_T, vt_T, bias, delta_T, N, P, C, K, (hipStream_t)s);
+}
+int l4p_t2i_probs(l4p_stream s, int dtype, const float* scores, long long ld_scores, void* probs_T, float* stats, int N, int P, int HT) {
+    return launch_t2i_probs(dtype, scores, ld_scores, probs_T, stats, N, P, HT, (hipStream_t)s);
+}
+int l4p_t2i_context(l4p_stream s, int dtype, const void* probs_T, const float* stats, const void* keys_T, void* ctx_T, int N, int P, int C,
+                    int heads, int tokens, long long Rg) {
+    return launch_t2i_context(dtype, probs_T, stats, keys_T, ctx_T, N, P, C, heads, tokens, Rg, (hipStream_t)s);
 }
 int l4p_mask_gather(l4p_stream s, const float* partial, float* masks, int N, int T, int h, int w, int chunks_per_tap) {
     return launch_mask_gather(partial, masks, N, T, h, w, chunks_per_tap, (hipStream_t)s);

@@ -41,6 +41,11 @@ int launch_split_hilo(int dtype, const float* in, void* out, int G, int R, long 
 int launch_t2i_attn_scores(int dtype, const float* scores, long long ld_scores, const void* v, void* out, int N, int P, int D, int heads,
                            hipStream_t stream);
 int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int C, int Rp, hipStream_t stream);
+int launch_i2t_delta(int dtype, const void* probs, const void* vt, const float* bias, void* delta, int N, int P, int C, int K,
+                     hipStream_t stream);
+int launch_t2i_probs(int dtype, const float* scores, long long ld_scores, void* probs, float* stats, int N, int P, int HT, hipStream_t stream);
+int launch_t2i_context(int dtype, const void* probs, const float* stats, const void* keys, void* ctx, int N, int P, int C, int heads,
+                       int tokens, long long Rg, hipStream_t stream);
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
                          int W, hipStream_t stream);
 
@@ -224,11 +229,19 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
     // Token -> image attention with the keys' projection folded into the tokens (packing.py fold_t2i; every track owns all rows of
     // its keys): Q' = q_tok x kfold^T [N][HT][C], scores = kP x Q'^T (row-grouped weights), softmax over the P keys and P.V in
     // l4p_t2i_attn_scores.  The [N * P, C/2] key projection (2 * P * C * C/2 FLOP per track, 4.06 GF) and its tensor disappear; the
-    // value projection stays (P.V contracts over the keys: folding it would need the keys transposed).
+    // value projection: see fold_v below.
     static const bool fold_t2i_env = !(getenv("L4P_TRACK_FOLD_T2I") && atoi(getenv("L4P_TRACK_FOLD_T2I")) == 0);
     const int HTk = 6 * g.sam_heads;
     const bool fold_t2i_ok = fold_t2i_env && P % 128 == 0 && HTk <= 64;
-    auto t2i_folded = [&](const void* tq, const std::string& prefix, const void* keysP, const void* tv, void* ta) {
+    // ... and the VALUE projection too (l4p_t2i_context: out = (probs x keys) Wv_h^T + bv_h): softmax to probs [N][P][HT]
+    // (l4p_t2i_probs), the context of every (token, head) against the keys WITHOUT the positional term - one read of the keys, MFMA -
+    // and the 48 context rows of each track through their head's block of W_v (row-grouped weights over head-major rows, every group
+    // writing its own column block of `ta`: o_gs).  Another 4.06 GF and a [P, C/2] tensor per track gone.  L4P_TRACK_FOLD_T2I_V=0:
+    // the projected values + l4p_t2i_attn_scores.
+    static const bool fold_v_env = !(getenv("L4P_TRACK_FOLD_T2I_V") && atoi(getenv("L4P_TRACK_FOLD_T2I_V")) == 0);
+    const bool fold_v = fold_t2i_ok && fold_v_env && HTk == 48 && Cc % 128 == 0 && (Dh / g.sam_heads) % 8 == 0 && P % 32 == 0 && P >= 96 && P <= 4096;
+    const long long RgT = (6ll * N + 127) / 128 * 128;  // rows of a head group of the context (and of `ta`, whose rows past 6 N are scratch)
+    auto t2i_folded = [&](const void* tq, const std::string& prefix, const void* keysP, const void* keysT, void* ta) {
         const long long KW = (long long)g.sam_heads * Cc;
         void* qf = c.T((long long)N * HTk + 128, Cc);  // Q' [N][HT][C] (+ slack rows under the last tile)
         c.gemm(tq, 6ll * N, Dh, Dh, prefix + ".kfold", (int)KW, false, ACT_NONE, nullptr, 0, nullptr, qf, KW);
@@ -240,7 +253,25 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
             p.out_f32 = sc, p.ldc = HTk, p.epi = EPI_DENSE;
             p.w_gr = P, p.w_gs = (long long)HTk * Cc, p.b_gs = 0;
             c.rc = launch_gemm(c.dt, 0, p, c.st);
-            if (!c.rc) c.rc = launch_t2i_attn_scores(c.dt, sc, HTk, tv, ta, N, P, Dh, g.sam_heads, c.st);
+        }
+        if (fold_v) {
+            const int hd = Dh / g.sam_heads;
+            void* pr = c.T(NP, HTk);
+            // (measured at full size, tools/probes/foldv_precision.py: keeping the context rows as [hi | lo] bf16 pairs changes nothing;
+            //  what does matter is that the softmax sums are those of the ROUNDED terms, see t2i_probs_kernel)
+            void* cx = c.T((long long)g.sam_heads * RgT, Cc);
+            float* stt = c.f32((long long)N * ((P + 255) / 256), 2 * HTk);  // per 256-key split: column maxima, sums
+            if (!c.rc && !c.dry) c.rc = launch_t2i_probs(c.dt, sc, HTk, pr, stt, N, P, HTk, c.st);
+            if (!c.rc && !c.dry) c.rc = launch_t2i_context(c.dt, pr, stt, keysT, cx, N, P, Cc, g.sam_heads, 6, RgT, c.st);
+            if (!c.rc && !c.dry) {
+                GemmParams p = c.desc(cx, (long long)g.sam_heads * RgT, Cc, Cc, prefix + ".v", hd, true, ACT_NONE, nullptr, 0, nullptr, ta, Dh);
+                p.w_gr = (int)RgT, p.w_gs = (long long)hd * Cc, p.b_gs = hd, p.o_gs = hd;
+                p.c_gr = (int)RgT, p.c_gs = 0, p.c_go = 0;
+                if (!c.rc) c.rc = launch_gemm(c.dt, 0, p, c.st);
+            }
+        } else {
+            void* tv = c.proj(keysT, NP, Cc, prefix + ".v", Dh);
+            if (!c.rc && !c.dry) c.rc = launch_t2i_attn_scores(c.dt, sc, HTk, tv, ta, N, P, Dh, g.sam_heads, c.st);
         }
     };
     for (int l = 0; l < g.sam_depth; ++l) {
@@ -266,13 +297,14 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         {
             void* tq = c.proj(qP, 6ll * N, Cc, lo + "t2i.q", Dh);
             const bool hs = half_shared && l == 0;
-            void* tv = hs ? proj_half_shared(curT, lo + "t2i.v", Dh) : c.proj(curT, (long long)Nk * P, Cc, lo + "t2i.v", Dh);
-            void* ta = c.T(6ll * N, Dh);
+            const bool folded = fold_t2i_ok && l >= 1 && !shared && !hs;
+            void* tv = folded ? nullptr : hs ? proj_half_shared(curT, lo + "t2i.v", Dh) : c.proj(curT, (long long)Nk * P, Cc, lo + "t2i.v", Dh);
+            void* ta = c.T(RgT, Dh);
             // (layer 0 keeps the projected form whatever the keys look like: where its keys are still common to all tracks, or
             //  half common, the projection of the common rows is one small GEMM - and the per-track evaluation of the same window
             //  (the equality tests of those shortcuts) stays bit-identical to it)
-            if (fold_t2i_ok && l >= 1 && !shared && !hs) {
-                t2i_folded(tq, lo + "t2i", curP, tv, ta);
+            if (folded) {
+                t2i_folded(tq, lo + "t2i", curP, curT, ta);
             } else {
                 void* tk = hs ? proj_half_shared(curP, lo + "t2i.k", Dh) : c.proj(curP, (long long)Nk * P, Cc, lo + "t2i.k", Dh);
                 c.attn(shared ? 3 : 1, tq, tk, tv, ta, N, P, Dh, g.sam_heads);
@@ -357,7 +389,11 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
                         c.rc = launch_gemm(c.dt, 0, p, c.st);
                     }
                     if (!c.rc) c.rc = launch_i2t_probs(c.dt, sc, NS, pair ? 1 : 0, cf, P, pr, HTp, NP, g.sam_heads, 6, c.st);
-                    if (!c.rc) {
+                    static const bool delta_env = !(getenv("L4P_TRACK_DELTA_KERNEL") && atoi(getenv("L4P_TRACK_DELTA_KERNEL")) == 0);
+                    if (!c.rc && delta_env && c.dt == L4P_BF16 && HTp == 64 && Cc % 128 == 0 && P % 16 == 0) {
+                        // (its own streaming kernel, bit-identical to the GEMM below: see i2t_delta_kernel)
+                        c.rc = launch_i2t_delta(c.dt, pr, vt, c.Wf(lo + "i2t.out.b"), delta, N, P, Cc, HTp, c.st);
+                    } else if (!c.rc) {
                         memset(&p, 0, sizeof(p));
                         p.A = pr, p.lda = HTp, p.W = vt, p.ldw = HTp, p.M = (int)NP, p.N = Cc, p.K = HTp;
                         p.bias = c.Wf(lo + "i2t.out.b"), p.out_T = delta, p.ldc = Cc, p.epi = EPI_DENSE;
@@ -390,11 +426,11 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
     size_t mark = c.ws.off;
     {
         void* fq = c.proj(qP, 6ll * N, Cc, "final.q", Dh);
-        void* fv = c.proj(curT, (long long)Nk * P, Cc, "final.v", Dh);
-        void* fa = c.T(6ll * N, Dh);
+        void* fa = c.T(RgT, Dh);
         if (fold_t2i_ok && Nk == N) {
-            t2i_folded(fq, "final", curP, fv, fa);
+            t2i_folded(fq, "final", curP, curT, fa);
         } else {
+            void* fv = c.proj(curT, (long long)Nk * P, Cc, "final.v", Dh);
             void* fk = c.proj(curP, (long long)Nk * P, Cc, "final.k", Dh);
             c.attn(1, fq, fk, fv, fa, N, P, Dh, g.sam_heads);
         }

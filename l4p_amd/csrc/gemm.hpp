@@ -729,6 +729,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p_in, const int wg_i
         patched = p_in;
         patched.W = (const T*)p_in.W + (long long)grp * p_in.w_gs;
         if (p_in.bias) patched.bias = p_in.bias + (long long)grp * p_in.b_gs;
+        if (p_in.o_gs) {
+            if (p_in.out_T) patched.out_T = (T*)p_in.out_T + (long long)grp * p_in.o_gs;
+            if (p_in.out_f32) patched.out_f32 = p_in.out_f32 + (long long)grp * p_in.o_gs;
+        }
         pp = &patched;
     }
     const GemmParams& p = *pp;

@@ -787,6 +787,299 @@ __global__ void transpose_pad_kernel(const T* __restrict__ in, T* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------------
+// delta = P x V' + b_out of the folded image -> token attention (bf16, k = 64): probs [N][P][64], V'^T [N][C][64] (l4p_transpose_pad),
+// delta [N][P][C].  The product is 2 MFMA k-steps per output tile; what it costs is the [N * P, C] result (369 MB per 64 tracks).
+// As a GEMM with one k-tile it ran 11 264 one-shot workgroups (load, 8 MFMAs per wave, store: 2.7 TB/s).  Here a workgroup owns
+// 128 columns of a track and half of its rows: the 128 x 64 block of V'^T lives in registers (64 VGPRs), every wave streams 16-row
+// tiles on its own - probs straight into the A fragments (2 x 16 bytes per lane, next tile requested before this one is used), 16
+// MFMAs, + bias, rounded, through a private 4 KB LDS tile into whole 256-byte row segments - no workgroup barrier anywhere.
+// Same products in the same order as the GEMM (two k-steps per accumulator): bit-identical to it.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void i2t_delta_kernel(const bf16_t* __restrict__ probs, const bf16_t* __restrict__ vt,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ delta, int P, int C,
+                                                        int rows_per_wg) {
+    constexpr int K = 64, CW = 128;
+    __shared__ __attribute__((aligned(16))) bf16_t tile[4][16 * CW];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, i16 = lane & 15;
+    const int c0 = blockIdx.x * CW, n = blockIdx.y, r0 = blockIdx.z * rows_per_wg;
+    const int rows = P - r0 < rows_per_wg ? P - r0 : rows_per_wg;
+    const int ntile = rows / 16;
+    const bf16_t* vb = vt + ((long long)n * C + c0) * K;
+    bf16x8 fb[8][2];
+    float bz[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fb[j][kk] = *(const bf16x8*)(vb + (long long)(16 * j + i16) * K + 32 * kk + 8 * g);
+        bz[j] = bias ? bias[c0 + 16 * j + i16] : 0.f;
+    }
+    const bf16_t* pa = probs + ((long long)n * P + r0) * K + (long long)i16 * K + 8 * g;
+    bf16_t* out = delta + ((long long)n * P + r0) * C + c0;
+    bf16_t* tl = tile[wave];
+    bf16x8 a0 = {}, a1 = {}, n0 = {}, n1 = {};
+    int t = wave;
+    if (t < ntile) {
+        a0 = *(const bf16x8*)(pa + (long long)t * 16 * K);
+        a1 = *(const bf16x8*)(pa + (long long)t * 16 * K + 32);
+    }
+    for (; t < ntile; t += 4) {
+        if (t + 4 < ntile) {
+            n0 = *(const bf16x8*)(pa + (long long)(t + 4) * 16 * K);
+            n1 = *(const bf16x8*)(pa + (long long)(t + 4) * 16 * K + 32);
+        }
+        f32x4 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] = mma16(a0, fb[j][0], (f32x4){0.f, 0.f, 0.f, 0.f});
+            acc[j] = mma16(a1, fb[j][1], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tl[(4 * g + e) * CW + 16 * j + i16] = (bf16_t)(acc[j][e] + bz[j]);
+        __builtin_amdgcn_wave_barrier();  // (the tile is this wave's own: LDS operations of a wave complete in order)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = q * 64 + lane, row = idx >> 4, part = idx & 15;
+            const u32x4 v = *(const u32x4*)(tl + row * CW + part * 8);
+            *(u32x4*)(out + (long long)(t * 16 + row) * C + part * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        a0 = n0;
+        a1 = n1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token -> image attention with the VALUE projection folded away as well (sam/transformer.py:168-173,223-245; round 4).
+//   out[t, head h] = sum_p prob[t,h,p] (keys[p] Wv_h^T + bv_h) = (sum_p prob[t,h,p] keys[p]) Wv_h^T + bv_h     (sum_p prob = 1)
+// so the [P, C] x [C, C/2] value projection of every track (4.06 GF, a 2.9 MB tensor per track) becomes a context
+// ctx[(t,h)] = prob[(t,h)] x keys - 48 x 2048 x 1408 per track, HBM-bound on ONE read of the keys - and a 48-row projection.
+//   t2i_probs: scores [N][P][48] (float; column t * heads + h) -> e [N][P][48] (T) = exp(score - m) with m the column maximum over
+//              the SPLIT of 256 keys the row belongs to, and stats [N][P / 256][2][48] (float): that maximum and the split's sum of e.
+//              (the softmax over all P keys is assembled by t2i_ctx: a split's terms carry exp(m_split - M) / Z.  One pass, fully
+//              coalesced - a track's [P][48] block is one contiguous run - over 8 x N workgroups; a whole-column softmax needs
+//              either three passes of N workgroups (measured 91 us at 64 tracks) or 192-byte-strided column groups (44 us))
+//   t2i_ctx:   ctx[(h * Rg + n * tokens + t)][c] = sum_splits scale * sum_{p in split} e[n][p][t * heads + h] * keys[n][p][c]
+//              (rows grouped by head, Rg rows per group: the A operand of the row-grouped-weights GEMM against Wv's head blocks)
+// ------------------------------------------------------------------------------------------------
+constexpr int T2I_SPLIT = 256;  // keys per softmax split
+template <typename T>
+__global__ __launch_bounds__(192) void t2i_probs_kernel(const float* __restrict__ s, long long ld, T* __restrict__ probs,
+                                                        float* __restrict__ stats, int P) {
+    constexpr int HT = 48, NCG = 12, NRL = 16, NR = T2I_SPLIT / NRL;
+    __shared__ __attribute__((aligned(16))) float red[NRL * HT];
+    __shared__ __attribute__((aligned(16))) float stat[HT];
+    const int sp_ = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, cg = tid % NCG, rl = tid / NCG;
+    const int p0 = sp_ * T2I_SPLIT;
+    const float* sp = s + ((long long)n * P + p0) * ld + 4 * cg;
+    f32x4 v[NR];
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int r = i * NRL + rl;
+        v[i] = p0 + r < P ? *(const f32x4*)(sp + (long long)r * ld) : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[i][e]);
+    *(f32x4*)(red + rl * HT + 4 * cg) = m;
+    __syncthreads();
+    if (tid < HT) {
+        float x = -INFINITY;
+        for (int r = 0; r < NRL; ++r) x = fmaxf(x, red[r * HT + tid]);
+        stat[tid] = x;
+    }
+    __syncthreads();
+    m = *(const f32x4*)(stat + 4 * cg);
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // (rows past P: exp(-inf) = 0.  The split's sum is the sum of the ROUNDED terms, the ones the context product adds up:
+            //  the weights then sum to one exactly, whatever the rounding did to a peaked column's few large terms)
+            v[i][e] = to_f32<T>(from_f32<T>(expf(v[i][e] - m[e])));
+            z[e] += v[i][e];
+        }
+    __syncthreads();
+    *(f32x4*)(red + rl * HT + 4 * cg) = z;
+    __syncthreads();
+    float* st = stats + ((long long)n * gridDim.x + sp_) * 2 * HT;
+    if (tid < HT) {
+        float x = 0.f;
+        for (int r = 0; r < NRL; ++r) x += red[r * HT + tid];
+        st[tid] = stat[tid];
+        st[HT + tid] = x;
+    }
+    T* pp = probs + ((long long)n * P + p0) * HT + 4 * cg;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int r = i * NRL + rl;
+        if (p0 + r < P) {
+            const float o[4] = {v[i][0], v[i][1], v[i][2], v[i][3]};
+            Vec4<T>::store(pp + (long long)r * HT, o);
+        }
+    }
+}
+// scale[split][column] = exp(m_split - M) / Z from the splits' statistics of track n (M: the column maximum over all splits,
+// Z = sum_splits z_split exp(m_split - M)); nsp <= 16
+__device__ __forceinline__ void t2i_scales(const float* __restrict__ stats, int n, int nsp, float* scale /* LDS [16][48] */) {
+    constexpr int HT = 48;
+    const int tid = threadIdx.x;
+    if (tid < HT) {
+        const float* st = stats + (long long)n * nsp * 2 * HT;
+        float M = -INFINITY;
+        for (int q = 0; q < nsp; ++q) M = fmaxf(M, st[q * 2 * HT + tid]);
+        float Z = 0.f;
+        for (int q = 0; q < nsp; ++q) Z += st[q * 2 * HT + HT + tid] * expf(st[q * 2 * HT + tid] - M);
+        const float iz = 1.f / Z;
+        for (int q = 0; q < nsp; ++q) scale[q * HT + tid] = expf(st[q * 2 * HT + tid] - M) * iz;
+    }
+    __syncthreads();
+}
+
+// bf16: MFMA form.  Workgroup = (128 columns of C, track); 4 waves x 32 columns, all HT rows.  Per 32-key step a stage of
+// keys [32][128] (8 KB) + probs [32][HT] (3 KB for HT = 48) lands by LDS-DMA (both are row-major images of global memory: the
+// probs of 32 keys are one contiguous run); both MFMA operands are k(= key)-strided in those images and are read with the
+// transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads a [4 keys][16 columns] block, lane i receives column i).
+// 4-stage ring, two stages in flight behind the one being read, counted vmcnt + one raw barrier per step.  The kernel is bound by
+// the single read of the keys (5.8 MB per track); per step a wave issues 10 LDS reads and 6 MFMAs.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ bf16x8 tr_frag(const char* lo, int hi_off) {
+    typedef __attribute__((address_space(3))) s16x4_t* lp_t;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(lo));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(lo + hi_off));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+template <int HT, int CW>
+__global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const bf16_t* __restrict__ probs, const bf16_t* __restrict__ keys,
+                                                           bf16_t* __restrict__ ctx, const float* __restrict__ stats, int P, int C, int heads,
+                                                           int tokens, long long Rg) {
+    static_assert(HT == 48, "t2i_scales");
+    constexpr int KT = 32, ST = 4, MT = HT / 16, NTW = CW / 64;  // NTW: 16-column tiles per wave
+    constexpr int SPK = T2I_SPLIT / KT;                          // key steps per softmax split
+    constexpr int KB = KT * CW * 2, PB = KT * HT * 2, SB = KB + PB;
+    constexpr int KP = KB / 4096;  // 1 KB pieces of the key stage per wave
+    constexpr int PW = PB / 1024;  // waves that carry a 1 KB piece of the probs stage (the others repeat the last piece)
+    constexpr int CPR = CW / 8;    // 16-byte chunks per key row
+    static_assert(HT % 16 == 0 && PB % 1024 == 0 && PW >= 1 && PW <= 4 && (CW == 64 || CW == 128), "stages in whole 1 KB pieces");
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float scale[16 * HT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c0 = blockIdx.x * CW, n = blockIdx.y;
+    const char* kb = (const char*)(keys + (long long)n * P * C + c0);
+    const char* pb = (const char*)(probs + (long long)n * P * HT);
+    const int ns = P / KT;
+    auto issue = [&](int s) {
+        char* dst = smem + (s & (ST - 1)) * SB;
+        const long long p0 = (long long)s * KT;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            const int q = wave * 64 + i * 256 + lane;  // 16-byte chunk of the [32][CW] tile: row q / CPR, part q % CPR
+            const char* src = kb + (p0 + q / CPR) * C * 2 + (q % CPR) * 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (wave * 64 + i * 256) * 16), 16, 0, 0);
+        }
+        const int pw = wave < PW ? wave : PW - 1;
+        __builtin_amdgcn_global_load_lds((gptr_t)(pb + p0 * HT * 2 + (pw * 64 + lane) * 16), (lptr_t)(dst + KB + pw * 1024), 16, 0, 0);
+    };
+    const int g = lane >> 4, i16 = lane & 15;
+    const int a_off = KB + ((8 * g + (i16 >> 2)) * HT + 4 * (i16 & 3)) * 2;
+    const int b_off = ((8 * g + (i16 >> 2)) * CW + wave * (16 * NTW) + 4 * (i16 & 3)) * 2;
+    f32x4 acc[MT][NTW], tot[MT][NTW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[m][j] = tot[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    issue(0);
+    issue(1);
+    issue(2);
+    t2i_scales(stats, n, (P + T2I_SPLIT - 1) / T2I_SPLIT, scale);
+    for (int s = 0; s < ns; ++s) {
+        const int ahead = ns - 1 - s < 2 ? ns - 1 - s : 2;
+        if (ahead == 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (KP + 1)) : "memory");
+        else if (ahead == 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KP + 1) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 3 < ns) issue(s + 3);
+        const char* base = smem + (s & (ST - 1)) * SB;
+        bf16x8 fa[MT], fb[NTW];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) fa[m] = tr_frag(base + a_off + m * 32, 4 * HT * 2);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) fb[j] = tr_frag(base + b_off + j * 32, 4 * CW * 2);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[m][j] = mma16(fa[m], fb[j], acc[m][j]);
+        if ((s % SPK) == SPK - 1 || s == ns - 1) {  // end of a softmax split: its sum joins the total with the split's weight
+            const float* sc = scale + (s / SPK) * HT + 4 * g;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x4 w = *(const f32x4*)(sc + m * 16);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tot[m][j][e] += w[e] * acc[m][j][e];
+                    acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tp = m * 16 + 4 * g + e;  // score column t * heads + h
+                const int t = tp / heads, h = tp - t * heads;
+                if (t < tokens)
+                    ctx[((long long)h * Rg + (long long)n * tokens + t) * C + c0 + wave * (16 * NTW) + j * 16 + i16] = (bf16_t)tot[m][j][e];
+            }
+}
+// any dtype (the f32 engine): one thread per column, the HT running sums in registers, probs rows read as wave-uniform values
+template <typename T, int HT>
+__global__ __launch_bounds__(256) void t2i_ctx_kernel(const T* __restrict__ probs, const T* __restrict__ keys, T* __restrict__ ctx,
+                                                      const float* __restrict__ stats, int P, int C, int heads, int tokens, long long Rg) {
+    __shared__ float scale[16 * HT];
+    const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    t2i_scales(stats, n, (P + T2I_SPLIT - 1) / T2I_SPLIT, scale);
+    if (c >= C) return;
+    float acc[HT], tot[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) acc[t] = tot[t] = 0.f;
+    const T* kp = keys + (long long)n * P * C + c;
+    const T* pp = probs + (long long)n * P * HT;
+    for (int p = 0; p < P; ++p) {
+        const float kv = to_f32<T>(kp[(long long)p * C]);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) acc[t] += to_f32<T>(pp[(long long)p * HT + t]) * kv;
+        if ((p % T2I_SPLIT) == T2I_SPLIT - 1 || p == P - 1) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+                tot[t] += scale[(p / T2I_SPLIT) * HT + t] * acc[t];
+                acc[t] = 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int tp = 0; tp < HT; ++tp) {
+        const int t = tp / heads, h = tp - t * heads;
+        if (t < tokens) ctx[((long long)h * Rg + (long long)n * tokens + t) * C + c] = from_f32<T>(tot[tp]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 #define GRID1D(total, cap) ((int)(((total) + 255) / 256 < (cap) ? ((total) + 255) / 256 : (cap)))
@@ -865,6 +1158,59 @@ int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int
     return 0;
 }
 
+int launch_i2t_delta(int dtype, const void* probs, const void* vt, const float* bias, void* delta, int N, int P, int C, int K,
+                     hipStream_t stream) {
+    if (dtype != L4P_BF16 || K != 64 || C % 128 || P % 16 || N < 1) {
+        l4p_set_error("i2t_delta: bf16, k = 64, C %% 128 == 0, P %% 16 == 0 (other shapes: the row-grouped-weights GEMM)");
+        return L4P_E_INVALID;
+    }
+    // (a batched GEMM - profiled in the GEMM class under the tag of the launch it replaces, so the executed-shapes check sees it)
+    ProfScope prof(PROF_GEMM, stream, "M%lld N%d K%d epi0 act0 delta t16x128 wgrp", (long long)N * P, C, K);
+    const int rs = P % 128 == 0 ? 2 : 1;
+    hipLaunchKernelGGL(i2t_delta_kernel, dim3(C / 128, N, rs), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)vt, bias,
+                       (bf16_t*)delta, P, C, P / rs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_t2i_probs(int dtype, const float* scores, long long ld_scores, void* probs, float* stats, int N, int P, int HT, hipStream_t stream) {
+    if (N < 1 || P < 1 || P > 16 * T2I_SPLIT || HT != 48 || ld_scores < HT || ld_scores % 4) {
+        l4p_set_error("t2i_probs: HT == 48, P <= 4096, score row stride >= HT and a multiple of 4");
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_TRACK, stream, "t2i_probs");
+    const dim3 grid((P + T2I_SPLIT - 1) / T2I_SPLIT, N);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(t2i_probs_kernel<bf16_t>, grid, dim3(192), 0, stream, scores, ld_scores, (bf16_t*)probs, stats, P);
+    else
+        hipLaunchKernelGGL(t2i_probs_kernel<float>, grid, dim3(192), 0, stream, scores, ld_scores, (float*)probs, stats, P);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_t2i_context(int dtype, const void* probs, const float* stats, const void* keys, void* ctx, int N, int P, int C, int heads,
+                       int tokens, long long Rg, hipStream_t stream) {
+    if (N < 1 || heads * tokens != 48 || C % 64 || P % 32 || P < 96 || P > 16 * T2I_SPLIT || Rg < (long long)N * tokens) {
+        l4p_set_error("t2i_context: heads * tokens == 48, C %% 64 == 0, P %% 32 == 0, 96 <= P <= 4096, Rg >= N * tokens");
+        return L4P_E_INVALID;
+    }
+    // (a batched GEMM: N x [HT x P] x [P x C]; profiled in the GEMM class so that the FLOP model's executed-shapes check sees it)
+    ProfScope prof(PROF_GEMM, stream, "M%d N%d K%d epi0 act0 ctx t48x%d", N * heads * tokens, C, P, C % 128 ? 64 : 128);
+    if (dtype == L4P_BF16) {
+        if (C % 128 == 0) {
+            constexpr int lds = 4 * (32 * 128 * 2 + 32 * 48 * 2);
+            hipLaunchKernelGGL((t2i_ctx_mfma_kernel<48, 128>), dim3(C / 128, N), dim3(256), lds, stream, (const bf16_t*)probs,
+                               (const bf16_t*)keys, (bf16_t*)ctx, stats, P, C, heads, tokens, Rg);
+        } else {
+            constexpr int lds = 4 * (32 * 64 * 2 + 32 * 48 * 2);
+            hipLaunchKernelGGL((t2i_ctx_mfma_kernel<48, 64>), dim3(C / 64, N), dim3(256), lds, stream, (const bf16_t*)probs,
+                               (const bf16_t*)keys, (bf16_t*)ctx, stats, P, C, heads, tokens, Rg);
+        }
+    } else {
+        hipLaunchKernelGGL((t2i_ctx_kernel<float, 48>), dim3((C + 255) / 256, N), dim3(256), 0, stream, (const float*)probs,
+                           (const float*)keys, (float*)ctx, stats, P, C, heads, tokens, Rg);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,

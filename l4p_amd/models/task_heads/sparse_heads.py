@@ -24,7 +24,7 @@ from ...ops import _p, _stream
 def _gemm(a: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, n: int, *, bias=None, act=ACT_NONE, res1=None,
           out_f32: Optional[torch.Tensor] = None, out_T: Optional[torch.Tensor] = None, ldc: Optional[int] = None,
           a_map=None, c_map=None, a_off: int = 0, f32_off: int = 0, res_mod: int = 0, wgroup=None,
-          ldw: Optional[int] = None) -> None:
+          ldw: Optional[int] = None, ogroup: int = 0) -> None:
     """Raw l4p_gemm call with explicit strides / row maps (see include/l4p_hip.h)."""
     d = GemmDesc()
     es = a.element_size()
@@ -44,6 +44,7 @@ def _gemm(a: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, n: int, *,
     if wgroup is not None:  # row-grouped weights: (rows per group, W elements between groups, bias elements between groups)
         d.w_gr, d.w_gs, d.b_gs = wgroup
         d.ldw = K if ldw is None else ldw
+        d.o_gs = ogroup  # output elements between groups
     _lib.check(_lib.load().l4p_gemm(_stream(), ops.code_of(a.dtype), C.byref(d)), "l4p_gemm")
 
 
@@ -190,15 +191,33 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         HTk = 6 * cfg.sam_heads
         fold_t2i_ok = os.environ.get("L4P_TRACK_FOLD_T2I", "1") != "0" and P % 128 == 0 and HTk <= 64
 
-        def t2i_folded(tq: torch.Tensor, prefix: str, keysP: torch.Tensor, tv: torch.Tensor) -> torch.Tensor:
+        # ... and the value projection (l4p_t2i_context): out = (probs x keys) Wv_h^T + bv_h - probs [N][P][HT], the context of every
+        # (token, head) against the keys without the positional term, then each head's 6 N context rows through its block of W_v
+        fold_v = (fold_t2i_ok and os.environ.get("L4P_TRACK_FOLD_T2I_V", "1") != "0" and HTk == 48 and Cc % 128 == 0 and (Dh // cfg.sam_heads) % 8 == 0 and P % 32 == 0
+                  and 96 <= P <= 4096)
+        RgT = (6 * N + 127) // 128 * 128
+
+        def t2i_folded(tq: torch.Tensor, prefix: str, keysP: torch.Tensor, keysT: torch.Tensor) -> torch.Tensor:
             KW = cfg.sam_heads * Cc
             qf = torch.empty((N * HTk + 128, Cc), dtype=td, device=dev)  # Q' [N][HT][C] (+ slack rows under the last tile)
             _gemm(tq, 6 * N, Dh, Dh, self._w(prefix + ".kfold.w"), KW, out_T=qf, ldc=KW)
             sc = torch.empty((N * P, HTk), **f32)
             _gemm(keysP, N * P, Cc, Cc, qf, HTk, out_f32=sc, ldc=HTk, wgroup=(P, HTk * Cc, 0), ldw=Cc)
-            ta = torch.empty((6 * N, Dh), dtype=td, device=dev)
-            _lib.check(lib.l4p_t2i_attn_scores(_stream(), dt, _p(sc), HTk, _p(tv), _p(ta), N, P, Dh, cfg.sam_heads),
-                       "l4p_t2i_attn_scores")
+            ta = torch.empty((RgT, Dh), dtype=td, device=dev)  # (rows past 6 N: scratch of the head groups' padding rows)
+            if fold_v:
+                hd = Dh // cfg.sam_heads
+                pr = torch.empty((N * P, HTk), dtype=td, device=dev)
+                cx = torch.empty((cfg.sam_heads * RgT, Cc), dtype=td, device=dev)
+                stt = torch.empty((N * ((P + 255) // 256), 2 * HTk), **f32)  # per 256-key split: column maxima, sums
+                _lib.check(lib.l4p_t2i_probs(_stream(), dt, _p(sc), HTk, _p(pr), _p(stt), N, P, HTk), "l4p_t2i_probs")
+                _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(stt), _p(keysT), _p(cx), N, P, Cc, cfg.sam_heads, 6, RgT),
+                           "l4p_t2i_context")
+                _gemm(cx, cfg.sam_heads * RgT, Cc, Cc, self._w(prefix + ".v.w"), hd, bias=self._w(prefix + ".v.b"), out_T=ta, ldc=Dh,
+                      wgroup=(RgT, hd * Cc, hd), c_map=(RgT, 0, 0), ogroup=hd)
+            else:
+                tv = self._proj(keysT, prefix + ".v", Dh)
+                _lib.check(lib.l4p_t2i_attn_scores(_stream(), dt, _p(sc), HTk, _p(tv), _p(ta), N, P, Dh, cfg.sam_heads),
+                           "l4p_t2i_attn_scores")
             return ta
 
         q32: Optional[torch.Tensor] = None
@@ -217,14 +236,13 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             # --- tokens -> image (transformer.py:168-173) ---
             tq = self._proj(qP, lo + "t2i.q", Dh)
             hs = half_shared and l == 0
-            tv = proj_half_shared(kT, lo + "t2i.v", Dh) if hs else self._proj(kT, lo + "t2i.v", Dh)
             if fold_t2i_ok and l >= 1 and not shared and not hs:  # (layer 0 keeps the projected form: see csrc/api_trackwin.hip)
-                ta = t2i_folded(tq, lo + "t2i", kP, tv)
+                ta = t2i_folded(tq, lo + "t2i", kP, kT)
             else:
+                tv = proj_half_shared(kT, lo + "t2i.v", Dh) if hs else self._proj(kT, lo + "t2i.v", Dh)
                 tk = proj_half_shared(kP, lo + "t2i.k", Dh) if hs else self._proj(kP, lo + "t2i.k", Dh)
                 ta = self._attn(3 if shared else 1, tq, tk, tv, N, P, Dh)
-                del tk
-            del tv
+                del tk, tv
             _gemm(ta, 6 * N, Dh, Dh, self._w(lo + "t2i.out.w"), Cc, bias=self._w(lo + "t2i.out.b"), res1=q32, out_f32=x32)
             q32, qT, qP = self._ln(x32, lo + "norm2", tok32, 6 * N, out32=torch.empty_like(x32))
             # --- MLP (transformer.py:175-178), ReLU ---
@@ -280,7 +298,13 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 pr = torch.empty((N * P, HTp), dtype=td, device=dev)
                 _lib.check(lib.l4p_i2t_probs(_stream(), dt, _p(sc), NS, 1 if pair else 0, _p(cf), P, _p(pr), HTp, N * P, heads, 6),
                            "l4p_i2t_probs")
-                _gemm(pr, N * P, HTp, HTp, vt, Cc, bias=self._w(lo + "i2t.out.b"), out_T=delta, ldc=Cc, wgroup=(P, Cc * HTp, 0), ldw=HTp)
+                if (os.environ.get("L4P_TRACK_DELTA_KERNEL", "1") != "0" and dt == L4P_BF16 and HTp == 64 and Cc % 128 == 0
+                        and P % 16 == 0):  # its own streaming kernel, bit-identical to the GEMM (csrc/track.hip i2t_delta_kernel)
+                    _lib.check(lib.l4p_i2t_delta(_stream(), dt, _p(pr), _p(vt), _p(self._w(lo + "i2t.out.b")), _p(delta), N, P, Cc, HTp),
+                               "l4p_i2t_delta")
+                else:
+                    _gemm(pr, N * P, HTp, HTp, vt, Cc, bias=self._w(lo + "i2t.out.b"), out_T=delta, ldc=Cc, wgroup=(P, Cc * HTp, 0),
+                          ldw=HTp)
                 del kf, vf, cf, vt, sc, pr
             else:
                 iq = proj_half_shared(kP, lo + "i2t.q", Dh) if hs else self._proj(kP, lo + "i2t.q", Dh)
@@ -304,14 +328,14 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             del delta, k_res
         # --- final tokens -> image attention (transformer.py:103-109) ---
         fq = self._proj(qP, "final.q", Dh)
-        fv = self._proj(kT, "final.v", Dh)
         if fold_t2i_ok and Nk == N:
-            fa = t2i_folded(fq, "final", kP, fv)
+            fa = t2i_folded(fq, "final", kP, kT)
         else:
+            fv = self._proj(kT, "final.v", Dh)
             fk = self._proj(kP, "final.k", Dh)
             fa = self._attn(1, fq, fk, fv, N, P, Dh)
-            del fk
-        del fv, kP
+            del fk, fv
+        del kP
         _gemm(fa, 6 * N, Dh, Dh, self._w("final.out.w"), Cc, bias=self._w("final.out.b"), res1=q32, out_f32=x32)
         _, hsT, _ = self._ln(x32, "norm_final", None, 0, want_T2=False)
 

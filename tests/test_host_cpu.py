@@ -128,7 +128,14 @@ def test_bench_algorithmic_flops_match_survey():
     fl = bench.algorithmic_flops(cfg, ["track_2d"], 1)  # the tracker needs all 40 encoder blocks
     assert fl["attention"] == 944_892_805_120  # 4 * 2048^2 * 88 * 16 * 40
     # per query and window: SURVEY's 73.81 GF minus the history projection (2*S*D*D) that a last / only window does not need
-    tracker = 73.81e9 - 2.0 * S * D * D
+    # ... and minus what the folded cross attentions of the tracker no longer execute (round 4): per layer the two
+    # image-side projections of the image -> token attention and its 6-token products become two [S, D] x [D, 48] products and
+    # two block-diagonal token-side ones; the key AND the value projection of the token -> image attention of layer 1 and of the
+    # final one become a [S, D] x [D, 48] product and a token-side one each
+    H2, HT, L = D // 2, 6 * cfg.sam_heads, cfg.sam_depth
+    i2t = (2 * 2.0 * S * D * H2 + 4.0 * S * 6 * H2) - (2 * 2.0 * S * D * HT + 2 * 2.0 * 6 * H2 * D)
+    t2i = (2.0 * S * D * H2 + 2.0 * S * 6 * H2) - (2.0 * S * D * HT + 2.0 * 6 * H2 * D)
+    tracker = 73.81e9 - 2.0 * S * D * D - L * i2t - 2 * L * t2i
     assert abs((fl["gemm"] - tracker) + fl["attention"] - 5_085_581_017_088) <= 1e-6 * 5_085_581_017_088
     dense = bench.algorithmic_flops(cfg, ["depth"], 0)
     enc36 = 2.0 * S * (3 * 2 * 14 * 14) * D + 36 * 2.0 * S * (D * 3 * D + D * D + 2 * D * cfg.mlp_hidden)

@@ -445,6 +445,124 @@ def test_row_grouped_weights_gemm_and_folded_i2t_kernels(dev, precision):
     assert float((delta.float().cpu().view(N, P, Cc) - dref).abs().max()) <= tol * float(dref.abs().max())
 
 
+@pytest.mark.parametrize("P,Cc", [(256, 1408), (272, 256)])
+def test_i2t_delta_kernel_equals_grouped_gemm(dev, P, Cc):
+    """l4p_i2t_delta (delta = P x V' + b of the folded image -> token attention as a streaming kernel, bf16) against the
+    row-grouped-weights GEMM it replaces on the same operands: bit-identical (same products, same two k-steps per accumulator),
+    with whole (P % 128 == 0: two row halves per workgroup column) and ragged row counts."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+    from l4p_amd._lib import EPI_DENSE, L4P_BF16, GemmDesc
+    from l4p_amd.ops import _p, _stream
+
+    lib = _lib.load()
+    N, HT, HTp = 3, 48, 64
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    pr = torch.zeros(N * P, HTp, dtype=torch.bfloat16, device="cuda")
+    pr[:, :HT] = torch.softmax(r(N * P, 6, 8), dim=1).reshape(N * P, HT).to(torch.bfloat16).cuda()
+    vt = torch.zeros(N * Cc + 128, HTp, dtype=torch.bfloat16, device="cuda")
+    vt[:N * Cc, :HT] = (0.3 * r(N * Cc, HT)).to(torch.bfloat16).cuda()
+    bias = r(Cc).cuda()
+    want = torch.empty(N * P, Cc, dtype=torch.bfloat16, device="cuda")
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = _p(pr), HTp, _p(vt), HTp
+    d.M, d.N, d.K = N * P, Cc, HTp
+    d.bias, d.out_T, d.ldc, d.epi = _p(bias), _p(want), Cc, EPI_DENSE
+    d.w_gr, d.w_gs, d.b_gs = P, Cc * HTp, 0
+    if P % 128 == 0:
+        _lib.check(lib.l4p_gemm(_stream(), L4P_BF16, C.byref(d)), "l4p_gemm(grouped W, K = 64)")
+    else:  # (the GEMM wants row groups of whole 128-row tiles: one launch per track)
+        for n in range(N):
+            d.A, d.W, d.out_T, d.M, d.w_gr = pr[n * P:].data_ptr(), vt[n * Cc:].data_ptr(), want[n * P:].data_ptr(), P, 0
+            _lib.check(lib.l4p_gemm(_stream(), L4P_BF16, C.byref(d)), "l4p_gemm")
+    got = torch.full((N * P + 16, Cc), 7.0, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.l4p_i2t_delta(_stream(), L4P_BF16, _p(pr), _p(vt), _p(bias), _p(got), N, P, Cc, HTp), "l4p_i2t_delta")
+    torch.cuda.synchronize()
+    assert torch.equal(got[:N * P], want)
+    assert bool((got[N * P:] == 7.0).all())
+    ref = torch.einsum("npk,nck->npc", pr.float().cpu().view(N, P, HTp), vt[:N * Cc].float().cpu().view(N, Cc, HTp)) + bias.cpu()
+    assert float((got[:N * P].float().cpu().view(N, P, Cc) - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+@pytest.mark.parametrize("Cc", [1408, 704, 256])
+def test_folded_t2i_value_kernels(dev, precision, Cc):
+    """The token -> image attention with the VALUE projection folded away (l4p_t2i_probs, l4p_t2i_context, the per-head projection as a
+    row-grouped-weights GEMM whose groups write their own column blocks: l4p_gemm_desc.o_gs) against plain torch on the same rounded
+    operands: softmax over the keys, P.V of the PROJECTED values (sam/transformer.py:223-245).  1408 and 256 columns take the 128-wide MFMA
+    form, 704 (the mini geometry; its head dim 44 keeps the tracker itself on the projected values) the 64-wide one; the f32 engine
+    its plain kernel.  Operands are random and asymmetric, the
+    (token, head) -> row mapping is checked through the final [6 N][C/2] layout the out-projection reads."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+    from l4p_amd._lib import EPI_DENSE, L4P_BF16, L4P_F32, GemmDesc
+    from l4p_amd.ops import _p, _stream
+
+    lib = _lib.load()
+    dt = L4P_BF16 if precision == "bf16" else L4P_F32
+    td = torch.bfloat16 if precision == "bf16" else torch.float32
+    N, P, heads, tokens = 5, 608, 8, 6   # (three softmax splits of 256 keys, the last one partial)
+    HT, Dh = heads * tokens, Cc // 2
+    hd = Dh // heads
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    sc = (3.0 * r(N * P, HT)).cuda()
+    keys = r(N * P, Cc).to(td).cuda()
+    wv = torch.zeros(Dh + 128, Cc, dtype=td, device="cuda")
+    wv[:Dh] = (r(Dh, Cc) * Cc ** -0.5).to(td).cuda()
+    bv = r(Dh).cuda()
+    # reference
+    pref = torch.softmax(sc.cpu().view(N, P, HT), dim=1)                                   # over the keys
+    vref = keys.float().cpu() @ wv[:Dh].float().cpu().t() + bv.cpu()                      # [N*P][Dh]
+    oref = torch.einsum("npth,nphd->nthd", pref.view(N, P, tokens, heads), vref.view(N, P, heads, hd)).reshape(N * tokens, Dh)
+    # engine: e = exp(score - split maximum) per split of 256 keys + the splits' statistics; softmax = e * exp(m_split - M) / Z
+    nsp = (P + 255) // 256
+    pr = torch.empty(N * P, HT, dtype=td, device="cuda")
+    st = torch.empty(N * nsp, 2 * HT, device="cuda")
+    _lib.check(lib.l4p_t2i_probs(_stream(), dt, _p(sc), HT, _p(pr), _p(st), N, P, HT), "l4p_t2i_probs")
+    torch.cuda.synchronize()
+    stc = st.cpu().view(N, nsp, 2, HT)
+    scv = sc.cpu().view(N, P, HT)
+    split_of = torch.arange(P) // 256
+    for q in range(nsp):
+        rows = scv[:, split_of == q]
+        assert torch.equal(stc[:, q, 0], rows.max(dim=1).values)
+        assert float((stc[:, q, 1] - torch.exp(rows - stc[:, q, 0][:, None]).to(td).float().sum(dim=1)).abs().max()) <= (
+            5e-3 if precision == "bf16" else 1e-5) * float(stc[:, q, 1].max())  # (sums of the terms as rounded to the engine dtype)
+    M = stc[:, :, 0].max(dim=1).values                                                     # [N][HT]
+    Z = (stc[:, :, 1] * torch.exp(stc[:, :, 0] - M[:, None])).sum(dim=1)
+    scale = torch.exp(stc[:, :, 0] - M[:, None]) / Z[:, None]                              # [N][nsp][HT]
+    pnorm = pr.float().cpu().view(N, P, HT) * scale[:, split_of]                           # the softmax the context kernel applies
+    assert float((pnorm - pref).abs().max()) <= (4e-3 if precision == "bf16" else 5e-6) * float(pref.max())
+    Rg = (tokens * N + 127) // 128 * 128
+    cx = torch.full((heads * Rg, Cc), float("nan"), dtype=td, device="cuda")
+    _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(st), _p(keys), _p(cx), N, P, Cc, heads, tokens, Rg), "l4p_t2i_context")
+    torch.cuda.synchronize()
+    cref = torch.einsum("npth,npc->htnc", pnorm.view(N, P, tokens, heads), keys.float().cpu().view(N, P, Cc))  # [h][t][n][c]
+    cxc = cx.float().cpu().view(heads, Rg, Cc)
+    got = cxc[:, :N * tokens].view(heads, N, tokens, Cc).permute(0, 2, 1, 3)
+    tol = 6e-3 if precision == "bf16" else 1e-4    # (one bf16 rounding of the f32 sum; f32: summation order, relative to >= 1 % of the maximum)
+    assert float(((got - cref).abs() / cref.abs().clamp_min(1e-2 * float(cref.abs().max()))).max()) <= tol
+    assert bool(torch.isnan(cxc[:, N * tokens:]).all())                                     # rows past N * tokens untouched
+    if hd % 8:
+        return  # (the grouped projection writes 8-column vectors: head dims of whole vectors only)
+    cx = torch.nan_to_num(cx, nan=0.0)
+    ta = torch.empty(Rg, Dh, dtype=td, device="cuda")
+    d = GemmDesc()
+    d.A, d.lda, d.W, d.ldw = _p(cx), Cc, _p(wv), Cc
+    d.M, d.N, d.K = heads * Rg, hd, Cc
+    d.bias, d.out_T, d.ldc, d.epi = _p(bv), _p(ta), Dh, EPI_DENSE
+    d.w_gr, d.w_gs, d.b_gs, d.o_gs = Rg, hd * Cc, hd, hd
+    d.c_gr, d.c_gs, d.c_go = Rg, 0, 0
+    _lib.check(lib.l4p_gemm(_stream(), dt, C.byref(d)), "l4p_gemm(head groups, o_gs)")
+    torch.cuda.synchronize()
+    err = float((ta[:N * tokens].float().cpu() - oref).abs().max()) / float(oref.abs().max())
+    assert err <= (2e-2 if precision == "bf16" else 1e-5), err
+
+
 def test_folded_i2t_equals_projected_form(dev, mini, monkeypatch):
     """The tracker with the image-side projections of its cross attentions folded into the token side (default: i2t.q / i2t.out of
     the image -> token attention, t2i.k / final.k of the token -> image attentions) against the form that projects every image
@@ -468,7 +586,7 @@ def test_folded_i2t_equals_projected_form(dev, mini, monkeypatch):
             monkeypatch.setenv("L4P_TRACK_FOLD_T2I", "1")
             a = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
             monkeypatch.setenv("L4P_TRACK_FOLD_I2T", "0")
-            monkeypatch.setenv("L4P_TRACK_FOLD_T2I", "0")
+            monkeypatch.setenv("L4P_TRACK_FOLD_T2I", "0")  # (also switches the value fold off: it rides on the folded scores)
             b = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
             monkeypatch.delenv("L4P_TRACK_PYTHON")
             monkeypatch.setenv("L4P_TRACK_FOLD_I2T", "1")

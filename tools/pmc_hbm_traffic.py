@@ -71,10 +71,20 @@ def main():
             f.write(f"| {c} | {n} | {rd / n / 1e6:.1f} | {wt / n / 1e6:.1f} |\n")
     js = {"per_class_bytes_per_launch": {c: {"launches": n, "hbm_read": rd / n, "hbm_write": wt / n, "hbm_total": (rd + wt) / n}
                                          for c, (n, rd, wt) in cls.items()},
-          "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate passes, bench.py c3 2 steps"}
+          "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate passes, bench.py c3 2 steps",
+          "kernel_tree": _kernel_tree()}  # bench.py attaches these figures only to the kernels they were measured on
     with open(out + ".json", "w") as f:
         json.dump(js, f, indent=1)
     print(open(out + ".md").read()[-1200:])
+
+
+def _kernel_tree():
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from l4p_amd._lib import kernel_tree_hash
+
+    return kernel_tree_hash()
 
 
 if __name__ == "__main__":
