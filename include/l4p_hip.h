@@ -44,6 +44,11 @@ const char* l4p_last_error(void);
 int l4p_abi_version(void); /* 4: l4p_gemm_desc.o_gs, l4p_i2t_delta, l4p_t2i_probs, l4p_t2i_context; 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs,
                               * l4p_t2i_attn_scores, l4p_split_hilo, l4p_transpose_pad */
 
+/* A HIP stream restricted to CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask) / its release.  Plumbing for the sharded
+ * long-video path (l4p_amd/parallel.py): the tracker recursion's small dependent kernels on a slice of the chip of their own. */
+int l4p_stream_create_cu_mask(int first_cu, int n_cus, l4p_stream* out);
+int l4p_stream_destroy(l4p_stream stream);
+
 /* Optional per-kernel-class timing: when enabled every kernel launch is bracketed by a HIP event pair
  * recorded on the launch stream (bench.py's live roofline numbers).  Classes: gemm, conv3d, attention,
  * layernorm, elementwise, track, preprocess.  l4p_prof_read sums the pair durations of one class since the last

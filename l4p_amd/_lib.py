@@ -85,6 +85,8 @@ _VP, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 SIGNATURES = {
     "l4p_last_error": (C.c_char_p, []),
     "l4p_abi_version": (_I, []),
+    "l4p_stream_create_cu_mask": (_I, [_I, _I, C.POINTER(C.c_void_p)]),
+    "l4p_stream_destroy": (_I, [_VP]),
     "l4p_prof_enable": (_I, [_I]),
     "l4p_prof_reset": (_I, []),
     "l4p_prof_num_classes": (_I, []),

@@ -31,6 +31,25 @@ extern "C" {
 const char* l4p_last_error(void) { return g_err; }
 int l4p_abi_version(void) { return 4; }
 
+// A HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (hipExtStreamCreateWithCUMask): the sharded long-video path
+// gives the tracker's latency-bound kernel chain a slice of the chip of its own, beside the chip-filling decoders on the rest.
+int l4p_stream_create_cu_mask(int first_cu, int n_cus, l4p_stream* out) {
+    if (!out || first_cu < 0 || n_cus < 1 || first_cu + n_cus > 1024) {
+        l4p_set_error("l4p_stream_create_cu_mask: bad CU range [%d, %d)", first_cu, first_cu + n_cus);
+        return L4P_E_INVALID;
+    }
+    uint32_t mask[32] = {0};
+    for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t s = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)((first_cu + n_cus + 31) / 32), mask));
+    *out = (l4p_stream)s;
+    return 0;
+}
+int l4p_stream_destroy(l4p_stream s) {
+    HIP_TRY(hipStreamDestroy((hipStream_t)s));
+    return 0;
+}
+
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d) {
     if (!d) {
         l4p_set_error("l4p_gemm: null descriptor");

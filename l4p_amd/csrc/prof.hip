@@ -19,7 +19,7 @@ struct Pair {
 std::mutex g_mu;
 std::vector<Pair> g_pairs;      // recorded this session
 std::vector<hipEvent_t> g_pool; // reusable events
-const char* kNames[PROF_NUM] = {"gemm", "conv3d", "attention", "layernorm", "elementwise", "track", "preprocess"};
+const char* kNames[PROF_NUM] = {"gemm", "conv3d", "attention", "layernorm", "elementwise", "track", "preprocess", "gemm_small"};
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) {

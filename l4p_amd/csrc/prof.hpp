@@ -7,13 +7,16 @@
 #include <cstdio>
 
 enum ProfClass {
-    PROF_GEMM = 0,      // gemm_kernel<..., MODE 0>: linears, 1x1x1 convs, ConvTranspose-as-GEMM
+    PROF_GEMM = 0,      // gemm8p / gemm_kernel<..., MODE 0>: linears, 1x1x1 convs, ConvTranspose-as-GEMM (>= 1024 rows, one weight matrix)
     PROF_CONV3D,        // gemm_kernel<..., MODE 1>: implicit-GEMM 3x3x3 conv
     PROF_ATTENTION,     // attn_kernel
     PROF_LAYERNORM,
     PROF_ELEMENTWISE,   // cast / patch gather / upsample / head_out / alignment / pose
     PROF_TRACK,         // tracker-specific small kernels
     PROF_PREP,          // clip preparation (preprocess.hip): Pillow resample passes, resize + normalise
+    PROF_GEMM_SMALL,    // dense products that are latency- or HBM-bound by construction: fewer than 1024 rows (the tracker's token-side
+                        // projections, the coarsest DPT levels) and the tracker's folded cross-attention products (row-grouped weights,
+                        // l4p_t2i_context, l4p_i2t_delta) - kept out of PROF_GEMM, whose time / FLOPs price the MFMA-bound kernels
     PROF_NUM
 };
 

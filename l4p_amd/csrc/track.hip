@@ -1164,8 +1164,8 @@ int launch_i2t_delta(int dtype, const void* probs, const void* vt, const float* 
         l4p_set_error("i2t_delta: bf16, k = 64, C %% 128 == 0, P %% 16 == 0 (other shapes: the row-grouped-weights GEMM)");
         return L4P_E_INVALID;
     }
-    // (a batched GEMM - profiled in the GEMM class under the tag of the launch it replaces, so the executed-shapes check sees it)
-    ProfScope prof(PROF_GEMM, stream, "M%lld N%d K%d epi0 act0 delta t16x128 wgrp", (long long)N * P, C, K);
+    // (a batched GEMM - profiled with the small / streaming products under the tag of the launch it replaces: the executed-shapes check sees it)
+    ProfScope prof(PROF_GEMM_SMALL, stream, "M%lld N%d K%d epi0 act0 delta t16x128 wgrp", (long long)N * P, C, K);
     const int rs = P % 128 == 0 ? 2 : 1;
     hipLaunchKernelGGL(i2t_delta_kernel, dim3(C / 128, N, rs), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)vt, bias,
                        (bf16_t*)delta, P, C, P / rs);
@@ -1192,8 +1192,8 @@ int launch_t2i_context(int dtype, const void* probs, const float* stats, const v
         l4p_set_error("t2i_context: heads * tokens == 48, C %% 64 == 0, P %% 32 == 0, 96 <= P <= 4096, Rg >= N * tokens");
         return L4P_E_INVALID;
     }
-    // (a batched GEMM: N x [HT x P] x [P x C]; profiled in the GEMM class so that the FLOP model's executed-shapes check sees it)
-    ProfScope prof(PROF_GEMM, stream, "M%d N%d K%d epi0 act0 ctx t48x%d", N * heads * tokens, C, P, C % 128 ? 64 : 128);
+    // (a batched GEMM: N x [HT x P] x [P x C]; profiled with the small / streaming products: the FLOP model's executed-shapes check sees it)
+    ProfScope prof(PROF_GEMM_SMALL, stream, "M%d N%d K%d epi0 act0 ctx t48x%d", N * heads * tokens, C, P, C % 128 ? 64 : 128);
     if (dtype == L4P_BF16) {
         if (C % 128 == 0) {
             constexpr int lds = 4 * (32 * 128 * 2 + 32 * 48 * 2);

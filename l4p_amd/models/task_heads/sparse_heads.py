@@ -518,7 +518,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                        and os.environ.get("L4P_TRACK_STREAMS", "1") != "0")
         if use_streams:
             main = torch.cuda.current_stream()
-            pool = getattr(self, "_clip_streams", None)
+            pool = getattr(self, "clip_stream_override", None)  # (the caller's streams: parallel.forward_windows_sharded, CU-masked)
+            if pool is None or len(pool) < B:
+                pool = getattr(self, "_clip_streams", None)
             if pool is None or len(pool) < B:
                 # (L4P_TRACK_PRIO=1: high-priority clip streams.  Measured, round 4, same call: c3 832 -> 654 frames/s - at 64 queries
                 #  the tracker's kernels are chip-sized themselves and pre-empt the decoders' rounds -, configs[4] 414 -> 415: off)

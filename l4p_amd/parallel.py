@@ -190,6 +190,46 @@ def local_last_features(groups: list, batch: int) -> dict:
     return local
 
 
+_MASKED_STREAMS: dict = {}
+
+
+def cu_masked_stream(device: torch.device, spec: Optional[str]):
+    """A stream of ``device`` restricted to the CUs ``"first,count"`` (l4p_stream_create_cu_mask), cached; None for an empty spec.
+    Used by the sharded long-video path to keep a slice of the chip free of the decoders' long-running workgroups: a tracker kernel
+    of a rank's query shard is small, but it can only start on a CU with free registers - and a 3x3x3-conv workgroup holds a CU's
+    whole register file for a millisecond (measured on one GPU: decoders 27 ms + tracker 49 ms side by side = 76 ms, no overlap)."""
+    if not spec or device.type != "cuda":
+        return None
+    key = (device.index, spec)
+    if key not in _MASKED_STREAMS:
+        import ctypes as C
+
+        from . import _lib
+
+        first, count = (int(x) for x in spec.split(","))
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().l4p_stream_create_cu_mask(first, count, C.byref(h)), "l4p_stream_create_cu_mask")
+        _MASKED_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=device)
+    return _MASKED_STREAMS[key]
+
+
+def decode_encoded_windows_on(stream, net, data: dict, tasks: List[str], groups: list) -> dict:
+    """decode_encoded_windows queued on ``stream`` (after everything queued on the current stream so far); the current stream waits
+    for it again before it returns (its host work is done then, its kernels are not), and the results are marked as used there."""
+    if stream is None:
+        return decode_encoded_windows(net, data, tasks, groups)
+    main = torch.cuda.current_stream()
+    stream.wait_stream(main)
+    with torch.cuda.stream(stream):
+        local = decode_encoded_windows(net, data, tasks, groups)
+    main.wait_stream(stream)
+    for d in local.values():
+        for v in d.values():
+            v.record_stream(main)
+    return local
+
+
 def decode_encoded_windows(net, data: dict, tasks: List[str], groups: list) -> dict:
     """Phase 1b (sharded): the DPT decoders of the encoded groups -> {window id: {"dec.<task>": tensor}}."""
     img_info = tuple(data.get("img_info", net.window_size))
@@ -300,7 +340,9 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
         # launches) whatever the query count - at 8 queries per rank that is all it costs - so the GPU works through the decoders
         # while the host is still feeding the tracker's stream.  The tracker's streams wait for `ready` (the gathered features),
         # not for the decoders queued behind it.
-        local = decode_encoded_windows(net, data, tasks, groups) if dense else None
+        # (L4P_C5_DEC_CUS / L4P_C5_TRK_CUS = "first,count": CU-masked streams for the decoders / the tracker, see cu_masked_stream)
+        dec_stream = cu_masked_stream(net.device, os.environ.get("L4P_C5_DEC_CUS")) if track and dense else None
+        local = decode_encoded_windows_on(dec_stream, net, data, tasks, groups) if dense else None
         del groups
         if track:
             d_trk, nq_local = shard_track_inputs(data, rank, world)
@@ -309,6 +351,8 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
                 if hasattr(trk, "join_streams"):
                     trk.defer_join = trk.own_stream = os.environ.get("L4P_TRACK_DEFER", "1") != "0"
                     trk.start_event = ready if trk.own_stream else None
+                    ts = cu_masked_stream(net.device, os.environ.get("L4P_C5_TRK_CUS")) if trk.own_stream else None
+                    trk.clip_stream_override = [ts] if ts is not None else None
                 wins_t = [DecodedWindow(net.cfg.depth, {}, g["last"]) for g in lasts]
                 trk_out = trk.forward_windowed(enc_features_bpc_2dlist=wins_t, time_strides=strides, **d_trk)
         out: dict = {}
@@ -324,6 +368,7 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
             trk.join_streams()
             trk.defer_join = trk.own_stream = False
             trk.start_event = None
+            trk.clip_stream_override = None
     if trk_out is not None:
         out.update(trk_out)
     if track and _collectives_on(world):

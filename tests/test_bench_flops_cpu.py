@@ -12,30 +12,19 @@ from l4p_amd.weights import ModelCfg
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROFILE = os.path.join(ROOT, "profiles", "r04_c3_per_shape_event_profile.txt")
-LINE = re.compile(r"^(gemm|conv3d)\s+M(\d+) N(\d+) K(\d+) epi(\d) act\d .*?\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s*$")
+LINE = re.compile(r"^(gemm|gemm_small|conv3d)\s+(M\d+ N\d+ K\d+ epi\d act\d .*?)\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s*$")
 
 
 def executed_flops():
+    """Σ 2*M*N*K over the profile's dense launches, padding removed by bench.executed_flops_of_tag (the rule bench.py itself applies
+    to the "gemm_small" class at run time); the small / streaming products count towards the model's "gemm" figure."""
     tot = {"gemm": 0.0, "conv3d": 0.0}
     for ln in open(PROFILE):
         m = LINE.match(ln.rstrip())
         if not m:
             continue
-        cls, M, N, K, epi, n = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), float(m.group(6))
-        if cls == "gemm":
-            if epi == 1:
-                N = N * 88 // 96            # QKV: head dim padded 88 -> 96 (zero weight rows)
-            if epi == 3:
-                N = N * 176 // 192          # up1 + mask product: 176 channels per tap padded to 192
-            if K == 1216:
-                K = 1176                    # patch vector 3*2*14*14 padded to a multiple of 64
-            if "wgrp" in ln and K == 64:
-                K = 48                      # folded i2t, P x V': 6 tokens x 8 heads, padded to one k-tile
-            if N == 8 * 1408 and K == 704:
-                N = 1408                    # folded i2t, token side: block-diagonal weights, head h meets head h's 1408 rows only
-            if N == 8 and K == 704:
-                N = 1                       # (the query-bias term likewise)
-        tot[cls] += 2.0 * M * N * K * n
+        cls, tag, n = m.group(1), m.group(2), float(m.group(3))
+        tot["conv3d" if cls == "conv3d" else "gemm"] += bench.executed_flops_of_tag(tag) * n
     return tot
 
 

@@ -1,5 +1,5 @@
 """Per-shape kernel time table for one bench workload (event profiler, l4p_prof_detail).
-usage: python tools/prof_detail.py [c2|c3|c3b8|c5|prep|demo] [steps]   (demo: 64 frames, 625 queries, depth+flow+mask+tracks;
+usage: python tools/prof_detail.py [c2|c3|c3b8|c5|prep|demo] [steps] [c5: queries, default 64]   (demo: 64 frames, 625 queries, depth+flow+mask+tracks;
 c3b8: all heads at batch 8, the per-GPU batch of configs[3] / of every rank of `bench.py --gpus N`)"""
 import contextlib
 import ctypes as C
@@ -53,7 +53,7 @@ def main():
         from l4p_amd.parallel import forward_windows_sharded
 
         tasks = list(bench.ALL_TASKS)
-        model, data, _ = bench.build_workload(tasks, 1, 64, dev, frames=256)
+        model, data, _ = bench.build_workload(tasks, 1, int(sys.argv[3]) if len(sys.argv) > 3 else 64, dev, frames=256)
         model.l4p_model.always_use_windowed_version = True
 
         def run():

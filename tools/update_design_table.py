@@ -32,19 +32,24 @@ rows = [("c3: all heads, B=4, 64 queries/clip", c3), ("c2: depth only, B=1", c2)
 b8 = os.path.join(P, f"{tag}_c3_batch8_bench_line.json")
 if os.path.exists(b8):
     rows.insert(1, ("c3 at batch 8 (the per-GPU batch of configs[3])", json.load(open(b8))))
-t = ("<!--R4TABLE-BEGIN-->\n| workload | frames/s | ms/step | GEMM class | conv3d class | attention | LayerNorm | elementwise | tracker kernels |\n"
-     "|---|---|---|---|---|---|---|---|---|\n")
+t = ("<!--R4TABLE-BEGIN-->\n| workload | frames/s | ms/step | GEMM class | conv3d class | attention | small / streaming products | LayerNorm | elementwise | tracker kernels |\n"
+     "|---|---|---|---|---|---|---|---|---|---|\n")
 for name, d in rows:
-    t += (f"| {name} | **{d['value']:.0f}** | {d['ms_per_step']:.1f} | {kc(d, 'gemm')} | {kc(d, 'conv3d')} | {kc(d, 'attention')} | "
+    t += (f"| {name} | **{d['value']:.0f}** | {d['ms_per_step']:.1f} | {kc(d, 'gemm')} | {kc(d, 'conv3d')} | {kc(d, 'attention')} | {kc(d, 'gemm_small')} | "
           f"{kc(d, 'layernorm', False)} | {kc(d, 'elementwise', False)} | {kc(d, 'track', False)} |\n")
-t += f"| prep: 50 decoded 480×854 frames → [3,64,224,224] | **{pr['value'] / 1000:.0f} k** | {pr['ms_per_step']:.2f} | | | | | | |\n"
+t += f"| prep: 50 decoded 480×854 frames → [3,64,224,224] | **{pr['value'] / 1000:.0f} k** | {pr['ms_per_step']:.2f} | | | | | | | |\n"
 attn = [l for l in open(os.path.join(P, f"{tag}_c3_kernel_stats.md")) if "attn_kernel" in l][0].split("|")
 avg = float(attn[4])
-ra, rg = c3["roofline_attention"], c3["roofline"]
-t += (f"\n`roofline` of the c3 line: GEMM class {rg['achieved']:.0f} TF/s = **{rg['frac']:.3f}** of 2.5 PF ({rg['launches_per_step']:.0f} launches per step, "
-      f"HIP-event-timed); `roofline_attention` {ra['achieved']:.0f} TF/s = **{ra['frac']:.3f}** ({ra['avg_launch_us']:.1f} µs per launch event-timed; "
-      f"rocprofv3 average of the same command {avg:.2f} µs = {94.49 / avg / 2.5:.3f}, `profiles/{tag}_c3_kernel_stats.md`; c5: "
-      f"{c5['roofline_attention']['frac']:.3f} at its batch of 16 windows).  CPU oracle on the same box: {c3['cpu_baseline']['value']:.2f} frames/s on "
+rd = c3["roofline"]
+ra = c3.get("roofline_attention", rd)
+rg = c3.get("roofline_gemm", rd)
+rc = c3.get("roofline_conv3d", rd)
+t += (f"\nThe c3 line: `roofline` = the class with the most time, {rd['kernel'].split(' ')[0]}: {rd['achieved']:.0f} TF/s = **{rd['frac']:.3f}** of 2.5 PF; "
+      f"GEMM class (`roofline_gemm`) {rg['achieved']:.0f} TF/s = **{rg['frac']:.3f}** ({rg['launches_per_step']:.0f} launches per step, HIP-event-timed); "
+      f"conv3d class {rc['achieved']:.0f} TF/s = **{rc['frac']:.3f}**; `roofline_attention` {ra['achieved']:.0f} TF/s = **{ra['frac']:.3f}** "
+      f"({ra['avg_launch_us']:.1f} µs per launch event-timed; rocprofv3 average of the same command {avg:.2f} µs = {94.49 / avg / 2.5:.3f}, "
+      f"`profiles/{tag}_c3_kernel_stats.md`; c5: {c5['roofline_attention']['frac']:.3f} at its batch of 16 windows).  HBM bytes per launch (PMC): "
+      f"{rd.get('traffic')} ({rd['kernel'].split(' ')[0]}), {rg.get('traffic')} (GEMM class).  CPU oracle on the same box: {c3['cpu_baseline']['value']:.2f} frames/s on "
       f"{c3['cpu_baseline']['cores']} cores ({c3['cpu_baseline']['sample'].split(';')[1].strip()}).\n")
 g = c5.get
 t += (f"c5 pieces on one GPU: encoders {g('phase1a_encoder_ms'):.0f} ms, decoders {g('phase1b_decoders_ms'):.0f} ms, dense stitch {g('phase3_dense_ms'):.1f} ms, "
