@@ -378,7 +378,7 @@ def test_gemm_group_equals_separate_launches(dev):
     from tests.test_gemm8p_gpu import prof_tags
     with prof_tags() as p:
         _lib.check(lib.l4p_gemm_group(st, L4P_BF16, da, 4), "l4p_gemm_group")
-    tags = [ln[1] for ln in p.lines if ln[0] == "gemm"]
+    tags = [ln[1] for ln in p.lines if ln[0] in ("gemm", "gemm_small")]  # (384-row problems: the small-products class)
     assert len(tags) == 1 and tags[0].startswith("group of 4"), tags
     for i in range(4):
         _lib.check(lib.l4p_gemm(st, L4P_BF16, C.byref(db[i])), "l4p_gemm")
@@ -397,6 +397,6 @@ def test_gemm_group_equals_separate_launches(dev):
         ds[i].bias, ds[i].epi, ds[i].out_T, ds[i].ldc = bs[0].data_ptr(), EPI_DENSE, o.data_ptr(), 1408
     with prof_tags() as p:
         _lib.check(lib.l4p_gemm_group(st, L4P_BF16, ds, 2), "l4p_gemm_group")
-    assert len([ln for ln in p.lines if ln[0] == "gemm"]) == 2
+    assert len([ln for ln in p.lines if ln[0] in ("gemm", "gemm_small")]) == 2  # (65536 rows: GEMM class; 384 rows: small products)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(ob.float()).all()) and float(ob.float().abs().max()) > 0

@@ -10,22 +10,28 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
+cd /tmp && export TMPDIR=/tmp
+# HBM bytes per launch first: bench.py attaches them to its roofline objects only from a file taken on THESE kernels (kernel tree hash)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_${TAG}_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_${TAG}_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
+cd $R
+python tools/pmc_hbm_traffic.py $O/pmc_${TAG}_fetch $O/pmc_${TAG}_write $O/${TAG}_c3_hbm_traffic > /dev/null
+cp $O/${TAG}_c3_hbm_traffic.json $O/${TAG}_c3_hbm_traffic.md $R/profiles/   # (on the box; copy them into the tracked profiles/ afterwards)
 python bench.py --steps 20 --warmup 5 > $O/${TAG}_c3_bench_line.json 2> $O/${TAG}_c3.err
 python bench.py --workload c2 --steps 40 --warmup 10 > $O/${TAG}_c2_bench_line.json 2> $O/${TAG}_c2.err
 python bench.py --workload c5 --steps 3 --warmup 1 > $O/${TAG}_c5_bench_line.json 2> $O/${TAG}_c5.err
 python bench.py --workload demo --steps 3 --warmup 1 > $O/${TAG}_demo_bench_line.json 2> $O/${TAG}_demo.err
 python bench.py --workload prep --steps 50 --warmup 10 > $O/${TAG}_prep_bench_line.json 2> $O/${TAG}_prep.err
+python bench.py --batch 8 --steps 10 --warmup 3 > $O/${TAG}_c3_batch8_bench_line.json 2> $O/${TAG}_c3_batch8.err
 python tools/prof_detail.py c3 5 > $O/${TAG}_c3_per_shape_event_profile.txt 2>/dev/null
 python tools/prof_detail.py c2 10 > $O/${TAG}_c2_per_shape_event_profile.txt 2>/dev/null
-cd /tmp && export TMPDIR=/tmp
+cd /tmp
 CMD3="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"
 CMD2="python $R/bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-prof"
 # (tracker clips serialised on one stream, as in bench.py's own event-timed pass: with the clips on their own streams and the
 #  dense decoders beside them, concurrent kernels share the chip and every one of them reports the shared interval)
 L4P_TRACK_STREAMS=0 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_c3 -o out -- $CMD3 > $O/prof_${TAG}_c3.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_c2 -o out -- $CMD2 > $O/prof_${TAG}_c2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_${TAG}_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_${TAG}_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $O/pmc_${TAG}_sq -o out -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_${TAG}_grbm -o out -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
 cd $R
@@ -33,5 +39,4 @@ bash tools/probes/power_probe.sh > $O/${TAG}_power_probe.txt 2>&1
 python tools/pmc_mfma_util.py $O/pmc_${TAG}_sq $O/pmc_${TAG}_grbm $O/${TAG}_power_probe.txt > $O/${TAG}_c3_mfma_util.md 2> $O/${TAG}_mfma_util.err
 python tools/rocprof_summary.py $(find $O/prof_${TAG}_c3 -name "*.db" | head -1) "L4P_TRACK_STREAMS=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof (c3: 7 steps, every kernel serialised on one stream)" > $O/${TAG}_c3_kernel_stats.md
 python tools/rocprof_summary.py $(find $O/prof_${TAG}_c2 -name "*.db" | head -1) "python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-prof (c2: 13 steps)" > $O/${TAG}_c2_kernel_stats.md
-python tools/pmc_hbm_traffic.py $O/pmc_${TAG}_fetch $O/pmc_${TAG}_write $O/${TAG}_c3_hbm_traffic > /dev/null
 ls -la $O | grep ${TAG}_ | head -30

@@ -49,7 +49,7 @@ t += (f"\nThe c3 line: `roofline` = the class with the most time, {rd['kernel'].
       f"conv3d class {rc['achieved']:.0f} TF/s = **{rc['frac']:.3f}**; `roofline_attention` {ra['achieved']:.0f} TF/s = **{ra['frac']:.3f}** "
       f"({ra['avg_launch_us']:.1f} µs per launch event-timed; rocprofv3 average of the same command {avg:.2f} µs = {94.49 / avg / 2.5:.3f}, "
       f"`profiles/{tag}_c3_kernel_stats.md`; c5: {c5['roofline_attention']['frac']:.3f} at its batch of 16 windows).  HBM bytes per launch (PMC): "
-      f"{rd.get('traffic')} ({rd['kernel'].split(' ')[0]}), {rg.get('traffic')} (GEMM class).  CPU oracle on the same box: {c3['cpu_baseline']['value']:.2f} frames/s on "
+      f"{(rd.get('traffic') or 0) / 1e6:.0f} MB ({rd['kernel'].split(' ')[0]}), {(rg.get('traffic') or 0) / 1e6:.0f} MB (GEMM class), {(ra.get('traffic') or 0) / 1e6:.0f} MB (attention; `profiles/{tag}_c3_hbm_traffic.md`).  CPU oracle on the same box: {c3['cpu_baseline']['value']:.2f} frames/s on "
       f"{c3['cpu_baseline']['cores']} cores ({c3['cpu_baseline']['sample'].split(';')[1].strip()}).\n")
 g = c5.get
 t += (f"c5 pieces on one GPU: encoders {g('phase1a_encoder_ms'):.0f} ms, decoders {g('phase1b_decoders_ms'):.0f} ms, dense stitch {g('phase3_dense_ms'):.1f} ms, "
