@@ -483,3 +483,49 @@ def test_full_size_24_tracks_four_windows_integer_state(dev, full_sd, precision)
     if rep:
         print("24 tracks, 4 windows, bf16, tracks with the reference's state:", int(same.sum()), {k: f"{v:.2e}" for k, v in rep.items()})
         assert_bf16_within_reference_drift(rep, "full_T40_track24", what="24 tracks")
+
+
+def test_folded_value_projection_equals_projected_values_at_full_size(dev, full_sd, monkeypatch):
+    """The tracker at the FULL geometry (1408 channels, 8 heads of 88: where the value projection of the token -> image attentions is
+    folded away - l4p_t2i_probs / l4p_t2i_context; the mini geometry's head dim 44 keeps the projected values) against
+    the projected form (L4P_TRACK_FOLD_T2I_V=0) over 3 windows (24 frames) with 8 tracks: the same function of the same weights.
+    f32 engine: equal to rounding (1e-4 of the maximum), values that mark invalid entries identical.  bf16 engine: each form as close
+    to the f32 engine as the other (mean distance of the tracks within 1.5x, worst track within 2x), and the native window call bit-identical to the Python composition
+    that the switch is read by."""
+    batch = make_batch(24, 8)
+    keys = ["track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"]
+    res = {}
+    for precision in ("32-true", "bf16"):
+        m = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision=precision)
+        m.load_state_dict({"l4p_model." + k: v for k, v in full_sd.items()})
+        with torch.no_grad():
+            monkeypatch.setenv("L4P_TRACK_PYTHON", "1")
+            monkeypatch.setenv("L4P_TRACK_FOLD_T2I_V", "1")
+            a = m.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+            monkeypatch.setenv("L4P_TRACK_FOLD_T2I_V", "0")
+            b = m.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+            monkeypatch.delenv("L4P_TRACK_PYTHON")
+            monkeypatch.delenv("L4P_TRACK_FOLD_T2I_V")
+            c = m.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
+        torch.cuda.synchronize()
+        res[precision] = ({k: a[k].float().cpu() for k in keys}, {k: b[k].float().cpu() for k in keys})
+        for k in keys:
+            assert torch.equal(a[k], c[k]), (precision, k, "native vs Python composition", float((a[k] - c[k]).abs().max()))
+        del m
+
+    def per_track(x, y):
+        return (x - y)[0].flatten(1).norm(dim=1) / y[0].flatten(1).norm(dim=1).clamp_min(1e-9)
+
+    for k in keys:
+        fa, fb = res["32-true"][0][k], res["32-true"][1][k]
+        ha, hb = res["bf16"][0][k], res["bf16"][1][k]
+        err = float((fa - fb).abs().max() / fb.abs().max())
+        d_fold, d_proj = per_track(ha, fb), per_track(hb, fb)
+        print(k, f"f32 folded vs projected values: max {err:.2e}; bf16 vs f32 per track (mean, max): folded {float(d_fold.mean()):.1e} "
+                 f"{float(d_fold.max()):.1e}, projected {float(d_proj.mean()):.1e} {float(d_proj.max()):.1e}")
+        assert err <= 1e-4, (k, err)
+        assert torch.equal(fa == -10.0, fb == -10.0) and torch.equal(fa == 0.0, fb == 0.0), k
+        # (8 tracks, two evaluation orders in bf16: single tracks move either way by a factor of two - see the printed rows -, so the
+        #  forms are compared on the tracks' mean and worst distance, not track by track)
+        assert float(d_fold.mean()) <= 1.5 * float(d_proj.mean()) + 1e-4, (k, d_fold, d_proj)
+        assert float(d_fold.max()) <= 2.0 * float(d_proj.max()) + 1e-3, (k, d_fold, d_proj)
