@@ -41,7 +41,8 @@ typedef void* l4p_stream; /* hipStream_t */
 typedef struct l4p_engine l4p_engine;
 
 const char* l4p_last_error(void);
-int l4p_abi_version(void); /* 4: l4p_gemm_desc.o_gs, l4p_i2t_delta, l4p_t2i_probs, l4p_t2i_context; 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs,
+int l4p_abi_version(void); /* 5: l4p_layernorm_res(out_stats), l4p_layernorm_chain, l4p_stream_create_cu_mask; 4: l4p_gemm_desc.o_gs, l4p_i2t_delta,
+                              * l4p_t2i_probs, l4p_t2i_context; 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs,
                               * l4p_t2i_attn_scores, l4p_split_hilo, l4p_transpose_pad */
 
 /* A HIP stream restricted to CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask) / its release.  Plumbing for the sharded
@@ -290,7 +291,15 @@ int l4p_layernorm_ex(l4p_stream stream, int dtype, const float* x, const float* 
  * feature + the learned mask token: l4p_track_keys_init's k32_shared); x_shared is never written, so out_f32 may still alias x. */
 int l4p_layernorm_res(l4p_stream stream, int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma,
                       const float* beta, float eps, void* out_T, float* out_f32, int M, int C, const float* add, int add_mod,
-                      void* out_T2, const float* x_shared, int x_period, int x_split);
+                      void* out_T2, const float* x_shared, int x_period, int x_split, float* out_stats);
+/* ... out_stats (may be NULL): float [M][2] = (mean, rstd) of every row, and
+ * l4p_layernorm_chain: the NEXT layer's keys = LayerNorm(y_prev + delta) where y_prev - the float result of an l4p_layernorm_res launch
+ * over x_shared_rows[row % x_mod] + delta_prev[row] that stored only its engine-dtype outputs and out_stats - is re-derived from those
+ * inputs, bit for bit (same affine form, same statistics).  The tracker's second layer in a first window: the float key master
+ * [N * P][C] is neither written by layer 0 nor read by layer 1 (1.1 GB of 3.7 GB per 64 tracks).  Outputs as l4p_layernorm_ex. */
+int l4p_layernorm_chain(l4p_stream stream, int dtype, const float* x_shared_rows, int x_mod, const void* delta_prev_T, const float* stats_prev,
+                        const float* gamma_prev, const float* beta_prev, const void* delta_T, const float* gamma, const float* beta, float eps,
+                        void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2);
 
 /* The same LayerNorm (+ optional GELU) for rows that are STORED in the engine dtype: x_T, out_T are T [M][C] and may be the
  * same buffer.  Used for LayerNorm3d + GELU after the first up-scaling ConvTranspose (mask_decoder.py:60-62), whose 1M x 352

@@ -115,7 +115,8 @@ SIGNATURES = {
     "l4p_similarity_apply": (_I, [_VP, _VP, _VP, _I, _VP, _LL]),
     "l4p_layernorm_ex": (_I, [_VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I, _VP, _I, _VP, _I]),
     "l4p_gemm_group": (_I, [_VP, _I, _VP, _I]),
-    "l4p_layernorm_res": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _I, _I]),
+    "l4p_layernorm_res": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _I, _I, _VP]),
+    "l4p_layernorm_chain": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _F, _VP, _VP, _I, _I, _VP, _I, _VP]),
     "l4p_track_tokens": (_I, [_VP] * 13 + [_I] * 5),
     "l4p_track_keys_init": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "l4p_fill_rows": (_I, [_VP, _VP, _VP, _LL, _I, _LL, _LL, _LL]),

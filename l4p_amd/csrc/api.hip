@@ -24,12 +24,12 @@ void l4p_set_error(const char* fmt, ...) {
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
                          void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
                          int x_period, int x_split, hipStream_t stream, float* out_sum = nullptr, const float* part = nullptr,
-                         int nsplit = 0, const float* pbias = nullptr);
+                         int nsplit = 0, const float* pbias = nullptr, float* out_stats = nullptr);
 
 extern "C" {
 
 const char* l4p_last_error(void) { return g_err; }
-int l4p_abi_version(void) { return 4; }
+int l4p_abi_version(void) { return 5; }
 
 // A HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (hipExtStreamCreateWithCUMask): the sharded long-video path
 // gives the tracker's latency-bound kernel chain a slice of the chip of its own, beside the chip-filling decoders on the rest.

@@ -9,7 +9,10 @@ int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const flo
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
                          void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
                          int x_period, int x_split, hipStream_t stream, float* out_sum = nullptr, const float* part = nullptr,
-                         int nsplit = 0, const float* pbias = nullptr);
+                         int nsplit = 0, const float* pbias = nullptr, float* out_stats = nullptr);
+int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dprev_T, const float* stats, const float* g0, const float* b0,
+                           const void* delta_T, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M, int C,
+                           const float* add, int add_mod, void* out_T2, hipStream_t stream);
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
@@ -48,9 +51,15 @@ extern "C" {
 
 int l4p_layernorm_res(l4p_stream s, int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta,
                       float eps, void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2,
-                      const float* x_shared, int x_period, int x_split) {
+                      const float* x_shared, int x_period, int x_split, float* out_stats) {
     return launch_layernorm_res(dtype, x, x_mod, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, x_shared, x_period,
-                                x_split, (hipStream_t)s);
+                                x_split, (hipStream_t)s, nullptr, nullptr, 0, nullptr, out_stats);
+}
+int l4p_layernorm_chain(l4p_stream s, int dtype, const float* x_shared_rows, int x_mod, const void* delta_prev_T, const float* stats_prev,
+                        const float* gamma_prev, const float* beta_prev, const void* delta_T, const float* gamma, const float* beta, float eps,
+                        void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2) {
+    return launch_layernorm_chain(dtype, x_shared_rows, x_mod, delta_prev_T, stats_prev, gamma_prev, beta_prev, delta_T, gamma, beta, eps, out_T,
+                                  out_f32, M, C, add, add_mod, out_T2, (hipStream_t)s);
 }
 int l4p_layernorm_ex(l4p_stream s, int dtype, const float* x, const float* gamma, const float* beta, float eps,
                      void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, int act) {

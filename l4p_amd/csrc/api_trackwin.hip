@@ -22,7 +22,10 @@ int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const flo
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
                          void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
                          int x_period, int x_split, hipStream_t stream, float* out_sum = nullptr, const float* part = nullptr,
-                         int nsplit = 0, const float* pbias = nullptr);
+                         int nsplit = 0, const float* pbias = nullptr, float* out_stats = nullptr);
+int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dprev_T, const float* stats, const float* g0, const float* b0,
+                           const void* delta_T, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M, int C,
+                           const float* add, int add_mod, void* out_T2, hipStream_t stream);
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
@@ -274,6 +277,15 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
             if (!c.rc && !c.dry) c.rc = launch_t2i_attn_scores(c.dt, sc, HTk, tv, ta, N, P, Dh, g.sam_heads, c.st);
         }
     };
+    // chained key LayerNorm (see the image -> token block below): L4P_TRACK_LN_CHAIN=0 keeps the float key master
+    static const bool chain_env = !(getenv("L4P_TRACK_LN_CHAIN") && atoi(getenv("L4P_TRACK_LN_CHAIN")) == 0);
+    const bool may_chain = chain_env && start_shared && g.sam_depth >= 2 && Cc <= 1536;
+    float* chain_stats = may_chain ? c.f32(NP, 2) : nullptr;
+    // (a third layer would need the chained layer's float result: with the master's storage holding layer 0's update it gets its own)
+    float* kc32 = may_chain && g.sam_depth > 2 ? c.f32(NP, Cc) : nullptr;
+    float* cur32_after_chain = nullptr;
+    bool chained = false;
+    std::string chain_norm;
     for (int l = 0; l < g.sam_depth; ++l) {
         const std::string lo = "l" + std::to_string(l) + ".";
         const bool shared = Nk == 1 && N > 1;  // keys still common to all tracks (only in layer 0 of a first window)
@@ -332,7 +344,11 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
             // LayerNorm forms the sum (l4p_layernorm_res): the float key stream is read once per layer instead of read + written
             // by the projection's epilogue and read again.  While the keys are still common to all tracks the float residual is
             // row m % P of the common set.
-            void* delta = c.T(NP, Cc);
+            // Chained LayerNorm (first window: this layer's float residual is the SHARED key set): the layer stores its update, its
+            // engine-dtype results and (mean, rstd) per row; the next layer re-derives this layer's float result from those
+            // (l4p_layernorm_chain) - the float key master is neither written nor read, and its storage holds this layer's update.
+            const bool chain_next = chain_env && shared && l + 1 < g.sam_depth && Cc <= 1536;
+            void* delta = chain_next ? (void*)k32 : c.T(NP, Cc);
             const int HT = 6 * g.sam_heads;               // (token, head) pairs of a track: the folded k dimension
             const int HTp = (HT + 63) / 64 * 64;
             // Folded form (packing.py fold_i2t; every track owns its keys, all rows of kP exist): the 2048 x N image tokens never
@@ -409,16 +425,27 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
                 c.gemm(ia, NP, Dh, Dh, lo + "i2t.out", Cc, true, ACT_NONE, nullptr, 0, nullptr, delta, Cc);
             }
             // (after the last layer nothing adds to the float keys any more: only the T copies are written)
-            float* o32 = l + 1 < g.sam_depth ? k32 : nullptr;
-            if (!c.rc && !c.dry)
+            float* o32 = l + 1 < g.sam_depth && !chain_next ? k32 : nullptr;
+            if (chained) {  // (the previous layer left its update in k32's storage and its statistics in chain_stats)
+                if (!c.rc && !c.dry)
+                    c.rc = launch_layernorm_chain(c.dt, ks32, P, k32, chain_stats, c.Wf(chain_norm + ".g"), c.Wf(chain_norm + ".b"), delta,
+                                                  c.Wf(lo + "norm4.g"), c.Wf(lo + "norm4.b"), 1e-5f, kT, l + 1 < g.sam_depth ? kc32 : nullptr,
+                                                  (int)NP, Cc, pos, P, kP, c.st);
+            } else if (!c.rc && !c.dry) {
                 c.rc = launch_layernorm_res(c.dt, cur32, shared ? P : 0, delta, c.Wf(lo + "norm4.g"), c.Wf(lo + "norm4.b"), 1e-5f, kT, o32,
-                                            (int)NP, Cc, pos, P, kP, half_shared && l == 0 ? kh32 : nullptr, P, P / 2, c.st);
+                                            (int)NP, Cc, pos, P, kP, half_shared && l == 0 ? kh32 : nullptr, P, P / 2, c.st, nullptr, nullptr, 0,
+                                            nullptr, chain_next ? chain_stats : nullptr);
+            }
+            if (chained) cur32_after_chain = kc32;
+            chained = chain_next;
+            chain_norm = lo + "norm4";
             if (shared) {  // from here on every track owns its keys
                 Nk = N;
                 curT = kT;
                 curP = kP;
             }
-            cur32 = k32;
+            cur32 = cur32_after_chain ? cur32_after_chain : k32;
+            cur32_after_chain = nullptr;
         }
         c.ws.off = mark;
     }

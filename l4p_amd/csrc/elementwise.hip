@@ -27,6 +27,11 @@
 #define LN_ST(ptr, val) (*(ptr) = (val))
 #define LN_LD(ptr) (*(ptr))
 #endif
+// y = (v - mean) * rstd * g + b, written ONCE: the chained key LayerNorm below re-derives another launch's float result from its
+// inputs and stored statistics, bit for bit - both must round the same way whatever the compiler would contract in each context
+__device__ __forceinline__ float ln_affine(float v, float mean, float rstd, float g, float b) {
+    return __builtin_fmaf((v - mean) * rstd, g, b);
+}
 template <typename T, int MAXV, bool XT = false, int ROWS = 1, bool RES = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, T* out_T, float* out_f32, int M,
@@ -35,7 +40,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                                                         const float* __restrict__ x_shared = nullptr, int x_period = 1,
                                                         int x_split = 0, float* out_sum = nullptr,
                                                         const float* __restrict__ part = nullptr, int nsplit = 0,
-                                                        const float* __restrict__ pbias = nullptr) {
+                                                        const float* __restrict__ pbias = nullptr, float* __restrict__ out_stats = nullptr) {
     // (x and the outputs are NOT restrict-qualified: the tracker normalises its key stream and the up-scaled activation in
     //  place; a wave has its whole row in registers - every store depends on the row statistics - before it writes)
     const int lane = threadIdx.x & 63;
@@ -112,18 +117,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float d = v[r][i][k] - mean;
-                    q += d * d;
+                    q = __builtin_fmaf(d, d, q);  // (explicit: the chained LayerNorm must round like the plain one in every instantiation)
                 }
             }
         }
         const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        if constexpr (RES) {  // (mean, rstd) of the row: what layernorm_chain_kernel re-derives this launch's float result from
+            if (out_stats && lane == 0) {
+                out_stats[2ll * row] = mean;
+                out_stats[2ll * row + 1] = rstd;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int idx = lane + i * 64;
             if (idx < nv) {
                 f32x4 y;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = (v[r][i][k] - mean) * rstd * g[i][k] + bb[i][k];
+                for (int k = 0; k < 4; ++k) y[k] = ln_affine(v[r][i][k], mean, rstd, g[i][k], bb[i][k]);
                 if (act == L4P_ACT_GELU) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) y[k] = gelu_for<T>(y[k]);
@@ -200,7 +211,7 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
 int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta_T, const float* gamma, const float* beta, float eps,
                          void* out_T, float* out_f32, int M, int C, const float* add, int add_mod, void* out_T2, const float* x_shared,
                          int x_period, int x_split, hipStream_t stream, float* out_sum, const float* part, int nsplit,
-                         const float* pbias) {
+                         const float* pbias, float* out_stats) {
     if (part && (nsplit < 1 || nsplit > 16)) {
         l4p_set_error("layernorm_res: 1 <= nsplit <= 16 slices of float partials");
         return L4P_E_INVALID;
@@ -219,18 +230,138 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
     if (dtype == L4P_BF16) {
         if (C <= 512)
             hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias);
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
         else
             hipLaunchKernelGGL((layernorm_kernel<bf16_t, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias);
+                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
     } else {
         if (C <= 512)
             hipLaunchKernelGGL((layernorm_kernel<float, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias);
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
         else
             hipLaunchKernelGGL((layernorm_kernel<float, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias);
+                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Chained key LayerNorm (the tracker's second layer in a FIRST window, sam/transformer.py:183-185): the layer before normalised
+// xs[row % x_mod] + dprev[row] - float rows common to all tracks plus that layer's update in the engine dtype - and stored only its
+// engine-dtype outputs and (mean, rstd) per row.  Its float result, the residual this layer adds to, is re-derived here from those
+// (ln_affine: bit for bit what it would have stored), so the float key master [N * P][C] is neither written nor read: 1.1 GB of
+// 3.7 GB per 64 tracks.  One wave per row, every load issued before the first use, C <= 1536.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_chain_kernel(const float* __restrict__ xs, int x_mod, const T* __restrict__ dprev,
+                                                              const float* __restrict__ stats, const float* __restrict__ g0,
+                                                              const float* __restrict__ b0, const T* __restrict__ delta,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                              T* __restrict__ out_T, float* __restrict__ out_f32, int M, int C,
+                                                              const float* __restrict__ add, int add_mod, T* __restrict__ out_T2) {
+    constexpr int MAXV = 6;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = C >> 2;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[MAXV], d1[MAXV], av[MAXV];
+    const f32x4* xr = (const f32x4*)(xs + (long long)(row % x_mod) * C);
+    const f32x4* ar = out_T2 ? (const f32x4*)(add + (long long)(row % add_mod) * C) : nullptr;
+    const float mean0 = stats[2ll * row], rstd0 = stats[2ll * row + 1];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        const bool in = idx < nv;
+        v[i] = in ? xr[idx] : z;
+        if (sizeof(T) == 2) {
+            const bf16x4 t = ((const bf16x4*)((const bf16_t*)dprev + (long long)row * C))[in ? idx : 0];
+            const bf16x4 u = ((const bf16x4*)((const bf16_t*)delta + (long long)row * C))[in ? idx : 0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[i][k] += in ? (float)t[k] : 0.f;
+                d1[i][k] = in ? (float)u[k] : 0.f;
+            }
+        } else {
+            const f32x4 t = ((const f32x4*)((const float*)dprev + (long long)row * C))[in ? idx : 0];
+            const f32x4 u = ((const f32x4*)((const float*)delta + (long long)row * C))[in ? idx : 0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[i][k] += in ? t[k] : 0.f;
+                d1[i][k] = in ? u[k] : 0.f;
+            }
+        }
+        av[i] = (in && ar) ? ar[idx] : z;
+    }
+    // the previous layer's float result (its out_f32, had it stored one) + this layer's update
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nv) {
+            const f32x4 gg = ((const f32x4*)g0)[idx], bb = ((const f32x4*)b0)[idx];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] = ln_affine(v[i][k], mean0, rstd0, gg[k], bb[k]) + d1[i][k];
+        } else {
+            v[i] = z;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (lane + i * 64 < nv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = v[i][k] - mean;
+                q = __builtin_fmaf(d, d, q);  // (explicit: the chained LayerNorm must round like the plain one in every instantiation)
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nv) {
+            const f32x4 gg = ((const f32x4*)gamma)[idx], bb = ((const f32x4*)beta)[idx];
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = ln_affine(v[i][k], mean, rstd, gg[k], bb[k]);
+            if (out_f32) ((f32x4*)(out_f32 + (long long)row * C))[idx] = y;
+            if (sizeof(T) == 2) {
+                bf16x4 o, o2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (bf16_t)y[k], o2[k] = (bf16_t)(y[k] + av[i][k]);
+                if (out_T) ((bf16x4*)((bf16_t*)out_T + (long long)row * C))[idx] = o;
+                if (out_T2) ((bf16x4*)((bf16_t*)out_T2 + (long long)row * C))[idx] = o2;
+            } else {
+                if (out_T) ((f32x4*)((float*)out_T + (long long)row * C))[idx] = y;
+                if (out_T2) {
+                    f32x4 o2;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o2[k] = y[k] + av[i][k];
+                    ((f32x4*)((float*)out_T2 + (long long)row * C))[idx] = o2;
+                }
+            }
+        }
+    }
+}
+int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dprev_T, const float* stats, const float* g0, const float* b0,
+                           const void* delta_T, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M, int C,
+                           const float* add, int add_mod, void* out_T2, hipStream_t stream) {
+    if (C % 4 || C > 1536 || x_mod < 1 || !xs || !dprev_T || !stats || !delta_T || (out_T2 && (!add || add_mod <= 0))) {
+        l4p_set_error("layernorm_chain: C=%d must be a multiple of 4 and <= 1536; shared rows, both updates and the statistics are required", C);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d chain T2%d f32%d", M, C, out_T2 != nullptr, out_f32 != nullptr);
+    const dim3 grid((M + 3) / 4);
+    if (dtype == L4P_BF16)
+        hipLaunchKernelGGL(layernorm_chain_kernel<bf16_t>, grid, dim3(256), 0, stream, xs, x_mod, (const bf16_t*)dprev_T, stats, g0, b0,
+                           (const bf16_t*)delta_T, gamma, beta, eps, (bf16_t*)out_T, out_f32, M, C, add, add_mod, (bf16_t*)out_T2);
+    else
+        hipLaunchKernelGGL(layernorm_chain_kernel<float>, grid, dim3(256), 0, stream, xs, x_mod, (const float*)dprev_T, stats, g0, b0,
+                           (const float*)delta_T, gamma, beta, eps, (float*)out_T, out_f32, M, C, add, add_mod, (float*)out_T2);
     HIP_TRY(hipGetLastError());
     return 0;
 }

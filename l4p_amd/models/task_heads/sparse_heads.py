@@ -223,6 +223,10 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         q32: Optional[torch.Tensor] = None
         qT, qP = tokT, tokT
         x32 = torch.empty((6 * N, Cc), **f32)
+        # chained key LayerNorm (csrc/api_trackwin.hip has the same sequence): in a first window layer 0 keeps its update, its
+        # engine-dtype results and (mean, rstd) per row; layer 1 re-derives layer 0's float result from those - no float key master
+        chain_on = os.environ.get("L4P_TRACK_LN_CHAIN", "1") != "0" and Cc <= 1536
+        chain = None  # (shared float rows, the previous layer's update, its statistics, its norm's name)
         for l in range(cfg.sam_depth):
             lo = f"l{l}."
             shared = Nk == 1 and N > 1  # keys still common to all tracks (only in layer 0 of a first window)
@@ -315,16 +319,31 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 _gemm(ia, N * P, Dh, Dh, self._w(lo + "i2t.out.w"), Cc, bias=self._w(lo + "i2t.out.b"), out_T=delta)
                 del ia
             k_res = k32
+            chain_next = chain_on and shared and l + 1 < cfg.sam_depth
             if shared:
-                k32 = torch.empty((N * P, Cc), **f32)
+                k32 = None if chain_next else torch.empty((N * P, Cc), **f32)
                 kT = torch.empty((N * P, Cc), dtype=td, device=dev)
                 kP = torch.empty((N * P, Cc), dtype=td, device=dev)
                 Nk = N
             # (after the last layer nothing adds to the float keys any more: only the T copies are written)
-            _lib.check(lib.l4p_layernorm_res(_stream(), dt, _p(k_res), P if shared else 0, _p(delta), _p(self._w(lo + "norm4.g")),
-                                             _p(self._w(lo + "norm4.b")), 1e-5, _p(kT), _p(k32) if l + 1 < cfg.sam_depth else None,
-                                             N * P, Cc, _p(pos), P, _p(kP), _p(kh32) if (half_shared and l == 0) else None, P, P // 2),
-                       "l4p_layernorm_res")
+            want32 = l + 1 < cfg.sam_depth and not chain_next
+            if chain is not None:
+                xs, dprev, stats, pnorm = chain
+                if want32:
+                    k32 = torch.empty((N * P, Cc), **f32)
+                _lib.check(lib.l4p_layernorm_chain(_stream(), dt, _p(xs), P, _p(dprev), _p(stats), _p(self._w(pnorm + ".g")),
+                                                   _p(self._w(pnorm + ".b")), _p(delta), _p(self._w(lo + "norm4.g")), _p(self._w(lo + "norm4.b")),
+                                                   1e-5, _p(kT), _p(k32) if want32 else None, N * P, Cc, _p(pos), P, _p(kP)),
+                           "l4p_layernorm_chain")
+                chain = None
+            else:
+                stats = torch.empty((N * P, 2), **f32) if chain_next else None
+                _lib.check(lib.l4p_layernorm_res(_stream(), dt, _p(k_res), P if shared else 0, _p(delta), _p(self._w(lo + "norm4.g")),
+                                                 _p(self._w(lo + "norm4.b")), 1e-5, _p(kT), _p(k32) if want32 else None,
+                                                 N * P, Cc, _p(pos), P, _p(kP), _p(kh32) if (half_shared and l == 0) else None, P, P // 2,
+                                                 _p(stats) if chain_next else None), "l4p_layernorm_res")
+                if chain_next:
+                    chain = (k_res, delta, stats, lo + "norm4")
             del delta, k_res
         # --- final tokens -> image attention (transformer.py:103-109) ---
         fq = self._proj(qP, "final.q", Dh)

@@ -445,6 +445,50 @@ def test_row_grouped_weights_gemm_and_folded_i2t_kernels(dev, precision):
     assert float((delta.float().cpu().view(N, P, Cc) - dref).abs().max()) <= tol * float(dref.abs().max())
 
 
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_layernorm_chain_equals_two_layernorms_bitwise(dev, precision):
+    """l4p_layernorm_chain (the tracker's second-layer key LayerNorm in a first window, re-deriving the first layer's float result from
+    the shared float rows, that layer's update and its stored (mean, rstd)) against the two l4p_layernorm_res launches with the float
+    key master between them: bit-identical outputs in both engine dtypes - also its optional float output."""
+    from l4p_amd import _lib
+    from l4p_amd._lib import L4P_BF16, L4P_F32
+    from l4p_amd.ops import _p, _stream
+
+    lib = _lib.load()
+    dt = L4P_BF16 if precision == "bf16" else L4P_F32
+    td = torch.bfloat16 if precision == "bf16" else torch.float32
+    P, Cc, N = 96, 1408, 3
+    M = N * P
+    g = torch.Generator().manual_seed(21)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    xs, pos = r(P, Cc).cuda(), r(P, Cc).cuda()
+    d0, d1 = (0.5 * r(M, Cc)).to(td).cuda(), (0.5 * r(M, Cc)).to(td).cuda()
+    g0, b0, g1, b1 = (1 + 0.1 * r(Cc)).cuda(), (0.1 * r(Cc)).cuda(), (1 + 0.1 * r(Cc)).cuda(), (0.1 * r(Cc)).cuda()
+    e = lambda dtype=td: torch.empty(M, Cc, dtype=dtype, device="cuda")  # noqa: E731
+    # with the float master
+    y0, kT0, kP0, kT1, kP1, y1 = e(torch.float32), e(), e(), e(), e(), e(torch.float32)
+    _lib.check(lib.l4p_layernorm_res(_stream(), dt, _p(xs), P, _p(d0), _p(g0), _p(b0), 1e-5, _p(kT0), _p(y0), M, Cc, _p(pos), P, _p(kP0),
+                                     None, 1, 0, None), "l4p_layernorm_res")
+    _lib.check(lib.l4p_layernorm_res(_stream(), dt, _p(y0), 0, _p(d1), _p(g1), _p(b1), 1e-5, _p(kT1), _p(y1), M, Cc, _p(pos), P, _p(kP1),
+                                     None, 1, 0, None), "l4p_layernorm_res")
+    # chained
+    st = torch.empty(M, 2, device="cuda")
+    cT0, cP0, cT1, cP1, c1 = e(), e(), e(), e(), e(torch.float32)
+    _lib.check(lib.l4p_layernorm_res(_stream(), dt, _p(xs), P, _p(d0), _p(g0), _p(b0), 1e-5, _p(cT0), None, M, Cc, _p(pos), P, _p(cP0),
+                                     None, 1, 0, _p(st)), "l4p_layernorm_res(stats)")
+    _lib.check(lib.l4p_layernorm_chain(_stream(), dt, _p(xs), P, _p(d0), _p(st), _p(g0), _p(b0), _p(d1), _p(g1), _p(b1), 1e-5, _p(cT1), _p(c1),
+                                       M, Cc, _p(pos), P, _p(cP1)), "l4p_layernorm_chain")
+    torch.cuda.synchronize()
+    assert torch.equal(kT0, cT0) and torch.equal(kP0, cP0)
+    assert torch.equal(kT1, cT1) and torch.equal(kP1, cP1) and torch.equal(y1, c1)
+    x0 = xs.repeat(N, 1) + d0.float()
+    ref0 = torch.nn.functional.layer_norm(x0, (Cc,), g0, b0, 1e-5)
+    ref1 = torch.nn.functional.layer_norm(ref0 + d1.float(), (Cc,), g1, b1, 1e-5)
+    assert float((y1 - ref1).abs().max()) <= 1e-4
+    mean, var = x0.mean(dim=1), x0.var(dim=1, unbiased=False)
+    assert float((st[:, 0] - mean).abs().max()) <= 1e-5 and float((st[:, 1] - torch.rsqrt(var + 1e-5)).abs().max()) <= 1e-4
+
+
 @pytest.mark.parametrize("P,Cc", [(256, 1408), (272, 256)])
 def test_i2t_delta_kernel_equals_grouped_gemm(dev, P, Cc):
     """l4p_i2t_delta (delta = P x V' + b of the folded image -> token attention as a streaming kernel, bf16) against the
