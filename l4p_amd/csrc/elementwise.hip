@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float d = v[r][i][k] - mean;
-                    q = __builtin_fmaf(d, d, q);  // (explicit: the chained LayerNorm must round like the plain one in every instantiation)
+                    {  // (product rounded, then added - never contracted: the chained LayerNorm must round like the plain one in every
+                       //  instantiation; left to the compiler the f32 kernels fused it and the bf16 ones did not)
+#pragma clang fp contract(off)
+                        q += d * d;
+                    }
                 }
             }
         }
@@ -315,7 +319,11 @@ __global__ __launch_bounds__(256) void layernorm_chain_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float d = v[i][k] - mean;
-                q = __builtin_fmaf(d, d, q);  // (explicit: the chained LayerNorm must round like the plain one in every instantiation)
+                {  // (product rounded, then added - never contracted: the chained LayerNorm must round like the plain one in every
+                       //  instantiation; left to the compiler the f32 kernels fused it and the bf16 ones did not)
+#pragma clang fp contract(off)
+                        q += d * d;
+                    }
             }
         }
     }
