@@ -400,3 +400,30 @@ def test_gemm_group_equals_separate_launches(dev):
     assert len([ln for ln in p.lines if ln[0] in ("gemm", "gemm_small")]) == 2  # (65536 rows: GEMM class; 384 rows: small products)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(ob.float()).all()) and float(ob.float().abs().max()) > 0
+
+
+def test_cu_masked_stream_runs_kernels(dev):
+    """l4p_stream_create_cu_mask (plumbing of the sharded long-video path, parallel.cu_masked_stream): a stream confined to 32 CUs
+    runs the engine's kernels with the same result as the default stream, and can be released."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(lib.l4p_stream_create_cu_mask(0, 32, C.byref(h)), "l4p_stream_create_cu_mask")
+    assert h.value
+    x = rnd((512, 1408), 901).cuda()
+    g, b = rnd((1408,), 902).cuda(), rnd((1408,), 903).cuda()
+    want = torch.empty(512, 1408, dtype=torch.bfloat16, device="cuda")
+    got = torch.empty_like(want)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.l4p_layernorm(st, L4P_BF16, x.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-6, want.data_ptr(), None, 512, 1408), "l4p_layernorm")
+    torch.cuda.synchronize()
+    ext = torch.cuda.ExternalStream(h.value)
+    _lib.check(lib.l4p_layernorm(h.value, L4P_BF16, x.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-6, got.data_ptr(), None, 512, 1408), "l4p_layernorm")
+    ext.synchronize()
+    assert torch.equal(got, want)
+    del ext
+    _lib.check(lib.l4p_stream_destroy(h.value), "l4p_stream_destroy")
+    assert lib.l4p_stream_create_cu_mask(0, 0, C.byref(h)) != 0  # an empty CU range is refused
