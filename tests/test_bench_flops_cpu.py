@@ -49,3 +49,34 @@ def test_history_projection_is_credited_only_where_it_is_needed():
     assert abs((3 * three - 3 * one) - (64 * hist + 2 * 63 * shared - 63 * shared)) <= 1e-6 * one
     # a single window credits less than the reference graph's 73.81 GF per query (no history projection, folded i2t)
     assert bench.algorithmic_flops(cfg, ["track_2d"], 64)["gemm"] - bench.algorithmic_flops(cfg, ["track_2d"], 0)["gemm"] < 73.81e9 * 64 - 64 * hist + 1
+
+
+def test_executed_flops_of_tag_padding_rules():
+    """The per-launch FLOP count bench.py takes from a profiler tag: padding the kernels add is not counted."""
+    f = bench.executed_flops_of_tag
+    assert f("M8192 N6144 K1408 epi0 act1 8p t256x256") == 2.0 * 8192 * 6144 * 1408
+    assert f("M8192 N4608 K1408 epi1 act0 8p t256x192") == 2.0 * 8192 * (4608 * 88 // 96) * 1408      # QKV: head dim 88 of 96
+    assert f("M1048576 N768 K352 epi3 act1 8p t256x256") == 2.0 * 1048576 * (768 * 176 // 192) * 352  # 176 of 192 channels per tap
+    assert f("M8192 N1408 K1216 epi0 act0 8p t256x256") == 2.0 * 8192 * 1408 * 1176                   # patch vector 1176 of 1216
+    assert f("M131072 N1408 K64 epi0 act0 delta t16x128 wgrp") == 2.0 * 131072 * 1408 * 48            # 48 of 64 k slots
+    assert f("M384 N11264 K704 epi0 act0 sk1 t128x64") == 2.0 * 384 * 1408 * 704                      # block-diagonal token-side weights
+    assert f("M384 N8 K704 epi0 act0 sk1 t128x64 deep") == 2.0 * 384 * 1 * 704
+    assert f("M3072 N1408 K2048 epi0 act0 ctx t48x128") == 2.0 * 3072 * 1408 * 2048
+    assert f("group of 3: M384 N1408 K1408 ... t128x64 deep") == 0.0                                  # (grouped launches carry no shape)
+
+
+def test_kernel_tree_hash_is_stable_and_tied_to_the_committed_traffic_file():
+    """roofline.traffic is attached only from a PMC file taken on the kernel sources being run: the committed r04 file carries the
+    hash of the committed tree."""
+    import json
+
+    from l4p_amd import _lib
+
+    h = _lib.kernel_tree_hash()
+    assert len(h) == 16 and h == _lib.kernel_tree_hash()
+    import glob
+
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_hbm_traffic.json")))[-1]  # (the file bench.py would attach)
+    tj = json.load(open(latest))
+    assert tj.get("kernel_tree") == h, f"{latest} was taken on other kernel sources: re-run tools/make_profiles.sh and commit its summaries"
+    assert {"gemm", "gemm_small", "conv3d", "attention", "layernorm"} <= set(tj["per_class_bytes_per_launch"])
