@@ -41,7 +41,7 @@ typedef void* l4p_stream; /* hipStream_t */
 typedef struct l4p_engine l4p_engine;
 
 const char* l4p_last_error(void);
-int l4p_abi_version(void); /* 5: l4p_layernorm_res(out_stats), l4p_layernorm_chain, l4p_stream_create_cu_mask; 4: l4p_gemm_desc.o_gs, l4p_i2t_delta,
+int l4p_abi_version(void); /* 6: l4p_set_knob / l4p_get_knob; 5: l4p_layernorm_res(out_stats), l4p_layernorm_chain, l4p_stream_create_cu_mask; 4: l4p_gemm_desc.o_gs, l4p_i2t_delta,
                               * l4p_t2i_probs, l4p_t2i_context; 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs,
                               * l4p_t2i_attn_scores, l4p_split_hilo, l4p_transpose_pad */
 
@@ -49,6 +49,14 @@ int l4p_abi_version(void); /* 5: l4p_layernorm_res(out_stats), l4p_layernorm_cha
  * long-video path (l4p_amd/parallel.py): the tracker recursion's small dependent kernels on a slice of the chip of their own. */
 int l4p_stream_create_cu_mask(int first_cu, int n_cus, l4p_stream* out);
 int l4p_stream_destroy(l4p_stream stream);
+
+/* Dispatch knobs of the launchers (A/B and test aids; the defaults are the shipped configuration).  A knob starts from its
+ * environment variable (read ONCE, at first use) and can be changed at run time through l4p_set_knob - no getenv on a launch path.
+ *   "conv_halo"  (L4P_CONV_HALO, default 1): 0 = implicit-GEMM forms for every 3x3x3 conv, 1 = the LDS-halo kernel where it fits
+ *   "gemm_4w"    (L4P_GEMM_4W,   default 0): the two-workgroups-per-CU GEMM: 0 never, 1 on the shapes it won, 2 wherever it fits
+ * l4p_set_knob returns L4P_E_INVALID for an unknown name; l4p_get_knob returns the current value (or -1). */
+int l4p_set_knob(const char* name, int value);
+int l4p_get_knob(const char* name);
 
 /* Optional per-kernel-class timing: when enabled every kernel launch is bracketed by a HIP event pair
  * recorded on the launch stream (bench.py's live roofline numbers).  Classes: gemm, conv3d, attention,
@@ -145,7 +153,8 @@ typedef struct l4p_gemm_desc {
      * multiply their OWN weight matrix W + g * w_gs (elements, same ldw) and add their own bias row bias + g * b_gs (b_gs = 0: one
      * bias for all groups).  The tracker's image -> token attention with the projections folded into the token side
      * (sparse_heads.py / sam/transformer.py:180-185, see l4p_amd/models/task_heads/sparse_heads.py): every track's 2048 key rows
-     * meet that track's 48 x 1408 folded key matrix, then its 1408 x 48 folded value matrix. */
+     * meet that track's 48 x 1408 folded key matrix, then its 1408 x 48 folded value matrix.  A group's matrix needs exactly N rows
+     * (tile rows past N re-read row N - 1); the plain (w_gr = 0) path reads whole tiles: W padded to a multiple of 128 rows. */
     int w_gr;
     long long w_gs;
     int b_gs;

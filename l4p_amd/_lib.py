@@ -87,6 +87,8 @@ SIGNATURES = {
     "l4p_abi_version": (_I, []),
     "l4p_stream_create_cu_mask": (_I, [_I, _I, C.POINTER(C.c_void_p)]),
     "l4p_stream_destroy": (_I, [_VP]),
+    "l4p_set_knob": (_I, [C.c_char_p, _I]),
+    "l4p_get_knob": (_I, [C.c_char_p]),
     "l4p_prof_enable": (_I, [_I]),
     "l4p_prof_reset": (_I, []),
     "l4p_prof_num_classes": (_I, []),
@@ -197,6 +199,11 @@ def kernel_tree_hash() -> str:
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def set_knob(name: str, value: int) -> None:
+    """Dispatch knob of the native launchers (include/l4p_hip.h: "conv_halo", "gemm_4w")."""
+    check(load().l4p_set_knob(name.encode(), int(value)), f"l4p_set_knob({name})")
 
 
 def check(rc: int, what: str = "") -> None:

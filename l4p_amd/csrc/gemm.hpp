@@ -811,6 +811,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p_in, const int wg_i
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
         int n = n0 + crow + i * (NT / 8);
+        // (plain weights are packed with rows padded to the tile, packing.py; a GROUP's matrix has exactly N rows and the next
+        //  group's - or nothing - behind them: rows past N re-read row N - 1, their outputs are discarded by the epilogue)
+        if constexpr (GROUPW) n = n < p.N ? n : p.N - 1;
         cs_w[i] = GLDS ? (cc ^ sww(crow + i * (NT / 8))) : cc;
         w_base[i] = (const T*)p.W + (long long)n * p.ldw + cs_w[i] * EPC;
     }

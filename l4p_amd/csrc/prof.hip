@@ -1,6 +1,9 @@
 #include "prof.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -9,6 +12,27 @@
 #include "common.hpp"
 
 bool g_prof_on = false;
+
+namespace {
+struct KnobDef {
+    const char* name;
+    const char* env;
+    int dflt;
+};
+const KnobDef kKnobs[KNOB_NUM] = {{"conv_halo", "L4P_CONV_HALO", 1}, {"gemm_4w", "L4P_GEMM_4W", 0}};
+std::atomic<int> g_knob[KNOB_NUM];
+std::once_flag g_knob_once;
+void knobs_init() {
+    for (int i = 0; i < KNOB_NUM; ++i) {
+        const char* e = getenv(kKnobs[i].env);
+        g_knob[i].store(e ? atoi(e) : kKnobs[i].dflt, std::memory_order_relaxed);
+    }
+}
+}  // namespace
+int knob(int id) {
+    std::call_once(g_knob_once, knobs_init);
+    return g_knob[id].load(std::memory_order_relaxed);
+}
 
 namespace {
 struct Pair {
@@ -50,6 +74,22 @@ void prof_end(int cls, hipStream_t stream) {
 }
 
 extern "C" {
+int l4p_set_knob(const char* name, int value) {
+    std::call_once(g_knob_once, knobs_init);
+    for (int i = 0; i < KNOB_NUM; ++i)
+        if (name && !strcmp(name, kKnobs[i].name)) {
+            g_knob[i].store(value, std::memory_order_relaxed);
+            return L4P_OK;
+        }
+    l4p_set_error("l4p_set_knob: unknown knob '%s'", name ? name : "(null)");
+    return L4P_E_INVALID;
+}
+int l4p_get_knob(const char* name) {
+    for (int i = 0; i < KNOB_NUM; ++i)
+        if (name && !strcmp(name, kKnobs[i].name)) return knob(i);
+    return -1;
+}
+
 int l4p_prof_enable(int on) {
     g_prof_on = on != 0;
     return 0;

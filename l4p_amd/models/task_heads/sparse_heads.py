@@ -551,6 +551,10 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 pool[0].wait_event(start)               # queued on it so far
                 with torch.cuda.stream(pool[0]):
                     traj_all, vis_all, dep_all = output_buffers()
+                # allocated on a clip stream, handed to the launching stream's consumers after the join: the allocator must not
+                # hand the blocks out again (to pool[0]) while work queued on the launching stream still reads them
+                for t in (traj_all, vis_all, dep_all):
+                    t.record_stream(main)
             for b in range(B):
                 if start is None:
                     pool[b].wait_stream(main)

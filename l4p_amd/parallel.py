@@ -308,14 +308,11 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
       x3  all-gather of the query shards
     The arithmetic is that of decode_local_windows + stitch_gathered_windows (the emulated-rank tests compare against those);
     only the order in which independent work is issued differs: the tracker no longer waits for the decoders.
-    Why J comes before 3 (L4P_TRACK_BESIDE_STITCH=1 moves it behind): with the recursion still running on its stream, the seam
-    alignment's small kernels were NOT reproducible - one quarter wave (lanes 48-63) of l4p_point_map_samples' broadcast loads
-    of a pose row read zeros, a few times per hundred launches, which moved RANSAC inlier sets (tests/test_sharded_windows_gpu.py
-    caught it: depth / pose of the 31-window stitch differed run to run).  Not reproduced beside any single tracker kernel family,
-    beside torch kernels or beside hipMemset traffic, and the tracker writes no byte outside its own buffers (canary test over
-    the whole allocator pool): tools/probes/race_c5*.py hold the diagnosis so far.  Until it is explained the alignment runs
-    with the GPU to itself, as it always did; the large decoder kernels beside the tracker are what the c3 step has run since
-    round 2 (bit-identical to the serial order in every comparison made)."""
+    J comes before 3 by default; L4P_TRACK_BESIDE_STITCH=1 moves it behind (the seam alignment beside the still-running recursion).
+    Round 4 saw the alignment's pointmap kernel compute zeros in that schedule and kept the two apart; round 5 found the cause - a
+    gfx950 interaction between MFMAs of one wave and packed-FP32 instructions with a swizzled src1 of another wave on the same SIMD
+    (csrc/common.hpp, tools/check_isa.py) - and removed the affected instruction form from the library, so both orders are
+    reproducible now (tests/test_stream_overlap_gpu.py)."""
     if rank is None or world is None:
         on = dist.is_available() and dist.is_initialized()
         rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
@@ -331,8 +328,13 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
     trk, trk_out = None, None
     try:
         lasts, ready = None, None
+        d_trk, nq_local = None, 0
         if track:
             lasts = all_gather_windows(local_last_features(groups, B), nwin, rank, world)
+            # the query shard is cut BEFORE `ready` is recorded: for B > 1 the [:, q0:q1] slices are copies, and their copy kernels
+            # must sit in front of the event the tracker's streams wait for - not behind the decoders queued below, where the
+            # tracker would read the shard before it exists (round-4 advisor finding)
+            d_trk, nq_local = shard_track_inputs(data, rank, world)
             if net.device.type == "cuda":
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream())
@@ -345,7 +347,6 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
         local = decode_encoded_windows_on(dec_stream, net, data, tasks, groups) if dense else None
         del groups
         if track:
-            d_trk, nq_local = shard_track_inputs(data, rank, world)
             if nq_local > 0:
                 trk = net.task_heads["track_2d"]
                 if hasattr(trk, "join_streams"):

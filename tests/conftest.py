@@ -19,3 +19,19 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def knob():
+    """Set a dispatch knob of the native launchers for one test (l4p_set_knob) and restore it afterwards."""
+    from l4p_amd import _lib
+
+    saved = {}
+
+    def set_(name: str, value: int) -> None:
+        saved.setdefault(name, int(_lib.load().l4p_get_knob(name.encode())))
+        _lib.set_knob(name, value)
+
+    yield set_
+    for name, value in saved.items():
+        _lib.set_knob(name, value)

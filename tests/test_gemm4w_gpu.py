@@ -2,7 +2,7 @@
 descriptors, 64-deep k-tiles, A double- and W single-buffered in 80 KB of LDS) against plain PyTorch fp32 on the same bf16-rounded inputs, at the shapes the bench runs on it
 and at the edges of its pipeline (1, 2, 3, 5.5, 18.4 k-tiles: K not a multiple of 64 reads its tail through the descriptor's range
 check; ragged M / N; row maps; every epilogue family it can be handed).
-The tests are tests/test_gemm8p_gpu.py's own bodies with the launcher forced onto this form (L4P_GEMM_4W=2) and the profiler tag
+The tests are tests/test_gemm8p_gpu.py's own bodies with the launcher forced onto this form (l4p_set_knob("gemm_4w", 2)) and the profiler tag
 asserted to be " 4w ".  Reference call sites: modeling_finetune.py:169-190,62-69, sam/transformer.py:223-245,
 mask_decoder.py:58-66,136-139."""
 import pytest
@@ -16,8 +16,8 @@ from tests.test_kernels_gpu import as_mode, check, rnd
 
 
 @pytest.fixture(autouse=True)
-def _force_4w(monkeypatch):
-    monkeypatch.setenv("L4P_GEMM_4W", "2")
+def _force_4w(monkeypatch, knob):
+    knob("gemm_4w", 2)
     monkeypatch.setattr(t8, "FORM_TAG", " 4w ")
 
 
@@ -60,7 +60,7 @@ def test_gemm4w_maskdot_large(dev):
     t8.test_gemm8p_maskdot_large(dev)
 
 
-def test_gemm4w_equals_8p_bitwise_and_is_deterministic(dev, monkeypatch):
+def test_gemm4w_equals_8p_bitwise_and_is_deterministic(dev, monkeypatch, knob):
     """Same k order inside a tile (ascending k, one accumulator per output) on both forms: the float outputs agree bit for bit,
     and two launches of the 4w form agree with each other (no inter-workgroup dependence)."""
     M, N, K = 8192, 4608, 1408
@@ -73,7 +73,7 @@ def test_gemm4w_equals_8p_bitwise_and_is_deterministic(dev, monkeypatch):
         _, y2 = ops.gemm(a, wp, N, bias=bias, out_f32=True, out_T=True)
     p.assert_8p()
     assert sum(int(ln[2]) for ln in p.lines if ln[0] == "gemm") == 2, p.lines
-    monkeypatch.setenv("L4P_GEMM_4W", "0")
+    knob("gemm_4w", 0)
     monkeypatch.setattr(t8, "FORM_TAG", " 8p ")
     with t8.prof_tags() as p:
         _, y8 = ops.gemm(a, wp, N, bias=bias, out_f32=True, out_T=True)

@@ -295,8 +295,8 @@ def _conv_rows_reference(x_ref, w_ref, bias, rows, stride=(1, 1, 1)):
 @pytest.mark.parametrize("shape,cout", [((4, 16, 64, 64, 256), 256),   # refinenet RCU convs of a B = 4 step: K = 6912
                                          ((4, 16, 32, 32, 512), 256),   # layer_rn: K = 13824
                                          ((2, 16, 56, 56, 256), 256)])  # plane 3136 = 12.25 tiles: walk falls back, ragged rows
-def test_gemm8p_conv3d(dev, shape, cout, monkeypatch):
-    monkeypatch.setenv("L4P_CONV_HALO", "0")  # the implicit-GEMM form (the LDS-halo kernel has its own tests below)
+def test_gemm8p_conv3d(dev, shape, cout, knob):
+    knob("conv_halo", 0)  # the implicit-GEMM form (the LDS-halo kernel has its own tests below)
     B, T, H, W, Cin = shape
     x, x_ref = as_mode(rnd(shape, 70), MODE)
     w = rnd((cout, Cin, 3, 3, 3), 71, (27 * Cin) ** -0.5)
@@ -380,7 +380,7 @@ def test_conv3_halo(dev, shape, cout, act, res):
     assert float(rms.min()) > 0.05 * float(rms.mean())  # (a block that was never written, or written at the wrong voxels)
 
 
-def test_conv3_halo_equals_implicit_gemm_form(dev, monkeypatch):
+def test_conv3_halo_equals_implicit_gemm_form(dev, knob):
     """Same arithmetic, different data movement: on the same inputs the LDS-halo kernel and the implicit-GEMM kernel agree to
     the summation-order level (the k order differs: channel slice outermost vs tap outermost) on EVERY output voxel."""
     shape, cout = (2, 8, 64, 64, 256), 256
@@ -392,7 +392,7 @@ def test_conv3_halo_equals_implicit_gemm_form(dev, monkeypatch):
     with prof_tags() as p:
         a = ops.conv3d_k3(x, wp, cout, bias=bias)
     _assert_halo(p)
-    monkeypatch.setenv("L4P_CONV_HALO", "0")
+    knob("conv_halo", 0)
     with prof_tags() as p:
         b = ops.conv3d_k3(x, wp, cout, bias=bias)
     assert all(" halo " not in ln[1] for ln in p.lines)
