@@ -42,7 +42,14 @@ from l4p_amd.packing import pack_state_dict  # noqa: E402
 from l4p_amd.parallel import broadcast_weights, collective_selftest, init_distributed  # noqa: E402
 from l4p_amd.weights import ModelCfg, actpost_of, fusion_of, seeded_state_dict  # noqa: E402
 
-PEAK_BF16_MFMA = 2.5e15  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_BF16_MFMA = 2.5e15  # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_MFMA = 157.3e12  # f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): the vector rate, 1/16 of the 16-bit peak
+# --precision: the engine's arithmetic / storage type.  "bf16" is what BASELINE.json's configs name (the default, the driver's line);
+# "16-mixed" = IEEE half, the mode the reference's own demo ships (Fabric "16-mixed" = fp16 autocast); "32-true" = the exact-f32
+# parity engine, priced against the f32 MFMA peak.
+PRECISION = {"bf16": ("bf16", torch.bfloat16, PEAK_BF16_MFMA), "16-mixed": ("f16", torch.float16, PEAK_BF16_MFMA),
+             "32-true": ("f32", torch.float32, PEAK_F32_MFMA)}
+ENGINE_PRECISION = "bf16"  # set from --precision in main()
 ALL_TASKS = ["flow_2d_backward", "track_2d", "depth", "dyn_mask", "camray"]
 
 
@@ -221,7 +228,7 @@ def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 0, sample_queri
 def build_workload(tasks, B, nq, device, rank=0, frames=16, same_data=False, use_intrinsics=None):
     """Model (name-seeded random weights, packed on rank 0 and broadcast once) + one synthetic batch of B clips."""
     cfg = ModelCfg.full()
-    model = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision="bf16")
+    model = build_model(os.path.join(ROOT, "configs", "model.yaml"), precision=ENGINE_PRECISION)
     net = model.l4p_model
     net.task_heads = torch.nn.ModuleDict({t: net.task_heads[t] for t in tasks})
     if "camray" in tasks and use_intrinsics is not None:
@@ -231,7 +238,7 @@ def build_workload(tasks, B, nq, device, rank=0, frames=16, same_data=False, use
     sd, pw = None, None
     if rank == 0:
         sd = seeded_state_dict(cfg, tasks=tasks)
-        pw = pack_state_dict(sd, cfg, torch.bfloat16, device, tasks=tasks)
+        pw = pack_state_dict(sd, cfg, PRECISION[ENGINE_PRECISION][1], device, tasks=tasks)
     pw = broadcast_weights(pw, device)  # RCCL over xGMI, once
     net.set_weights(pw)
 
@@ -474,14 +481,14 @@ def bench_demo(args, rank, world, device, lib, selftest):
         "metric": "frames/sec (depth + flow + motion-seg + 2D/3D tracks), 64-frame 224x224 clip, 625 track queries",
         "value": round(world * T_out * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded 480x854 video, name-seeded random weights)",
+        "vs_baseline": None, "dtype": PRECISION[ENGINE_PRECISION][0], "data": "synthetic (seeded 480x854 video, name-seeded random weights)",
         "rccl_ranks": selftest["ranks"] if selftest.get("backend") == "nccl" else (1 if world == 1 else 0),
         "config": {"workload": f"demo generic video (demo/demo.py:84-100): 1 clip of {T_out} frames = {nwin} windows per GPU, tasks "
                                f"{'+'.join(DEMO_TASKS)}, {nq} grid queries in chunks of {net.task_heads['track_2d'].max_queries}, windows batched {net.window_batch} at a time",
                    "queries": nq, "windows": nwin, "tasks": DEMO_TASKS},
         "roofline": {"kernel": {"gemm": "gemm8p_kernel<0> / gemm_kernel<bf16,MODE0>", "conv3d": "gemm8p_kernel<1> / gemm_kernel<bf16,MODE1>",
                                 "attention": "attn_kernel<bf16,96,64>"}[dom], "bound": "mfma", "achieved": classes[dom]["tflops"],
-                     "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(classes[dom]["tflops"] / (PEAK_BF16_MFMA / 1e12), 4),
+                     "peak": PRECISION[ENGINE_PRECISION][2] / 1e12, "unit": "TFLOP/s", "frac": round(classes[dom]["tflops"] / (PRECISION[ENGINE_PRECISION][2] / 1e12), 4),
                      "traffic": None, "method": "algorithmic FLOPs / HIP-event-bracketed kernel time, second pass of the same K steps",
                      "algorithmic_flops_per_step": fl[dom] * nwin},
         "kernel_classes": classes,
@@ -502,9 +509,13 @@ def main():
                                                                   "the shipped use_intrinsics=false (K estimated from the ray map)")
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--group", type=int, default=16, help="c5: windows batched through encoder + dense decoders per launch group (16: whole rounds of 256x256 tiles in the encoder linears; 4 -> 16: +6.8 % on one GPU)")
+    ap.add_argument("--precision", default="bf16", choices=sorted(PRECISION), help="engine dtype: bf16 (BASELINE.json's configs; default), "
+                    "16-mixed (IEEE half: the reference demo's own mode), 32-true (exact-f32 parity engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     args = ap.parse_args()
+    global ENGINE_PRECISION
+    ENGINE_PRECISION = args.precision
 
     rank, world, local = init_distributed()
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
@@ -580,13 +591,13 @@ def main():
                   "frames/sec (depth head only), 16x224x224 clip; encoder MFMA-roofline %",
         "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if c5 else "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (randn clips, name-seeded random weights of the VideoMAE-v2-giant + DPT geometry)",
+        "dtype": PRECISION[ENGINE_PRECISION][0], "data": "synthetic (randn clips, name-seeded random weights of the VideoMAE-v2-giant + DPT geometry)",
         "rccl_ranks": selftest["ranks"] if selftest.get("backend") == "nccl" else (1 if world == 1 else 0),
         "rccl_selftest": None if world == 1 else selftest,
-        "config": {"workload": ("configs[1]: single MI355X, depth head only, bf16, batch=1 16-frame 224x224 clip" if args.workload == "c2"
+        "config": {"workload": (f"configs[1]: single MI355X, depth head only, {PRECISION[ENGINE_PRECISION][0]}, batch=1 16-frame 224x224 clip" if args.workload == "c2"
                                  else f"configs[4]: one {args.frames}-frame video -> {(args.frames - 16) // 8 + 1} overlapping 16-frame windows sharded over the ranks, all heads, on-GPU pose / window alignment, {args.queries} track queries" if c5
-                                 else (f"configs[2]: single MI355X, all heads (depth+flow+track2d/3d+motion-seg+pose), bf16, batch={B} clips, {args.queries} track queries per clip" if world == 1
-                                       else f"configs[3]: {world}xMI355X data-parallel over clips, all heads, bf16, batch={world * B} clips ({B} per GPU), {args.queries} track queries per clip, RCCL weight broadcast")),
+                                 else (f"configs[2]: single MI355X, all heads (depth+flow+track2d/3d+motion-seg+pose), {PRECISION[ENGINE_PRECISION][0]}, batch={B} clips, {args.queries} track queries per clip" if world == 1
+                                       else f"configs[3]: {world}xMI355X data-parallel over clips, all heads, {PRECISION[ENGINE_PRECISION][0]}, batch={world * B} clips ({B} per GPU), {args.queries} track queries per clip, RCCL weight broadcast")),
                    "clips_per_gpu_per_step": B, "tasks": tasks,
                    "camray_use_intrinsics": bool(args.use_intrinsics) if "camray" in tasks else None,
                    "parallelism": (f"windows sharded over {world} rank(s); all-gather of the last-layer features after the encoders, query-sharded tracker beside the decoders, all-gather of the decoded windows, stitching replicated" if c5
@@ -657,8 +668,9 @@ def main():
 
         def roof(k):
             a = classes[k]["tflops"]
-            return {"kernel": kern[k], "bound": "mfma", "achieved": a, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
-                    "frac": round(a / (PEAK_BF16_MFMA / 1e12), 4), "traffic": traffic.get(k),
+            peak = PRECISION[ENGINE_PRECISION][2] / 1e12
+            return {"kernel": kern[k], "bound": "mfma", "achieved": a, "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(a / peak, 4), "traffic": traffic.get(k),
                     "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this command): {traffic_note}",
                     "method": "algorithmic FLOPs / HIP-event-bracketed kernel time, second pass of the same K steps",
                     "avg_launch_us": classes[k]["avg_launch_us"], "launches_per_step": classes[k]["launches_per_step"],

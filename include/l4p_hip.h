@@ -17,7 +17,8 @@
  *    hipStream_t, NULL = default stream).  No hidden synchronisation, no allocation.
  *  - dtype selects the arithmetic/storage type T of activations and weights: L4P_BF16 (bf16 storage,
  *    bf16 MFMA, f32 accumulate; residual stream, LayerNorm and softmax statistics always f32) or
- *    L4P_F32 (f32 storage, exact-f32 MFMA) — the parity mode.
+ *    L4P_F32 (f32 storage, exact-f32 MFMA) — the parity mode; L4P_F16: as L4P_BF16 with IEEE half in place of bf16
+ *    (3 more mantissa bits, 5-bit exponent: the arithmetic class of the reference's fp16 autocast).
  */
 #ifndef L4P_HIP_H
 #define L4P_HIP_H
@@ -31,6 +32,7 @@ extern "C" {
 
 #define L4P_BF16 0
 #define L4P_F32 1
+#define L4P_F16 2 /* IEEE half storage + f16 MFMA, f32 accumulate: what the reference's shipped "16-mixed" (fp16 autocast) computes in */
 
 #define L4P_OK 0
 #define L4P_E_INVALID (-1) /* bad argument / unsupported shape */
@@ -41,7 +43,7 @@ typedef void* l4p_stream; /* hipStream_t */
 typedef struct l4p_engine l4p_engine;
 
 const char* l4p_last_error(void);
-int l4p_abi_version(void); /* 6: l4p_set_knob / l4p_get_knob; 5: l4p_layernorm_res(out_stats), l4p_layernorm_chain, l4p_stream_create_cu_mask; 4: l4p_gemm_desc.o_gs, l4p_i2t_delta,
+int l4p_abi_version(void); /* 7: L4P_F16; 6: l4p_set_knob / l4p_get_knob; 5: l4p_layernorm_res(out_stats), l4p_layernorm_chain, l4p_stream_create_cu_mask; 4: l4p_gemm_desc.o_gs, l4p_i2t_delta,
                               * l4p_t2i_probs, l4p_t2i_context; 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs,
                               * l4p_t2i_attn_scores, l4p_split_hilo, l4p_transpose_pad */
 

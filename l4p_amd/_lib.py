@@ -12,6 +12,7 @@ from typing import Optional
 
 L4P_BF16 = 0
 L4P_F32 = 1
+L4P_F16 = 2  # IEEE half storage / f16 MFMA: the arithmetic class of the reference's "16-mixed" (fp16 autocast)
 
 EPI_DENSE, EPI_QKV, EPI_CONVT, EPI_MASKDOT = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

@@ -29,7 +29,7 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
 extern "C" {
 
 const char* l4p_last_error(void) { return g_err; }
-int l4p_abi_version(void) { return 6; }
+int l4p_abi_version(void) { return 7; }
 
 // A HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (hipExtStreamCreateWithCUMask): the sharded long-video path
 // gives the tracker's latency-bound kernel chain a slice of the chip of its own, beside the chip-filling decoders on the rest.
@@ -115,7 +115,7 @@ int l4p_rays_to_pose_rot(l4p_stream stream, const float* rays, const float* R, f
 // engine
 // ---------------------------------------------------------------------------------------------
 int l4p_create(int device, int dtype, l4p_engine** out) {
-    if (!out || (dtype != L4P_BF16 && dtype != L4P_F32)) {
+    if (!out || !dtype_ok(dtype)) {
         l4p_set_error("l4p_create: bad arguments");
         return L4P_E_INVALID;
     }
@@ -179,7 +179,7 @@ struct EncWs {
 static int enc_fc2_splitk(const l4p_engine* e, size_t M) {
     const l4p_encoder_cfg& c = e->enc;
     const size_t tiles = ((M + 127) / 128) * (((size_t)c.dim + 63) / 64);
-    if (!(e->dtype == L4P_BF16 && tiles < 512 && c.mlp_hidden >= 4096)) return 1;
+    if (!(is16(e->dtype) && tiles < 512 && c.mlp_hidden >= 4096)) return 1;
     static const int env8 = getenv("L4P_FC2_SPLITK8") ? atoi(getenv("L4P_FC2_SPLITK8")) : -1;  // (A/B aid: 0 = the 2-slice form, n = n slices)
     const bool no8 = env8 == 0;
     const size_t t8 = ((M + 255) / 256) * (((size_t)c.dim + 255) / 256);
@@ -189,7 +189,7 @@ static int enc_fc2_splitk(const l4p_engine* e, size_t M) {
 }
 static EncWs enc_layout(const l4p_engine* e, int B, char* base) {
     const l4p_encoder_cfg& c = e->enc;
-    const size_t es = e->dtype == L4P_BF16 ? 2 : 4;
+    const size_t es = esize_of(e->dtype);
     const size_t M = (size_t)B * e->enc_tokens;
     const size_t wide = (size_t)(c.dim > c.patch_kp ? c.dim : c.patch_kp);
     EncWs w;
@@ -233,7 +233,7 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
     hipStream_t stream = (hipStream_t)stream_;
     const l4p_encoder_cfg& c = e->enc;
     const int dt = e->dtype;
-    const size_t es = dt == L4P_BF16 ? 2 : 4;
+    const size_t es = esize_of(dt);
     const int S = e->enc_tokens, M = B * S, C = c.dim, H = c.heads, Dh = c.head_dim, Dp = 96;
     EncWs w = enc_layout(e, B, (char*)workspace);
     if (ws_bytes < w.total) {
@@ -319,7 +319,7 @@ int l4p_encoder_forward(l4p_engine* e, l4p_stream stream_, const float* rgb, int
     // bias + product in the engine dtype, which is what the reference's autocast linear returns before the float sum.
     // L4P_ENC_DEFER_RES=0: the fused-epilogue form (A/B aid).  The float engine keeps the fused form.
     static const int defer_env = getenv("L4P_ENC_DEFER_RES") ? atoi(getenv("L4P_ENC_DEFER_RES")) : 1;
-    const bool defer = dt == L4P_BF16 && defer_env != 0 && C % 4 == 0 && C <= 1536;
+    const bool defer = is16(dt) && defer_env != 0 && C % 4 == 0 && C <= 1536;
     void* const delta = w.qk;  // [M][C] engine dtype, in the q / k slot (free between the attention and the next QKV projection)
     static const int sk_in_ln = getenv("L4P_ENC_SK_IN_LN") ? atoi(getenv("L4P_ENC_SK_IN_LN")) : 1;  // (0: finish pass, A/B aid)
     bool pending = false;

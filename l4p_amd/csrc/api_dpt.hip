@@ -246,7 +246,7 @@ size_t l4p_dpt_workspace_bytes(const l4p_engine* e, const l4p_dpt_cfg* cfg, int 
     c.e = e;
     c.st = nullptr;
     c.dt = e->dtype;
-    c.es = e->dtype == L4P_BF16 ? 2 : 4;
+    c.es = esize_of(e->dtype);
     c.B = B;
     c.ws = Bump{nullptr, 0, 0, true};
     c.dry = true;
@@ -265,7 +265,7 @@ int l4p_dpt_forward(l4p_engine* e, l4p_stream stream, const char* task, const l4
     c.e = e;
     c.st = (hipStream_t)stream;
     c.dt = e->dtype;
-    c.es = e->dtype == L4P_BF16 ? 2 : 4;
+    c.es = esize_of(e->dtype);
     c.B = B;
     c.ws = Bump{(char*)workspace, 0, ws_bytes, false};
     c.pre = std::string("dpt.") + task + ".";

@@ -369,7 +369,7 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
                 // with K' rounded ONCE to bf16 the folded form is already as close to f32 as the projected form (traj 3e-4, depth
                 // 6e-3 per track, both forms) - the pair changes nothing and is off (L4P_TRACK_FOLD_PAIR=1 turns it on).
                 static const bool pair_env = getenv("L4P_TRACK_FOLD_PAIR") && atoi(getenv("L4P_TRACK_FOLD_PAIR")) == 1;
-                const bool pair = pair_env && c.dt == L4P_BF16;
+                const bool pair = pair_env && is16(c.dt);
                 const int NS = pair ? 2 * HT : HT;               // score columns
                 float* kf32 = pair ? c.f32(6ll * N, (int)KW) : nullptr;
                 void* kf = c.T((long long)N * NS + 128, Cc);     // K' [N][NS][C] (+ slack rows under the last tile)
@@ -406,7 +406,7 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
                     }
                     if (!c.rc) c.rc = launch_i2t_probs(c.dt, sc, NS, pair ? 1 : 0, cf, P, pr, HTp, NP, g.sam_heads, 6, c.st);
                     static const bool delta_env = !(getenv("L4P_TRACK_DELTA_KERNEL") && atoi(getenv("L4P_TRACK_DELTA_KERNEL")) == 0);
-                    if (!c.rc && delta_env && c.dt == L4P_BF16 && HTp == 64 && Cc % 128 == 0 && P % 16 == 0) {
+                    if (!c.rc && delta_env && is16(c.dt) && HTp == 64 && Cc % 128 == 0 && P % 16 == 0) {
                         // (its own streaming kernel, bit-identical to the GEMM below: see i2t_delta_kernel)
                         c.rc = launch_i2t_delta(c.dt, pr, vt, c.Wf(lo + "i2t.out.b"), delta, N, P, Cc, HTp, c.st);
                     } else if (!c.rc) {
@@ -588,7 +588,7 @@ size_t l4p_track_window_workspace_bytes(const l4p_engine* e, const l4p_track_cfg
     c.e = e;
     c.st = nullptr;
     c.dt = e->dtype;
-    c.es = e->dtype == L4P_BF16 ? 2 : 4;
+    c.es = esize_of(e->dtype);
     c.ws = Stack{nullptr, 0, 0, 0, true};
     c.dry = true;
     run(c, *cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, 1, hist_uniform, nullptr, nullptr, nullptr, nullptr);
@@ -608,7 +608,7 @@ int l4p_track_window_forward(l4p_engine* e, l4p_stream stream, const l4p_track_c
     c.e = e;
     c.st = (hipStream_t)stream;
     c.dt = e->dtype;
-    c.es = e->dtype == L4P_BF16 ? 2 : 4;
+    c.es = esize_of(e->dtype);
     const size_t mis = (size_t)((uintptr_t)workspace & 255);
     char* base = (char*)workspace + (mis ? 256 - mis : 0);
     c.ws = Stack{base, 0, ws_bytes - (mis ? 256 - mis : 0), 0, false};

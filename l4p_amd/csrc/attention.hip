@@ -32,10 +32,13 @@
 
 __device__ __attribute__((aligned(16))) static const unsigned short g_ones_bf16[8] = {0x3F80, 0x3F80, 0x3F80, 0x3F80,
                                                                                          0x3F80, 0x3F80, 0x3F80, 0x3F80};
+__device__ __attribute__((aligned(16))) static const unsigned short g_ones_f16[8] = {0x3C00, 0x3C00, 0x3C00, 0x3C00,
+                                                                                        0x3C00, 0x3C00, 0x3C00, 0x3C00};
 __device__ __attribute__((aligned(16))) static const float g_ones_f32[4] = {1.f, 1.f, 1.f, 1.f};
 // K-tile chunk holding head dims DH .. DH+7 (all padding) in the deferred-maximum form: dims DH and DH+1 read as 1.0, so
 // the two bf16 halves of -m that sit in the same dims of Q are added to every score by the QK^T MFMA itself
 __device__ __attribute__((aligned(16))) static const unsigned short g_kone_bf16[8] = {0x3F80, 0x3F80, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) static const unsigned short g_kone_f16[8] = {0x3C00, 0x3C00, 0, 0, 0, 0, 0, 0};
 
 // SPLIT = 2: the workgroup has 8 waves; waves 0-3 walk the even KV blocks and waves 4-7 the odd ones for the
 // SAME 128 query rows, and the two partial (m, O, denominator) states are merged through LDS at the end.
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256 * SPLIT * QS) void attn_kernel(const T* __restr
         vones[i] = d == DH;
         vsrc[i] = (const char*)(vt + (long long)d * S) + vchunk * 16;  // + voff + kb*128
     }
-    const char* ones = ES == 2 ? (const char*)g_ones_bf16 : (const char*)g_ones_f32;
+    const char* ones = std::is_same<T, f16_t>::value ? (const char*)g_ones_f16 : ES == 2 ? (const char*)g_ones_bf16 : (const char*)g_ones_f32;
     // chunk c = tid + 256 i of a K tile is (k-step c / (2 KVB), key (c % (2 KVB)) / 2, half (c & 1) ^ ((key >> 3) & 1))
     bool kpad[K_IT];
 #pragma unroll
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256 * SPLIT * QS) void attn_kernel(const T* __restr
         const int c = tid + 256 * i, key = (c % (2 * KVB)) >> 1;
         kpad[i] = DEFER && (c / (2 * KVB)) * 16 + (((c & 1) ^ ((key >> 3) & 1)) << 3) == DH;
     }
-    const char* kone = (const char*)g_kone_bf16;
+    const char* kone = std::is_same<T, f16_t>::value ? (const char*)g_kone_f16 : (const char*)g_kone_bf16;
     // QS: the 768 chunks of a tile are spread over 512 lanes: chunk gt (all lanes) + one more for half of the waves (K: chunk
     // 512 + gt from waves 0-3; V^T: chunk gt - 256 from waves 4-7, its first pass being chunks 256 + gt) - 3 requests per wave
     const int gt = threadIdx.x, gwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -652,9 +655,9 @@ __global__ __launch_bounds__(256 * SPLIT * QS) void attn_kernel(const T* __restr
         u32x2 pk[NG];
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
-            bf16x4 v;
+            vec4h<T> v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[k >> 2][4 * (k & 3) + e] * inv);
+            for (int e = 0; e < 4; ++e) v[e] = (vec4e<T>)(o[k >> 2][4 * (k & 3) + e] * inv);
             pk[k] = __builtin_bit_cast(u32x2, v);
         }
 #pragma unroll
@@ -674,10 +677,10 @@ __global__ __launch_bounds__(256 * SPLIT * QS) void attn_kernel(const T* __restr
             const int d0 = dt * 32 + 8 * g + 4 * hi;
             if (d0 < DH) {
                 if (ES == 2) {
-                    bf16x4 v;
+                    vec4h<T> v;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = (bf16_t)(o[dt][4 * g + k] * inv);
-                    *(bf16x4*)(op + d0) = v;
+                    for (int k = 0; k < 4; ++k) v[k] = (vec4e<T>)(o[dt][4 * g + k] * inv);
+                    *(vec4h<T>*)(op + d0) = v;
                 } else {
                     *(f32x4*)(op + d0) = (f32x4){o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
                                                  o[dt][4 * g + 3] * inv};
@@ -711,6 +714,26 @@ static int launch_attn_t(const void* q, const void* kt, const void* vt, void* ou
     return 0;
 }
 
+template <typename T16>
+static int launch_attention16(int variant, bool split, const void* q, const void* kt, const void* vt, void* out, int B, int S, int H,
+                              int Dh, float scale, hipStream_t stream) {
+    if (variant != 1) {
+        // query split (8 waves share the K / V^T tiles): when the launch still fills the chip with 256-row workgroups, two per CU
+        const bool qsplit = !split && S % 256 == 0 && (long long)(S / 256) * H * B >= 512 && variant != 2;
+        if (Dh == 88 && qsplit) return launch_attn_t<T16, 64, 88, 1, true, 2>(q, kt, vt, out, B, S, H, scale, stream);
+        if (Dh == 88)
+            return split ? launch_attn_t<T16, 64, 88, 2, true>(q, kt, vt, out, B, S, H, scale, stream)
+                         : launch_attn_t<T16, 64, 88, 1, true>(q, kt, vt, out, B, S, H, scale, stream);
+        return split ? launch_attn_t<T16, 64, 64, 2, true>(q, kt, vt, out, B, S, H, scale, stream)
+                     : launch_attn_t<T16, 64, 64, 1, true>(q, kt, vt, out, B, S, H, scale, stream);
+    }
+    if (Dh == 88)
+        return split ? launch_attn_t<T16, 64, 88, 2>(q, kt, vt, out, B, S, H, scale, stream)
+                     : launch_attn_t<T16, 64, 88, 1>(q, kt, vt, out, B, S, H, scale, stream);
+    return split ? launch_attn_t<T16, 64, 64, 2>(q, kt, vt, out, B, S, H, scale, stream)
+                 : launch_attn_t<T16, 64, 64, 1>(q, kt, vt, out, B, S, H, scale, stream);
+}
+
 // scale = Dh^-0.5 (reference :150)
 int launch_attention(int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, int Dh,
                      float scale, hipStream_t stream) {
@@ -721,23 +744,7 @@ int launch_attention(int dtype, const void* q, const void* kt, const void* vt, v
     // too few workgroups for two per CU (256 CUs): split the KV range over two wave groups inside each workgroup
     const bool split = (long long)(S / 128) * H * B < 512 && (S / 64) % 2 == 0;
     static const int variant = getenv("L4P_ATTN_VARIANT") ? atoi(getenv("L4P_ATTN_VARIANT")) : 0;  // tuning aid: 1 = compiler-scheduled body
-    if (dtype == L4P_BF16 && variant != 1) {
-        // query split (8 waves share the K / V^T tiles): when the launch still fills the chip with 256-row workgroups, two per CU
-        const bool qsplit = !split && S % 256 == 0 && (long long)(S / 256) * H * B >= 512 && variant != 2;
-        if (Dh == 88 && qsplit) return launch_attn_t<bf16_t, 64, 88, 1, true, 2>(q, kt, vt, out, B, S, H, scale, stream);
-        if (Dh == 88)
-            return split ? launch_attn_t<bf16_t, 64, 88, 2, true>(q, kt, vt, out, B, S, H, scale, stream)
-                         : launch_attn_t<bf16_t, 64, 88, 1, true>(q, kt, vt, out, B, S, H, scale, stream);
-        return split ? launch_attn_t<bf16_t, 64, 64, 2, true>(q, kt, vt, out, B, S, H, scale, stream)
-                     : launch_attn_t<bf16_t, 64, 64, 1, true>(q, kt, vt, out, B, S, H, scale, stream);
-    }
-    if (dtype == L4P_BF16) {
-        if (Dh == 88)
-            return split ? launch_attn_t<bf16_t, 64, 88, 2>(q, kt, vt, out, B, S, H, scale, stream)
-                         : launch_attn_t<bf16_t, 64, 88, 1>(q, kt, vt, out, B, S, H, scale, stream);
-        return split ? launch_attn_t<bf16_t, 64, 64, 2>(q, kt, vt, out, B, S, H, scale, stream)
-                     : launch_attn_t<bf16_t, 64, 64, 1>(q, kt, vt, out, B, S, H, scale, stream);
-    }
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, return launch_attention16<T16>(variant, split, q, kt, vt, out, B, S, H, Dh, scale, stream));
     if (Dh == 88) return launch_attn_t<float, 32, 88, 1>(q, kt, vt, out, B, S, H, scale, stream);
     return launch_attn_t<float, 32, 64, 1>(q, kt, vt, out, B, S, H, scale, stream);
 }

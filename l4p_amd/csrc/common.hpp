@@ -7,6 +7,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -27,10 +30,31 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // bijection is the same for both operands, so the contraction is exact either way.
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<f16_t> { typedef f16x8 type; };
 template <> struct Frag<float> { typedef f32x8 type; };
+template <typename T> using vec8 = typename Frag<T>::type;  // 8 consecutive elements of a 16-bit engine type (one MFMA fragment)
+// ... for code shared with the f32 engine whose 16-bit branch is dead there (a 16-byte placeholder keeps it compiling)
+template <typename T> struct Half8 { typedef vec8<T> type; };
+template <> struct Half8<float> { typedef bf16x8 type; };
+template <typename T> using vec8h = typename Half8<T>::type;
+template <typename T> struct Vec4T;
+template <> struct Vec4T<bf16_t> { typedef bf16x4 type; };
+template <> struct Vec4T<f16_t> { typedef f16x4 type; };
+template <typename T> using vec4 = typename Vec4T<T>::type;
+template <> struct Vec4T<float> { typedef bf16x4 type; };  // (placeholder: 16-bit branches that are dead in the f32 engine)
+template <typename T> using vec4h = typename Vec4T<T>::type;
+template <typename T> struct Elem16 { typedef T type; };
+template <> struct Elem16<float> { typedef bf16_t type; };
+template <typename T> using vec4e = typename Elem16<T>::type;  // element type of vec4h<T>
 
 __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mma16(f32x8 a, f32x8 b, f32x4 c) {
 #pragma unroll
@@ -59,6 +83,7 @@ __device__ __forceinline__ f32x16 mma32(f32x8 a, f32x8 b, f32x16 c) {
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 
 // exact (erf) GELU, matches torch.nn.GELU() default
@@ -102,6 +127,25 @@ template <> __device__ __forceinline__ float gelu_for<bf16_t>(float x) { return 
 #else
 template <> __device__ __forceinline__ float gelu_for<bf16_t>(float x) { return gelu_poly(x); }
 #endif
+// (half has three more mantissa bits than bf16: the polynomial's 8e-5 absolute error would be a sixth of its ulp at 1; the
+//  erfc form's 1.5e-7 is not seen)
+template <> __device__ __forceinline__ float gelu_for<f16_t>(float x) { return gelu_erf_fast(x); }
+
+// host side: engine dtype codes (include/l4p_hip.h)
+static inline bool is16(int dtype) { return dtype == L4P_BF16 || dtype == L4P_F16; }
+static inline int esize_of(int dtype) { return dtype == L4P_F32 ? 4 : 2; }
+static inline bool dtype_ok(int dtype) { return dtype == L4P_BF16 || dtype == L4P_F32 || dtype == L4P_F16; }
+// run `...` with T16 = the 16-bit engine type of `dtype` (bf16_t / f16_t); the caller has checked is16(dtype)
+#define L4P_WITH_T16(dtype, T16, ...)      \
+    do {                                   \
+        if ((dtype) == L4P_F16) {          \
+            typedef f16_t T16;             \
+            __VA_ARGS__;                   \
+        } else {                           \
+            typedef bf16_t T16;            \
+            __VA_ARGS__;                   \
+        }                                  \
+    } while (0)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -46,10 +46,9 @@ struct ConvHaloCfg {
     static constexpr int H_PASS = (PRP * 4 + 511) / 512;   // ... per halo plane
 };
 
-template <int WR, int WC>
+template <typename T, int WR, int WC>
 __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
     static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
-    typedef bf16_t T;
     typedef ConvHaloCfg<WR, WC> Cfg;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, TM = 8, TN = 4;
     constexpr int TT = Cfg::TT, TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, PR = Cfg::PR, PRP = Cfg::PRP;
@@ -152,16 +151,16 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 xa[4], wb[4];
+    vec8<T> xa[4], wb[4];
 
     auto read_w = [&](int t) {
         const char* base = wring + (t & 3) * WSLOT + w_off;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wb[j] = *(const bf16x8*)(base + j * 1024);
+        for (int j = 0; j < 4; ++j) wb[j] = *(const vec8<T>*)(base + j * 1024);
     };
     auto read_a = [&](int half, int abase) {  // fragments half * 4 .. + 3; abase = this tap's address of fragment 0
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) xa[ii] = *(const bf16x8*)(smem + abase + (half * 4 + ii) * (HW * 64));
+        for (int ii = 0; ii < 4; ++ii) xa[ii] = *(const vec8<T>*)(smem + abase + (half * 4 + ii) * (HW * 64));
     };
     auto mfma16 = [&](int half) {
         __builtin_amdgcn_s_setprio(1);

@@ -57,7 +57,7 @@ __device__ __forceinline__ void upsample_line(const T* __restrict__ xb, T* __res
                 for (int cc = 0; cc < 2; ++cc) {
                     const T* p = xb + (((long long)ti[a] * Hi + hi[bb]) * Wi + wi[cc]) * C + c;
                     if (sizeof(T) == 2) {
-                        const bf16x8 t = *(const bf16x8*)p;
+                        const vec8h<T> t = *(const vec8h<T>*)p;
 #pragma unroll
                         for (int k = 0; k < V; ++k) v[a][bb][cc][k] = (float)t[k];
                     } else {
@@ -84,13 +84,13 @@ __device__ __forceinline__ void upsample_line(const T* __restrict__ xb, T* __res
                 }
         T* yp = yl + (long long)wo * C + c;
         if (sizeof(T) == 2) {
-            bf16x8 o;
+            vec8h<T> o;
 #pragma unroll
-            for (int k = 0; k < V; ++k) o[k] = (bf16_t)acc[k];
+            for (int k = 0; k < V; ++k) o[k] = (vec4e<T>)acc[k];
             if (NT_STORE)
-                __builtin_nontemporal_store(o, (bf16x8*)yp);
+                __builtin_nontemporal_store(o, (vec8h<T>*)yp);
             else
-                *(bf16x8*)yp = o;
+                *(vec8h<T>*)yp = o;
         } else {
             *(f32x4*)yp = (f32x4){acc[0], acc[1], acc[2], acc[3]};
             *(f32x4*)((float*)yp + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
@@ -139,12 +139,10 @@ int launch_upsample(int dtype, const void* x, void* y, int B, int Ti, int Hi, in
     const dim3 grid(gx, lines < 65535 ? lines : 65535, (lines + 65534) / 65535);
     ProfScope prof(PROF_ELEMENTWISE, stream, "upsample");
     static const int nt = getenv("L4P_UPS_NT") ? atoi(getenv("L4P_UPS_NT")) : 1;
-    if (dtype == L4P_BF16 && nt)
-        hipLaunchKernelGGL((upsample_kernel<bf16_t, true>), grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, B, Ti,
-                           Hi, Wi, To, Ho, Wo, C, align);
-    else if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(upsample_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, B, Ti,
-                           Hi, Wi, To, Ho, Wo, C, align);
+    if (is16(dtype) && nt) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL((upsample_kernel<T16, true>), grid, dim3(256), 0, stream, (const T16*)x, (T16*)y, B, Ti,
+                           Hi, Wi, To, Ho, Wo, C, align));
+    else if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(upsample_kernel<T16>, grid, dim3(256), 0, stream, (const T16*)x, (T16*)y, B, Ti,
+                           Hi, Wi, To, Ho, Wo, C, align));
     else
         hipLaunchKernelGGL(upsample_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)y, B, Ti, Hi,
                            Wi, To, Ho, Wo, C, align);
@@ -176,7 +174,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(const T* __restrict__ x, 
         for (int c0 = 0; c0 < C; c0 += 8) {
             float v[8];
             if (sizeof(T) == 2) {
-                const bf16x8 t = *(const bf16x8*)(xp + c0);
+                const vec8h<T> t = *(const vec8h<T>*)(xp + c0);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
             } else {
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(256) void head_out_lds_kernel(const T* __restrict__
     for (int c0 = 0; c0 < C; c0 += 8) {
         const char* cp = xr + ((((c0 * (int)sizeof(T)) >> 4) ^ (tid & 15)) << 4);  // (bf16: one chunk = 8 channels)
         float v[8];
-        const bf16x8 t = *(const bf16x8*)cp;
+        const vec8h<T> t = *(const vec8h<T>*)cp;
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
 #pragma unroll
@@ -275,13 +273,13 @@ int launch_head_out(int dtype, const void* x, const float* w, const float* bias,
     const long long total = vox_per_b * B;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     ProfScope prof(PROF_ELEMENTWISE, stream, "head_out");
-    if (dtype == L4P_BF16) {
-        auto kern = head_out_lds_kernel<bf16_t, 128>;
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
+        auto kern = head_out_lds_kernel<T16, 128>;
         const size_t lds = (8 * 128 + 8) * 4 + 256 * 256;
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, stream, (const bf16_t*)x, w, bias, y, vox_per_b,
+        hipLaunchKernelGGL(kern, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, stream, (const T16*)x, w, bias, y, vox_per_b,
                            B, Cout, post_exp);
-    } else
+    }); else
         hipLaunchKernelGGL((head_out_kernel<float, 128>), dim3(grid), dim3(256), 0, stream, (const float*)x, w, bias, y,
                            vox_per_b, B, Cout, post_exp);
     HIP_TRY(hipGetLastError());

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
             const int idx = lane + i * 64;
             const bool in = idx < nv;
             if (XT && sizeof(T) == 2) {  // (branch-free: the load is clamped, not predicated, so all slots are requested at once)
-                const bf16x4 t = ((const bf16x4*)((const bf16_t*)x + (long long)row * C))[in ? idx : 0];
+                const vec4h<T> t = ((const vec4h<T>*)((const vec4e<T>*)x + (long long)row * C))[in ? idx : 0];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[r][i][k] = in ? (float)t[k] : 0.f;
             } else {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[r][i][k] += in ? d[k] : 0.f;
                 } else if (sizeof(T) == 2) {
-                    const bf16x4 t = LN_LD((const bf16x4*)((const bf16_t*)delta + (long long)row * C) + (in ? idx : 0));
+                    const vec4h<T> t = LN_LD((const vec4h<T>*)((const vec4e<T>*)delta + (long long)row * C) + (in ? idx : 0));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[r][i][k] += in ? (float)t[k] : 0.f;
                 } else {
@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                 }
                 if (out_T2) {  // T(y + add[row % add_mod]): the "+ positional / + prompt token" operand of the tracker
                     if (sizeof(T) == 2) {
-                        bf16x4 o;
+                        vec4h<T> o;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = (bf16_t)(y[k] + av[r][i][k]);
-                        LN_ST((bf16x4*)((bf16_t*)out_T2 + (long long)row * C) + idx, o);
+                        for (int k = 0; k < 4; ++k) o[k] = (vec4e<T>)(y[k] + av[r][i][k]);
+                        LN_ST((vec4h<T>*)((vec4e<T>*)out_T2 + (long long)row * C) + idx, o);
                     } else {
                         f32x4 o;
 #pragma unroll
@@ -162,10 +162,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                 }
                 if (out_T) {
                     if (sizeof(T) == 2) {
-                        bf16x4 o;
+                        vec4h<T> o;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = (bf16_t)y[k];
-                        LN_ST((bf16x4*)((bf16_t*)out_T + (long long)row * C) + idx, o);
+                        for (int k = 0; k < 4; ++k) o[k] = (vec4e<T>)y[k];
+                        LN_ST((vec4h<T>*)((vec4e<T>*)out_T + (long long)row * C) + idx, o);
                     } else {
                         ((f32x4*)((float*)out_T + (long long)row * C))[idx] = y;
                     }
@@ -201,8 +201,7 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
         return L4P_E_INVALID;
     }
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d add%d T2%d act%d f32%d", M, C, add != nullptr, out_T2 != nullptr, act, out_f32 != nullptr);
-    if (dtype == L4P_BF16)
-        launch_ln<bf16_t>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, launch_ln<T16>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream));
     else
         launch_ln<float>(x, gamma, beta, eps, out_T, out_f32, M, C, add, add_mod, out_T2, act, stream);
     HIP_TRY(hipGetLastError());
@@ -231,14 +230,14 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
     }
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d res T2%d f32%d", M, C, out_T2 != nullptr, out_f32 != nullptr);
     const dim3 grid((M + 3) / 4);
-    if (dtype == L4P_BF16) {
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
         if (C <= 512)
-            hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
+            hipLaunchKernelGGL((layernorm_kernel<T16, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (T16*)out_T,
+                               out_f32, M, C, add, add_mod, (T16*)out_T2, (int)L4P_ACT_NONE, (const T16*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
         else
-            hipLaunchKernelGGL((layernorm_kernel<bf16_t, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (bf16_t*)out_T,
-                               out_f32, M, C, add, add_mod, (bf16_t*)out_T2, (int)L4P_ACT_NONE, (const bf16_t*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
-    } else {
+            hipLaunchKernelGGL((layernorm_kernel<T16, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (T16*)out_T,
+                               out_f32, M, C, add, add_mod, (T16*)out_T2, (int)L4P_ACT_NONE, (const T16*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
+    }); else {
         if (C <= 512)
             hipLaunchKernelGGL((layernorm_kernel<float, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
                                out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
@@ -278,8 +277,8 @@ __global__ __launch_bounds__(256) void layernorm_chain_kernel(const float* __res
         const bool in = idx < nv;
         v[i] = in ? xr[idx] : z;
         if (sizeof(T) == 2) {
-            const bf16x4 t = ((const bf16x4*)((const bf16_t*)dprev + (long long)row * C))[in ? idx : 0];
-            const bf16x4 u = ((const bf16x4*)((const bf16_t*)delta + (long long)row * C))[in ? idx : 0];
+            const vec4h<T> t = ((const vec4h<T>*)((const vec4e<T>*)dprev + (long long)row * C))[in ? idx : 0];
+            const vec4h<T> u = ((const vec4h<T>*)((const vec4e<T>*)delta + (long long)row * C))[in ? idx : 0];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 v[i][k] += in ? (float)t[k] : 0.f;
@@ -338,11 +337,11 @@ __global__ __launch_bounds__(256) void layernorm_chain_kernel(const float* __res
             for (int k = 0; k < 4; ++k) y[k] = ln_affine(v[i][k], mean, rstd, gg[k], bb[k]);
             if (out_f32) ((f32x4*)(out_f32 + (long long)row * C))[idx] = y;
             if (sizeof(T) == 2) {
-                bf16x4 o, o2;
+                vec4h<T> o, o2;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = (bf16_t)y[k], o2[k] = (bf16_t)(y[k] + av[i][k]);
-                if (out_T) ((bf16x4*)((bf16_t*)out_T + (long long)row * C))[idx] = o;
-                if (out_T2) ((bf16x4*)((bf16_t*)out_T2 + (long long)row * C))[idx] = o2;
+                for (int k = 0; k < 4; ++k) o[k] = (vec4e<T>)y[k], o2[k] = (vec4e<T>)(y[k] + av[i][k]);
+                if (out_T) ((vec4h<T>*)((vec4e<T>*)out_T + (long long)row * C))[idx] = o;
+                if (out_T2) ((vec4h<T>*)((vec4e<T>*)out_T2 + (long long)row * C))[idx] = o2;
             } else {
                 if (out_T) ((f32x4*)((float*)out_T + (long long)row * C))[idx] = y;
                 if (out_T2) {
@@ -364,9 +363,8 @@ int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dp
     }
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d chain T2%d f32%d", M, C, out_T2 != nullptr, out_f32 != nullptr);
     const dim3 grid((M + 3) / 4);
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(layernorm_chain_kernel<bf16_t>, grid, dim3(256), 0, stream, xs, x_mod, (const bf16_t*)dprev_T, stats, g0, b0,
-                           (const bf16_t*)delta_T, gamma, beta, eps, (bf16_t*)out_T, out_f32, M, C, add, add_mod, (bf16_t*)out_T2);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(layernorm_chain_kernel<T16>, grid, dim3(256), 0, stream, xs, x_mod, (const T16*)dprev_T, stats, g0, b0,
+                           (const T16*)delta_T, gamma, beta, eps, (T16*)out_T, out_f32, M, C, add, add_mod, (T16*)out_T2));
     else
         hipLaunchKernelGGL(layernorm_chain_kernel<float>, grid, dim3(256), 0, stream, xs, x_mod, (const float*)dprev_T, stats, g0, b0,
                            (const float*)delta_T, gamma, beta, eps, (float*)out_T, out_f32, M, C, add, add_mod, (float*)out_T2);
@@ -377,7 +375,7 @@ int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dp
 // LayerNorm of rows stored in the engine dtype (bf16 engine: bf16 in, bf16 out, possibly in place; f32 engine: the plain kernel)
 int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T, int M, int C,
                        int act, hipStream_t stream) {
-    if (dtype != L4P_BF16)
+    if (!is16(dtype))
         return launch_layernorm_ex(dtype, (const float*)x_T, gamma, beta, eps, out_T, nullptr, M, C, nullptr, 0, nullptr, act, stream);
     if (C % 4 || C > 2048) {
         l4p_set_error("layernorm_T: C=%d must be a multiple of 4 and <= 2048", C);
@@ -386,15 +384,17 @@ int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const flo
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d inT act%d", M, C, act);
     const dim3 grid((M + 3) / 4);
     const float* xf = (const float*)x_T;  // (re-typed inside the kernel)
-    if (C <= 512)
-        hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2, true>), grid, dim3(256), 0, stream, xf, gamma, beta, eps, (bf16_t*)out_T,
-                           (float*)nullptr, M, C, (const float*)nullptr, 0, (bf16_t*)nullptr, act);
-    else if (C <= 1536)
-        hipLaunchKernelGGL((layernorm_kernel<bf16_t, 6, true>), grid, dim3(256), 0, stream, xf, gamma, beta, eps, (bf16_t*)out_T,
-                           (float*)nullptr, M, C, (const float*)nullptr, 0, (bf16_t*)nullptr, act);
-    else
-        hipLaunchKernelGGL((layernorm_kernel<bf16_t, 8, true>), grid, dim3(256), 0, stream, xf, gamma, beta, eps, (bf16_t*)out_T,
-                           (float*)nullptr, M, C, (const float*)nullptr, 0, (bf16_t*)nullptr, act);
+    L4P_WITH_T16(dtype, T16, {
+        if (C <= 512)
+            hipLaunchKernelGGL((layernorm_kernel<T16, 2, true>), grid, dim3(256), 0, stream, xf, gamma, beta, eps, (T16*)out_T,
+                               (float*)nullptr, M, C, (const float*)nullptr, 0, (T16*)nullptr, act);
+        else if (C <= 1536)
+            hipLaunchKernelGGL((layernorm_kernel<T16, 6, true>), grid, dim3(256), 0, stream, xf, gamma, beta, eps, (T16*)out_T,
+                               (float*)nullptr, M, C, (const float*)nullptr, 0, (T16*)nullptr, act);
+        else
+            hipLaunchKernelGGL((layernorm_kernel<T16, 8, true>), grid, dim3(256), 0, stream, xf, gamma, beta, eps, (T16*)out_T,
+                               (float*)nullptr, M, C, (const float*)nullptr, 0, (T16*)nullptr, act);
+    });
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -412,10 +412,10 @@ __global__ void cast_kernel(const float* __restrict__ x, T* __restrict__ y, long
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const f32x4 v = ((const f32x4*)x)[i];
         if (sizeof(T) == 2) {
-            bf16x4 o;
+            vec4h<T> o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (bf16_t)v[k];
-            ((bf16x4*)y)[i] = o;
+            for (int k = 0; k < 4; ++k) o[k] = (vec4e<T>)v[k];
+            ((vec4h<T>*)y)[i] = o;
         } else {
             ((f32x4*)y)[i] = v;
         }
@@ -430,8 +430,7 @@ int launch_cast(int dtype, const float* x, void* y, long long n, hipStream_t str
     const long long n4 = n / 4;
     const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     ProfScope prof(PROF_ELEMENTWISE, stream, "cast");
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, x, (bf16_t*)y, n4);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(cast_kernel<T16>, dim3(grid), dim3(256), 0, stream, x, (T16*)y, n4));
     else
         hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, stream, x, (float*)y, n4);
     HIP_TRY(hipGetLastError());
@@ -484,9 +483,8 @@ int launch_patch_gather(int dtype, const float* rgb, void* out, int B, int Cin, 
     const long long total = (long long)B * (T / pt) * (H / ph) * (W / pw) * Kp;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     ProfScope prof(PROF_ELEMENTWISE, stream, "patch_gather");
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, rgb, (bf16_t*)out, B, Cin, T,
-                           H, W, pt, ph, pw, Kp);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(patch_gather_kernel<T16>, dim3(grid), dim3(256), 0, stream, rgb, (T16*)out, B, Cin, T,
+                           H, W, pt, ph, pw, Kp));
     else
         hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(grid), dim3(256), 0, stream, rgb, (float*)out, B, Cin, T, H,
                            W, pt, ph, pw, Kp);

@@ -305,10 +305,10 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
                     ((((long long)(b * p.H + h) * (p.S / KVB) + kb) * (p.Dp / 16) + ks) * KVB + key) * 2 + (half ^ ((key >> 3) & 1));
                 T* kp = (T*)p.k_tiled + g8 * 8;
                 if (ES == 2) {
-                    bf16x8 o;
+                    vec8h<T> o;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
-                    *(bf16x8*)kp = o;
+                    for (int q = 0; q < 8; ++q) o[q] = (T)vv[q];
+                    *(vec8h<T>*)kp = o;
                 } else {
                     *(f32x4*)kp = (f32x4){vv[0], vv[1], vv[2], vv[3]};
                     *(f32x4*)((float*)kp + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
@@ -333,10 +333,10 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
             if (p.out_relu_T) {  // second output: relu(v) as T (pre-activated input of the next ResidualConvUnit conv)
                 T* op = (T*)p.out_relu_T + off;
                 if (ES == 2) {
-                    bf16x8 o;
+                    vec8h<T> o;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)fmaxf(vv[q], 0.f);
-                    *(bf16x8*)op = o;
+                    for (int q = 0; q < 8; ++q) o[q] = (T)fmaxf(vv[q], 0.f);
+                    *(vec8h<T>*)op = o;
                 } else {
                     *(f32x4*)op = (f32x4){fmaxf(vv[0], 0.f), fmaxf(vv[1], 0.f), fmaxf(vv[2], 0.f), fmaxf(vv[3], 0.f)};
                     *(f32x4*)((float*)op + 4) = (f32x4){fmaxf(vv[4], 0.f), fmaxf(vv[5], 0.f), fmaxf(vv[6], 0.f), fmaxf(vv[7], 0.f)};
@@ -345,13 +345,13 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
             if (p.out_T) {
                 T* op = (T*)p.out_T + off;
                 if (ES == 2) {
-                    bf16x8 o;
+                    vec8h<T> o;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
+                    for (int q = 0; q < 8; ++q) o[q] = (T)vv[q];
 #ifdef GEMM_DBG_NOSTORE  // (tools/probes: epilogue arithmetic without the output traffic)
                     asm volatile("" ::"v"(o), "v"(op));
 #else
-                    *(bf16x8*)op = o;
+                    *(vec8h<T>*)op = o;
 #endif
                 } else {
                     *(f32x4*)op = (f32x4){vv[0], vv[1], vv[2], vv[3]};
@@ -499,7 +499,7 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (ES == 2) {
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, rt[sl][g][0]), b = __builtin_bit_cast(bf16x8, rt[sl][g][1]);
+                        const vec8h<T> a = __builtin_bit_cast(vec8h<T>, rt[sl][g][0]), b = __builtin_bit_cast(vec8h<T>, rt[sl][g][1]);
                         v[8 * g + q] += two ? (float)a[q] + (float)b[q] : (float)a[q];
                     }
                 }
@@ -521,19 +521,19 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
             }
             if (ES == 2) {
                 if (p.out_relu_T) {
-                    bf16x8 o;
+                    vec8h<T> o;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)fmaxf(vv[q], 0.f);
-                    *(bf16x8*)((T*)p.out_relu_T + off + 8 * g) = o;
+                    for (int q = 0; q < 8; ++q) o[q] = (T)fmaxf(vv[q], 0.f);
+                    *(vec8h<T>*)((T*)p.out_relu_T + off + 8 * g) = o;
                 }
                 if (p.out_T) {
-                    bf16x8 o;
+                    vec8h<T> o;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)vv[q];
+                    for (int q = 0; q < 8; ++q) o[q] = (T)vv[q];
 #ifdef GEMM_DBG_NOSTORE
                     asm volatile("" ::"v"(o));
 #else
-                    *(bf16x8*)((T*)p.out_T + off + 8 * g) = o;
+                    *(vec8h<T>*)((T*)p.out_T + off + 8 * g) = o;
 #endif
                 }
             }
@@ -591,14 +591,14 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmParams& p, f32x4 (&a
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (kind[g] < 0) continue;
-            bf16x8 o;
+            vec8h<T> o;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] = (bf16_t)((acc[i][2 * g + q / 4][q % 4] + bv[8 * g + q]) * qs[g]);
+            for (int q = 0; q < 8; ++q) o[q] = (T)((acc[i][2 * g + q / 4][q % 4] + bv[8 * g + q]) * qs[g]);
             if (kind[g] == 0) {
-                *(bf16x8*)((T*)p.out_T + (long long)m * p.ldc + cbase[g]) = o;
+                *(vec8h<T>*)((T*)p.out_T + (long long)m * p.ldc + cbase[g]) = o;
             } else if (kind[g] == 1) {
                 const long long g8 = (cbase[g] + ((long long)b * p.H * (p.S / KVB) + kb) * (p.Dp / 16) * KVB + key) * 2 + (kflip[g] ^ ((key >> 3) & 1));
-                *(bf16x8*)((T*)p.k_tiled + g8 * 8) = o;
+                *(vec8h<T>*)((T*)p.k_tiled + g8 * 8) = o;
             } else {
                 T* vp = (T*)p.vt + (long long)b * p.H * p.Dp * p.S + cbase[g] + s_;
 #pragma unroll
@@ -658,10 +658,10 @@ __device__ __forceinline__ void gemm_epilogue_convt(const GemmParams& p, f32x4 (
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (!gok[g]) continue;
-            bf16x8 o;
+            vec8h<T> o;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] = (bf16_t)(acc[i][2 * g + q / 4][q % 4] + bv[8 * g + q]);
-            *(bf16x8*)((T*)p.out_T + rowoff + coff[g]) = o;
+            for (int q = 0; q < 8; ++q) o[q] = (T)(acc[i][2 * g + q / 4][q % 4] + bv[8 * g + q]);
+            *(vec8h<T>*)((T*)p.out_T + rowoff + coff[g]) = o;
         }
     }
 }

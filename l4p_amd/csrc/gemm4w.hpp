@@ -41,9 +41,8 @@ struct Gemm4wCfg {
 
 // DBG (tools/probes/gemm4w_probe.hip only; 0 in the library): 1 no epilogue, 2 no LDS-DMA in the loop, 4 no fragment reads,
 // 8 no s_setprio
-template <bool SPLITK = false, int DBG = 0, int PSTEP = 3>
+template <typename T, bool SPLITK = false, int DBG = 0, int PSTEP = 3>
 __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const GemmParams p) {
-    typedef bf16_t T;
     typedef Gemm4wCfg Cfg;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, TM = 8, TN = 4;
     constexpr int A_BUF = Cfg::A_BUF;
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const GemmParams p) {
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(issued - (2 * TN + g) - 1) : "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[i][j] = mma16(__builtin_bit_cast(bf16x8, fw[kk][j]), __builtin_bit_cast(bf16x8, fa[g % RA]), acc[i][j]);
+            acc[i][j] = mma16(__builtin_bit_cast(vec8<T>, fw[kk][j]), __builtin_bit_cast(vec8<T>, fa[g % RA]), acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j == 0 && g + PREA < 2 * TM) rd_a(std::integral_constant<int, (g + PREA < 2 * TM ? g + PREA : 0)>{});
             if constexpr (m == TN - 1) {  // every wave holds W(t) in registers (the wait of MFMA 0 covered the eight W reads)

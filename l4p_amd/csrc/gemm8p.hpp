@@ -24,7 +24,7 @@
 #include "gemm.hpp"
 
 #ifdef GEMM_PROBE_VARIANTS
-__device__ int g_tile_gm = 0;
+static __device__ int g_tile_gm = 0;
 #endif
 // SPLITK is a compile-time form: the k-range arithmetic it adds to the staging segments of every phase cost the plain kernel
 // 1.7 % of the c3 step when it was a run-time condition
@@ -45,12 +45,11 @@ struct Gemm8pCfg {
 // pointers of the next tile live only across those six stage calls (they are recomputed at the top of the next iteration from an
 // opaque copy of the tile origin): the epilogue's register budget is unchanged.  Matters most where tiles are short: the mask
 // product (K = 352: 5.5 k-tiles per tile, 48 - 96 tiles per CU).
-template <int MODE, int WR, int WC, bool SPLITK = false, int TM = 8, int TN = 4, bool PERSIST = false>
+template <typename T, int MODE, int WR, int WC, bool SPLITK = false, int TM = 8, int TN = 4, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     static_assert(!PERSIST || (MODE == 0 && !SPLITK), "persistent form: dense GEMM without split-K");
     static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
     static_assert(TM % 2 == 0 && TN % 2 == 0 && (WR * TM) % 8 == 0, "half tiles; A half-tile = whole 64-row staging passes");
-    typedef bf16_t T;
     constexpr int BM = WR * TM * 16, BN = WC * TN * 16, BK = 64;
     constexpr int RH = TM * 8, CH = TN * 8;               // rows of A / of W that one wave owns in a half-tile
     constexpr int A_PASS = WR * RH / 64, W_PASS = (WC * CH + 63) / 64;  // 512-lane LDS-DMA passes (64 rows each) per half-tile
@@ -253,21 +252,21 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p) {
     };
 
     f32x4 acc[TM][TN];
-    bf16x8 xa[TM / 2][2], wb[2][TN / 2][2];
+    vec8<T> xa[TM / 2][2], wb[2][TN / 2][2];
 
     auto read_a = [&](int h, int buf) {
         const char* base = smem + buf * BUF + h * A_HALF;
 #pragma unroll
         for (int ii = 0; ii < TM / 2; ++ii)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) xa[ii][kk] = *(const bf16x8*)(base + a_off[kk] + ii * 2048);
+            for (int kk = 0; kk < 2; ++kk) xa[ii][kk] = *(const vec8<T>*)(base + a_off[kk] + ii * 2048);
     };
     auto read_w = [&](int h, int buf) {
         const char* base = smem + buf * BUF + 2 * A_HALF + h * W_HALF;
 #pragma unroll
         for (int jj = 0; jj < TN / 2; ++jj)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) wb[h][jj][kk] = *(const bf16x8*)(base + w_off[kk] + jj * 512);
+            for (int kk = 0; kk < 2; ++kk) wb[h][jj][kk] = *(const vec8<T>*)(base + w_off[kk] + jj * 512);
     };
     auto quadrant = [&](int qa, int qw) {
         __builtin_amdgcn_s_setprio(1);

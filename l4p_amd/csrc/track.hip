@@ -19,6 +19,19 @@ template <> struct Vec8<bf16_t> {
         *(bf16x8*)p = t;
     }
 };
+template <> struct Vec8<f16_t> {
+    static __device__ __forceinline__ void load(const f16_t* p, float* v) {
+        const f16x8 t = *(const f16x8*)p;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+    }
+    static __device__ __forceinline__ void store(f16_t* p, const float* v) {
+        f16x8 t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (f16_t)v[k];
+        *(f16x8*)p = t;
+    }
+};
 template <> struct Vec8<float> {
     static __device__ __forceinline__ void load(const float* p, float* v) {
         const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
@@ -46,6 +59,19 @@ template <> struct Vec4<bf16_t> {
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] = (bf16_t)v[k];
         *(bf16x4*)p = t;
+    }
+};
+template <> struct Vec4<f16_t> {
+    static __device__ __forceinline__ void load(const f16_t* p, float* v) {
+        const f16x4 t = *(const f16x4*)p;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (float)t[k];
+    }
+    static __device__ __forceinline__ void store(f16_t* p, const float* v) {
+        f16x4 t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = (f16_t)v[k];
+        *(f16x4*)p = t;
     }
 };
 template <> struct Vec4<float> {
@@ -221,9 +247,9 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const T* __restrict__ q, 
     const bool whole_rows = sizeof(T) == 2 && (hd & 7) == 0 && (hd >> 3) <= MAXCH;
     if (whole_rows && !pre) {
         const int nch = hd >> 3;
-        bf16x8 cur[MAXCH], nxt[MAXCH];
-        auto load_row = [&](int p, bf16x8 (&r)[MAXCH]) {
-            const bf16x8* kr = (const bf16x8*)((const bf16_t*)kp + (long long)p * D);
+        vec8h<T> cur[MAXCH], nxt[MAXCH];
+        auto load_row = [&](int p, vec8h<T> (&r)[MAXCH]) {
+            const vec8h<T>* kr = (const vec8h<T>*)((const vec4e<T>*)kp + (long long)p * D);
 #pragma unroll
             for (int c = 0; c < MAXCH; ++c)
                 if (c < nch) r[c] = kr[c];
@@ -795,37 +821,38 @@ __global__ void transpose_pad_kernel(const T* __restrict__ in, T* __restrict__ o
 // MFMAs, + bias, rounded, through a private 4 KB LDS tile into whole 256-byte row segments - no workgroup barrier anywhere.
 // Same products in the same order as the GEMM (two k-steps per accumulator): bit-identical to it.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void i2t_delta_kernel(const bf16_t* __restrict__ probs, const bf16_t* __restrict__ vt,
-                                                        const float* __restrict__ bias, bf16_t* __restrict__ delta, int P, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void i2t_delta_kernel(const T* __restrict__ probs, const T* __restrict__ vt,
+                                                        const float* __restrict__ bias, T* __restrict__ delta, int P, int C,
                                                         int rows_per_wg) {
     constexpr int K = 64, CW = 128;
-    __shared__ __attribute__((aligned(16))) bf16_t tile[4][16 * CW];
+    __shared__ __attribute__((aligned(16))) T tile[4][16 * CW];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, i16 = lane & 15;
     const int c0 = blockIdx.x * CW, n = blockIdx.y, r0 = blockIdx.z * rows_per_wg;
     const int rows = P - r0 < rows_per_wg ? P - r0 : rows_per_wg;
     const int ntile = rows / 16;
-    const bf16_t* vb = vt + ((long long)n * C + c0) * K;
-    bf16x8 fb[8][2];
+    const T* vb = vt + ((long long)n * C + c0) * K;
+    vec8<T> fb[8][2];
     float bz[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fb[j][kk] = *(const bf16x8*)(vb + (long long)(16 * j + i16) * K + 32 * kk + 8 * g);
+        for (int kk = 0; kk < 2; ++kk) fb[j][kk] = *(const vec8<T>*)(vb + (long long)(16 * j + i16) * K + 32 * kk + 8 * g);
         bz[j] = bias ? bias[c0 + 16 * j + i16] : 0.f;
     }
-    const bf16_t* pa = probs + ((long long)n * P + r0) * K + (long long)i16 * K + 8 * g;
-    bf16_t* out = delta + ((long long)n * P + r0) * C + c0;
-    bf16_t* tl = tile[wave];
-    bf16x8 a0 = {}, a1 = {}, n0 = {}, n1 = {};
+    const T* pa = probs + ((long long)n * P + r0) * K + (long long)i16 * K + 8 * g;
+    T* out = delta + ((long long)n * P + r0) * C + c0;
+    T* tl = tile[wave];
+    vec8<T> a0 = {}, a1 = {}, n0 = {}, n1 = {};
     int t = wave;
     if (t < ntile) {
-        a0 = *(const bf16x8*)(pa + (long long)t * 16 * K);
-        a1 = *(const bf16x8*)(pa + (long long)t * 16 * K + 32);
+        a0 = *(const vec8<T>*)(pa + (long long)t * 16 * K);
+        a1 = *(const vec8<T>*)(pa + (long long)t * 16 * K + 32);
     }
     for (; t < ntile; t += 4) {
         if (t + 4 < ntile) {
-            n0 = *(const bf16x8*)(pa + (long long)(t + 4) * 16 * K);
-            n1 = *(const bf16x8*)(pa + (long long)(t + 4) * 16 * K + 32);
+            n0 = *(const vec8<T>*)(pa + (long long)(t + 4) * 16 * K);
+            n1 = *(const vec8<T>*)(pa + (long long)(t + 4) * 16 * K + 32);
         }
         f32x4 acc[8];
 #pragma unroll
@@ -836,7 +863,7 @@ __global__ __launch_bounds__(256) void i2t_delta_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tl[(4 * g + e) * CW + 16 * j + i16] = (bf16_t)(acc[j][e] + bz[j]);
+            for (int e = 0; e < 4; ++e) tl[(4 * g + e) * CW + 16 * j + i16] = (T)(acc[j][e] + bz[j]);
         __builtin_amdgcn_wave_barrier();  // (the tile is this wave's own: LDS operations of a wave complete in order)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -947,17 +974,18 @@ __device__ __forceinline__ void t2i_scales(const float* __restrict__ stats, int 
 // 4-stage ring, two stages in flight behind the one being read, counted vmcnt + one raw barrier per step.  The kernel is bound by
 // the single read of the keys (5.8 MB per track); per step a wave issues 10 LDS reads and 6 MFMAs.
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-__device__ __forceinline__ bf16x8 tr_frag(const char* lo, int hi_off) {
+template <typename T>
+__device__ __forceinline__ vec8<T> tr_frag(const char* lo, int hi_off) {
     typedef __attribute__((address_space(3))) s16x4_t* lp_t;
     const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(lo));
     const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(lo + hi_off));
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     const s16x8_t r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    return __builtin_bit_cast(bf16x8, r);
+    return __builtin_bit_cast(vec8<T>, r);
 }
-template <int HT, int CW>
-__global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const bf16_t* __restrict__ probs, const bf16_t* __restrict__ keys,
-                                                           bf16_t* __restrict__ ctx, const float* __restrict__ stats, int P, int C, int heads,
+template <typename T, int HT, int CW>
+__global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__ probs, const T* __restrict__ keys,
+                                                           T* __restrict__ ctx, const float* __restrict__ stats, int P, int C, int heads,
                                                            int tokens, long long Rg) {
     static_assert(HT == 48, "t2i_scales");
     constexpr int KT = 32, ST = 4, MT = HT / 16, NTW = CW / 64;  // NTW: 16-column tiles per wave
@@ -1012,11 +1040,11 @@ __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const bf16_t* __restr
         __builtin_amdgcn_s_barrier();
         if (s + 3 < ns) issue(s + 3);
         const char* base = smem + (s & (ST - 1)) * SB;
-        bf16x8 fa[MT], fb[NTW];
+        vec8<T> fa[MT], fb[NTW];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) fa[m] = tr_frag(base + a_off + m * 32, 4 * HT * 2);
+        for (int m = 0; m < MT; ++m) fa[m] = tr_frag<T>(base + a_off + m * 32, 4 * HT * 2);
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) fb[j] = tr_frag(base + b_off + j * 32, 4 * CW * 2);
+        for (int j = 0; j < NTW; ++j) fb[j] = tr_frag<T>(base + b_off + j * 32, 4 * CW * 2);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1044,7 +1072,7 @@ __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const bf16_t* __restr
                 const int tp = m * 16 + 4 * g + e;  // score column t * heads + h
                 const int t = tp / heads, h = tp - t * heads;
                 if (t < tokens)
-                    ctx[((long long)h * Rg + (long long)n * tokens + t) * C + c0 + wave * (16 * NTW) + j * 16 + i16] = (bf16_t)tot[m][j][e];
+                    ctx[((long long)h * Rg + (long long)n * tokens + t) * C + c0 + wave * (16 * NTW) + j * 16 + i16] = (T)tot[m][j][e];
             }
 }
 // any dtype (the f32 engine): one thread per column, the HT running sums in registers, probs rows read as wave-uniform values
@@ -1098,12 +1126,12 @@ int launch_t2i_attn_scores(int dtype, const float* scores, long long ld_scores, 
     const size_t need2 = (size_t)nkg * 6 * hd * 4;
     if (need2 > (size_t)6 * P * 4) lds += need2 - (size_t)6 * P * 4;
     const long long kv_stride = (long long)P * D;
-    if (dtype == L4P_BF16) {
-        auto kb = t2i_attn_kernel<bf16_t>;
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
+        auto kb = t2i_attn_kernel<T16>;
         HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kb, dim3(N, heads), dim3(256), lds, stream, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)v,
-                           (bf16_t*)out, P, D, hd, 1.f, kv_stride, scores, ld_scores, heads);
-    } else {
+        hipLaunchKernelGGL(kb, dim3(N, heads), dim3(256), lds, stream, (const T16*)nullptr, (const T16*)nullptr, (const T16*)v,
+                           (T16*)out, P, D, hd, 1.f, kv_stride, scores, ld_scores, heads);
+    }); else {
         auto kf = t2i_attn_kernel<float>;
         HIP_TRY(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kf, dim3(N, heads), dim3(256), lds, stream, (const float*)nullptr, (const float*)nullptr, (const float*)v,
@@ -1120,9 +1148,8 @@ int launch_i2t_probs(int dtype, const float* s, long long lds_, int pairs, const
     }
     ProfScope prof(PROF_TRACK, stream, "i2t_probs");
     const int grid = GRID1D(M * heads, 16384);
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(i2t_probs_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, s, lds_, pairs, cbias, rows_per_group, (bf16_t*)p, ldp, M,
-                           heads, tokens);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(i2t_probs_kernel<T16>, dim3(grid), dim3(256), 0, stream, s, lds_, pairs, cbias, rows_per_group, (T16*)p, ldp, M,
+                           heads, tokens));
     else
         hipLaunchKernelGGL(i2t_probs_kernel<float>, dim3(grid), dim3(256), 0, stream, s, lds_, pairs, cbias, rows_per_group, (float*)p, ldp, M, heads,
                            tokens);
@@ -1136,8 +1163,7 @@ int launch_split_hilo(int dtype, const float* in, void* out, int G, int R, long 
     }
     ProfScope prof(PROF_TRACK, stream, "split_hilo");
     const int grid = GRID1D((long long)G * R * C, 16384);
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(split_hilo_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, in, (bf16_t*)out, G, R, C);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(split_hilo_kernel<T16>, dim3(grid), dim3(256), 0, stream, in, (T16*)out, G, R, C));
     else
         hipLaunchKernelGGL(split_hilo_kernel<float>, dim3(grid), dim3(256), 0, stream, in, (float*)out, G, R, C);
     HIP_TRY(hipGetLastError());
@@ -1150,8 +1176,7 @@ int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int
     }
     ProfScope prof(PROF_TRACK, stream, "transpose_pad");
     const int grid = GRID1D((long long)G * C * Rp, 16384);
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(transpose_pad_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)in, (bf16_t*)out, G, R, C, Rp);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(transpose_pad_kernel<T16>, dim3(grid), dim3(256), 0, stream, (const T16*)in, (T16*)out, G, R, C, Rp));
     else
         hipLaunchKernelGGL(transpose_pad_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)in, (float*)out, G, R, C, Rp);
     HIP_TRY(hipGetLastError());
@@ -1160,15 +1185,15 @@ int launch_transpose_pad(int dtype, const void* in, void* out, int G, int R, int
 
 int launch_i2t_delta(int dtype, const void* probs, const void* vt, const float* bias, void* delta, int N, int P, int C, int K,
                      hipStream_t stream) {
-    if (dtype != L4P_BF16 || K != 64 || C % 128 || P % 16 || N < 1) {
-        l4p_set_error("i2t_delta: bf16, k = 64, C %% 128 == 0, P %% 16 == 0 (other shapes: the row-grouped-weights GEMM)");
+    if (!is16(dtype) || K != 64 || C % 128 || P % 16 || N < 1) {
+        l4p_set_error("i2t_delta: 16-bit engine, k = 64, C %% 128 == 0, P %% 16 == 0 (other shapes: the row-grouped-weights GEMM)");
         return L4P_E_INVALID;
     }
     // (a batched GEMM - profiled with the small / streaming products under the tag of the launch it replaces: the executed-shapes check sees it)
     ProfScope prof(PROF_GEMM_SMALL, stream, "M%lld N%d K%d epi0 act0 delta t16x128 wgrp", (long long)N * P, C, K);
     const int rs = P % 128 == 0 ? 2 : 1;
-    hipLaunchKernelGGL(i2t_delta_kernel, dim3(C / 128, N, rs), dim3(256), 0, stream, (const bf16_t*)probs, (const bf16_t*)vt, bias,
-                       (bf16_t*)delta, P, C, P / rs);
+    L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(i2t_delta_kernel<T16>, dim3(C / 128, N, rs), dim3(256), 0, stream, (const T16*)probs, (const T16*)vt, bias,
+                       (T16*)delta, P, C, P / rs));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1179,8 +1204,7 @@ int launch_t2i_probs(int dtype, const float* scores, long long ld_scores, void* 
     }
     ProfScope prof(PROF_TRACK, stream, "t2i_probs");
     const dim3 grid((P + T2I_SPLIT - 1) / T2I_SPLIT, N);
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(t2i_probs_kernel<bf16_t>, grid, dim3(192), 0, stream, scores, ld_scores, (bf16_t*)probs, stats, P);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(t2i_probs_kernel<T16>, grid, dim3(192), 0, stream, scores, ld_scores, (T16*)probs, stats, P));
     else
         hipLaunchKernelGGL(t2i_probs_kernel<float>, grid, dim3(192), 0, stream, scores, ld_scores, (float*)probs, stats, P);
     HIP_TRY(hipGetLastError());
@@ -1194,17 +1218,17 @@ int launch_t2i_context(int dtype, const void* probs, const float* stats, const v
     }
     // (a batched GEMM: N x [HT x P] x [P x C]; profiled with the small / streaming products: the FLOP model's executed-shapes check sees it)
     ProfScope prof(PROF_GEMM_SMALL, stream, "M%d N%d K%d epi0 act0 ctx t48x%d", N * heads * tokens, C, P, C % 128 ? 64 : 128);
-    if (dtype == L4P_BF16) {
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
         if (C % 128 == 0) {
             constexpr int lds = 4 * (32 * 128 * 2 + 32 * 48 * 2);
-            hipLaunchKernelGGL((t2i_ctx_mfma_kernel<48, 128>), dim3(C / 128, N), dim3(256), lds, stream, (const bf16_t*)probs,
-                               (const bf16_t*)keys, (bf16_t*)ctx, stats, P, C, heads, tokens, Rg);
+            hipLaunchKernelGGL((t2i_ctx_mfma_kernel<T16, 48, 128>), dim3(C / 128, N), dim3(256), lds, stream, (const T16*)probs,
+                               (const T16*)keys, (T16*)ctx, stats, P, C, heads, tokens, Rg);
         } else {
             constexpr int lds = 4 * (32 * 64 * 2 + 32 * 48 * 2);
-            hipLaunchKernelGGL((t2i_ctx_mfma_kernel<48, 64>), dim3(C / 64, N), dim3(256), lds, stream, (const bf16_t*)probs,
-                               (const bf16_t*)keys, (bf16_t*)ctx, stats, P, C, heads, tokens, Rg);
+            hipLaunchKernelGGL((t2i_ctx_mfma_kernel<T16, 48, 64>), dim3(C / 64, N), dim3(256), lds, stream, (const T16*)probs,
+                               (const T16*)keys, (T16*)ctx, stats, P, C, heads, tokens, Rg);
         }
-    } else {
+    }); else {
         hipLaunchKernelGGL((t2i_ctx_kernel<float, 48>), dim3((C + 255) / 256, N), dim3(256), 0, stream, (const float*)probs,
                            (const float*)keys, (float*)ctx, stats, P, C, heads, tokens, Rg);
     }
@@ -1232,9 +1256,8 @@ int launch_track_keys_init(int dtype, const float* enc, const float* hist, const
     const long long shared8 = shared_from > 0 ? (long long)shared_from * C / 8 : per_q8;  // (0: no shared rows)
     if (shared_from == 0) k32_shared = nullptr;
     ProfScope prof(PROF_TRACK, stream, "track_keys_init");
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(track_keys_init_kernel<bf16_t>, dim3(GRID1D(total8, 16384)), dim3(256), 0, stream, enc, hist,
-                           pos, k32, (bf16_t*)kT, (bf16_t*)kP, per_q8, total8, shared8, k32_shared);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(track_keys_init_kernel<T16>, dim3(GRID1D(total8, 16384)), dim3(256), 0, stream, enc, hist,
+                           pos, k32, (T16*)kT, (T16*)kP, per_q8, total8, shared8, k32_shared));
     else
         hipLaunchKernelGGL(track_keys_init_kernel<float>, dim3(GRID1D(total8, 16384)), dim3(256), 0, stream, enc, hist, pos,
                            k32, (float*)kT, (float*)kP, per_q8, total8, shared8, k32_shared);
@@ -1285,9 +1308,8 @@ int launch_small_attn(int dtype, int kind, const void* q, const void* k, const v
     }
     ProfScope prof(PROF_TRACK, stream, "small_attn kind%d N%d P%d D%d", kind, N, P, D);
     if (kind == 0) {  // 6 x 6 self attention
-        if (dtype == L4P_BF16)
-            hipLaunchKernelGGL(self_attn6_kernel<bf16_t>, dim3(N, heads), dim3(64), 0, stream, (const bf16_t*)q,
-                               (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, D, hd, scale);
+        if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(self_attn6_kernel<T16>, dim3(N, heads), dim3(64), 0, stream, (const T16*)q,
+                               (const T16*)k, (const T16*)v, (T16*)out, D, hd, scale));
         else
             hipLaunchKernelGGL(self_attn6_kernel<float>, dim3(N, heads), dim3(64), 0, stream, (const float*)q,
                                (const float*)k, (const float*)v, (float*)out, D, hd, scale);
@@ -1297,29 +1319,29 @@ int launch_small_attn(int dtype, int kind, const void* q, const void* k, const v
         size_t lds = (size_t)(6 * P + 6 * 96 + 256) * 4;
         const size_t need2 = (size_t)nkg * 6 * hd * 4;
         if (need2 > (size_t)6 * P * 4) lds += need2 - (size_t)6 * P * 4;
-        auto kb = t2i_attn_kernel<bf16_t>;
         auto kf = t2i_attn_kernel<float>;
-        if (dtype == L4P_BF16) {
+        if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
+            auto kb = t2i_attn_kernel<T16>;
             HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kb, dim3(N, heads), dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, scale, kv_stride, (const float*)nullptr, 0ll, 0);
-        } else {
+            hipLaunchKernelGGL(kb, dim3(N, heads), dim3(256), lds, stream, (const T16*)q, (const T16*)k,
+                               (const T16*)v, (T16*)out, P, D, hd, scale, kv_stride, (const float*)nullptr, 0ll, 0);
+        }); else {
             HIP_TRY(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kf, dim3(N, heads), dim3(256), lds, stream, (const float*)q, (const float*)k,
                                (const float*)v, (float*)out, P, D, hd, scale, kv_stride, (const float*)nullptr, 0ll, 0);
         }
     } else if (kind == 2 || kind == 4) {  // image -> tokens (4: one query set shared by every track)
         const long long q_stride = kind == 2 ? (long long)P * D : 0;
-        if (256 % heads == 0 && (D * (dtype == L4P_BF16 ? 2 : 4)) % 16 == 0) {
-            const int rows = 256 / heads, es = dtype == L4P_BF16 ? 2 : 4;
+        if (256 % heads == 0 && (D * (esize_of(dtype))) % 16 == 0) {
+            const int rows = 256 / heads, es = esize_of(dtype);
             const size_t lds = (((size_t)12 * D * 4 + 15) & ~(size_t)15) + (size_t)rows * D * es;
             const dim3 grid((P + rows - 1) / rows, N);
-            if (dtype == L4P_BF16) {
-                auto kern = i2t_attn_lds_kernel<bf16_t>;
+            if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
+                auto kern = i2t_attn_lds_kernel<T16>;
                 HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                                   (bf16_t*)out, P, D, hd, heads, scale, q_stride);
-            } else {
+                hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T16*)q, (const T16*)k, (const T16*)v,
+                                   (T16*)out, P, D, hd, heads, scale, q_stride);
+            }); else {
                 auto kern = i2t_attn_lds_kernel<float>;
                 HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const float*)q, (const float*)k, (const float*)v,
@@ -1330,9 +1352,8 @@ int launch_small_attn(int dtype, int kind, const void* q, const void* k, const v
         }
         const size_t lds = (size_t)12 * D * 4;
         const dim3 grid((P * heads + 255) / 256, N);
-        if (dtype == L4P_BF16)
-            hipLaunchKernelGGL(i2t_attn_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)out, P, D, hd, heads, scale, q_stride);
+        if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(i2t_attn_kernel<T16>, grid, dim3(256), lds, stream, (const T16*)q, (const T16*)k,
+                               (const T16*)v, (T16*)out, P, D, hd, heads, scale, q_stride));
         else
             hipLaunchKernelGGL(i2t_attn_kernel<float>, grid, dim3(256), lds, stream, (const float*)q, (const float*)k,
                                (const float*)v, (float*)out, P, D, hd, heads, scale, q_stride);
@@ -1391,16 +1412,16 @@ int launch_mask_product(int dtype, const void* up, const float* hyper, float* ma
         return L4P_E_INVALID;
     }
     ProfScope prof(PROF_TRACK, stream, "mask_product");
-    const int es = dtype == L4P_BF16 ? 2 : 4;
+    const int es = esize_of(dtype);
     const int VT = 128;
     const size_t lds_tile = ((size_t)3 * Cc * 4 + 15) / 16 * 16 + (size_t)VT * Cc * es;
     if (lds_tile <= 160 * 1024) {
         const dim3 grid((unsigned)((vox + VT - 1) / VT), N);
-        if (dtype == L4P_BF16) {
-            auto kern = mask_product_lds_kernel<bf16_t, 128>;
+        if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
+            auto kern = mask_product_lds_kernel<T16, 128>;
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
-            hipLaunchKernelGGL(kern, grid, dim3(128), lds_tile, stream, (const bf16_t*)up, hyper, masks, vox, Cc);
-        } else {
+            hipLaunchKernelGGL(kern, grid, dim3(128), lds_tile, stream, (const T16*)up, hyper, masks, vox, Cc);
+        }); else {
             auto kern = mask_product_lds_kernel<float, 128>;
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
             hipLaunchKernelGGL(kern, grid, dim3(128), lds_tile, stream, (const float*)up, hyper, masks, vox, Cc);
@@ -1410,8 +1431,7 @@ int launch_mask_product(int dtype, const void* up, const float* hyper, float* ma
     }
     const dim3 grid(GRID1D(vox, 1024), N);
     const size_t lds = (size_t)3 * Cc * 4;
-    if (dtype == L4P_BF16)
-        hipLaunchKernelGGL(mask_product_kernel<bf16_t>, grid, dim3(256), lds, stream, (const bf16_t*)up, hyper, masks, vox, Cc);
+    if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(mask_product_kernel<T16>, grid, dim3(256), lds, stream, (const T16*)up, hyper, masks, vox, Cc));
     else
         hipLaunchKernelGGL(mask_product_kernel<float>, grid, dim3(256), lds, stream, (const float*)up, hyper, masks, vox, Cc);
     HIP_TRY(hipGetLastError());

@@ -15,7 +15,7 @@ from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 import torch
 
 from .. import _lib
-from .._lib import L4P_BF16, L4P_F32
+from .._lib import L4P_BF16, L4P_F16, L4P_F32
 from ..engine import Engine
 from ..packing import PackedWeights, pack_state_dict
 from ..weights import ModelCfg, state_dict_schema
@@ -71,8 +71,12 @@ def _on_own_device(fn):
 
 
 def _engine_dtype(name) -> int:
-    if name in (L4P_BF16, "bf16", "bf16-mixed", "16-mixed", "bf16-true", "16-true"):
-        return L4P_BF16  # the reference's fp16 autocast maps to the bf16 MFMA path (>= its precision class)
+    if name in (L4P_BF16, "bf16", "bf16-mixed", "bf16-true"):
+        return L4P_BF16
+    # Fabric's "16-mixed" / "16-true" are float16 (demo/demo.py:22-23, l4p/models/utils.py:57-58 of the reference): the half engine -
+    # f16 MFMA operands and stored activations, f32 accumulate / residual stream / LayerNorm / softmax statistics
+    if name in (L4P_F16, "16-mixed", "16-true", "f16", "fp16", "16"):
+        return L4P_F16
     if name in (L4P_F32, "32", "32-true", "fp32", "f32"):
         return L4P_F32
     raise ValueError(f"unsupported precision {name!r}")
@@ -164,7 +168,7 @@ class L4P_VideoMAE(torch.nn.Module):
         # the device is resolved when the weights arrive, not at construction: a rank that builds the model before
         # torch.cuda.set_device(local_rank) must still end up on its own GPU
         self.device = self._device_arg or torch.device("cuda", torch.cuda.current_device())
-        self.set_weights(pack_state_dict(sd, self.cfg, torch.bfloat16 if self.engine_dtype == L4P_BF16 else torch.float32,
+        self.set_weights(pack_state_dict(sd, self.cfg, {L4P_BF16: torch.bfloat16, L4P_F16: torch.float16, L4P_F32: torch.float32}[self.engine_dtype],
                                          self.device, tasks=list(self.task_heads.keys())))
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 

@@ -17,7 +17,7 @@ from typing import Dict, List, Literal, Optional, Tuple
 import torch
 
 from ... import _lib, ops
-from ..._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, EPI_MASKDOT, L4P_BF16, GemmDesc
+from ..._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, EPI_MASKDOT, L4P_BF16, L4P_F32, GemmDesc
 from ...ops import _p, _stream
 
 
@@ -271,7 +271,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 KW = heads * Cc
                 # optional (bf16 engine): K' as a pair of bf16 matrices (hi, lo; l4p_split_hilo); the two score halves and c are
                 # summed in l4p_i2t_probs
-                pair = dt == L4P_BF16 and os.environ.get("L4P_TRACK_FOLD_PAIR") == "1"  # (measured: no accuracy effect; off)
+                pair = dt != L4P_F32 and os.environ.get("L4P_TRACK_FOLD_PAIR") == "1"  # (measured: no accuracy effect; off)
                 NS = 2 * HT if pair else HT
                 kf = torch.empty((N * NS + 128, Cc), dtype=td, device=dev)  # K' [N][NS][C] (+ slack rows under the last tile)
                 vf = torch.empty((N * HT, Cc), dtype=td, device=dev)        # V' [N][HT][C]
@@ -302,7 +302,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 pr = torch.empty((N * P, HTp), dtype=td, device=dev)
                 _lib.check(lib.l4p_i2t_probs(_stream(), dt, _p(sc), NS, 1 if pair else 0, _p(cf), P, _p(pr), HTp, N * P, heads, 6),
                            "l4p_i2t_probs")
-                if (os.environ.get("L4P_TRACK_DELTA_KERNEL", "1") != "0" and dt == L4P_BF16 and HTp == 64 and Cc % 128 == 0
+                if (os.environ.get("L4P_TRACK_DELTA_KERNEL", "1") != "0" and dt != L4P_F32 and HTp == 64 and Cc % 128 == 0
                         and P % 16 == 0):  # its own streaming kernel, bit-identical to the GEMM (csrc/track.hip i2t_delta_kernel)
                     _lib.check(lib.l4p_i2t_delta(_stream(), dt, _p(pr), _p(vt), _p(self._w(lo + "i2t.out.b")), _p(delta), N, P, Cc, HTp),
                                "l4p_i2t_delta")

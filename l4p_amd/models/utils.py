@@ -68,7 +68,7 @@ def prepare_model(model_config_path: str, ckpt_path: Optional[str], max_queries:
 
             raise _lib.L4PHipError("no AMD GPU visible: the L4P engine has no CPU path")
         pw = PackedWeights.load(ckpt_path, torch.device("cuda", torch.cuda.current_device()))
-        want = "bfloat16" if net.engine_dtype == 0 else "float32"
+        want = {0: "bfloat16", 1: "float32", 2: "float16"}[net.engine_dtype]
         have = getattr(pw, "extra", {}).get("dtype")
         if have != want:
             raise ValueError(f"{ckpt_path} was packed for {have}, the model was built with precision={precision!r} ({want})")

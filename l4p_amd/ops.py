@@ -12,18 +12,20 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, EPI_QKV, L4P_BF16, L4P_F32, GemmDesc
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_CONVT, EPI_DENSE, EPI_QKV, L4P_BF16, L4P_F16, L4P_F32, GemmDesc
 
 DP = 96  # padded attention head dim used by the kernels
 
 
 def torch_dtype(dtype: int) -> torch.dtype:
-    return torch.bfloat16 if dtype == L4P_BF16 else torch.float32
+    return {L4P_BF16: torch.bfloat16, L4P_F16: torch.float16, L4P_F32: torch.float32}[dtype]
 
 
 def code_of(t: torch.dtype) -> int:
     if t == torch.bfloat16:
         return L4P_BF16
+    if t == torch.float16:
+        return L4P_F16
     if t == torch.float32:
         return L4P_F32
     raise ValueError(f"unsupported engine dtype {t}")

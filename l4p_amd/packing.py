@@ -290,7 +290,7 @@ class PackedWeights:
         """magic | u64 header length | JSON header {layout, meta, extra} | zero padding to 4096 | raw arena bytes."""
         import json
 
-        names = {torch.float32: "float32", torch.bfloat16: "bfloat16"}
+        names = {torch.float32: "float32", torch.bfloat16: "bfloat16", torch.float16: "float16"}
         hdr = json.dumps({"layout": [[n, list(sh), names[dt], off] for n, sh, dt, off in self.layout], "meta": self.meta,
                           "nbytes": int(self.arena.numel()), "extra": extra or {}}).encode()
         with open(path, "wb") as f:
@@ -318,7 +318,7 @@ class PackedWeights:
             n = int.from_bytes(f.read(8), "little")
             hdr = json.loads(f.read(n))
             data_off = (f.tell() + 4095) // 4096 * 4096
-        dts = {"float32": torch.float32, "bfloat16": torch.bfloat16}
+        dts = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}
         layout = [(nm, tuple(sh), dts[dt], off) for nm, sh, dt, off in hdr["layout"]]
         raw = np.memmap(path, dtype=np.uint8, mode="r", offset=data_off, shape=(hdr["nbytes"],))
         arena = torch.from_numpy(np.array(raw)).to(device)  # (one host copy: the map is read-only)

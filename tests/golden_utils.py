@@ -87,19 +87,25 @@ BF16_MARGIN_SMALL = 2.0   # ... for outputs of fewer than 4096 values (4 tracks 
                           # values from ONE run of each side is a noisy statistic; the geometric-mean bar below still holds)
 
 
-def reference_autocast_drift(case: str) -> dict:
-    """tests/golden/reference_autocast_drift.json (tools/gen_golden_full_autocast.py): the imported reference under
-    torch.autocast(bfloat16) against its own fp32 run on the golden inputs -> {key: rel-L2}."""
+def is_half(precision) -> bool:
+    """The engine's IEEE-half mode (what the reference's shipped "16-mixed" computes in)."""
+    return precision in ("16-mixed", "16-true", "f16", "fp16", 2)
+
+
+def reference_autocast_drift(case: str, precision="bf16") -> dict:
+    """tests/golden/reference_autocast_drift.json / ..._f16.json (tools/gen_golden_full_autocast.py [--dtype float16]): the imported
+    reference under torch.autocast(bfloat16 / float16) against its own fp32 run on the golden inputs -> {key: rel-L2}."""
     import json
     import os
 
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_autocast_drift.json")) as f:
+    name = "reference_autocast_drift_f16.json" if is_half(precision) else "reference_autocast_drift.json"
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)) as f:
         rep = json.load(f)[case]
     assert "autocast_failed" not in rep, rep
     return {k: v["rel_l2"] for k, v in rep.items() if isinstance(v, dict)} | {k: v for k, v in rep.items() if not isinstance(v, dict)}
 
 
-def assert_bf16_within_reference_drift(report_l2: dict, case: str, keymap=None, what: str = "", small=()) -> dict:
+def assert_bf16_within_reference_drift(report_l2: dict, case: str, keymap=None, what: str = "", small=(), precision="bf16") -> dict:
     """``report_l2``: {key: rel-L2 of the bf16 ENGINE against the reference's fp32 golden}.  The bar is the reference's own
     mixed-precision drift on the same inputs: every key within BF16_MARGIN x the reference's figure, and the geometric mean of
     engine / reference over the keys <= 1 (overall the engine is no further from the fp32 reference than the reference's own
@@ -107,7 +113,7 @@ def assert_bf16_within_reference_drift(report_l2: dict, case: str, keymap=None, 
     with fewer than 4096 values, held to BF16_MARGIN_SMALL per key.  Returns the ratios."""
     import math
 
-    ref = reference_autocast_drift(case)
+    ref = reference_autocast_drift(case, precision)
     ratios = {}
     for k, v in report_l2.items():
         rk = (keymap or {}).get(k, k)
@@ -116,7 +122,7 @@ def assert_bf16_within_reference_drift(report_l2: dict, case: str, keymap=None, 
             assert v <= 1e-6, (what, k, v)
             continue
         ratios[k] = v / ref[rk]
-    print(f"bf16 engine drift / reference autocast drift [{case}{' ' + what if what else ''}]:",
+    print(f"{'f16' if is_half(precision) else 'bf16'} engine drift / reference autocast drift [{case}{' ' + what if what else ''}]:",
           {k: f"{r:.2f}" for k, r in ratios.items()})
     bad = {k: r for k, r in ratios.items() if r > (BF16_MARGIN_SMALL if k in small else BF16_MARGIN)}
     assert not bad, (what, bad)

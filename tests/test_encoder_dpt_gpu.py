@@ -45,7 +45,7 @@ def rel_l2(a, b):
     return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
 
 
-@pytest.mark.parametrize("precision,tol_max,tol_l2", [("32-true", 1e-3, 1e-3), ("bf16", None, 3e-2)])
+@pytest.mark.parametrize("precision,tol_max,tol_l2", [("32-true", 1e-3, 1e-3), ("bf16", None, 3e-2), ("16-mixed", None, 4e-3)])
 def test_mini_encoder_and_dense_heads_vs_oracle_and_golden(dev, mini, precision, tol_max, tol_l2):
     from oracle.l4p_oracle import OracleModel, encoder_forward
 
@@ -87,10 +87,10 @@ def test_mini_encoder_and_dense_heads_vs_oracle_and_golden(dev, mini, precision,
         # the bf16 engine against the reference's OWN autocast drift on these inputs (tools/gen_golden_full_autocast.py)
         from tests.golden_utils import assert_bf16_within_reference_drift
 
-        assert_bf16_within_reference_drift(drift, "mini_T16_all")
+        assert_bf16_within_reference_drift(drift, "mini_T16_all", precision=precision)
 
 
-@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+@pytest.mark.parametrize("precision", ["32-true", "bf16", "16-mixed"])
 def test_native_dpt_call_equals_python_composition(dev, mini, precision, monkeypatch):
     """l4p_dpt_forward (one C++ call) issues the same kernels in the same order as dense_heads.dpt_decode
     (kernel-by-kernel from Python): outputs must be bit-identical, for a full-resolution head and the camray head."""

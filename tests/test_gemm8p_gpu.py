@@ -17,10 +17,19 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from l4p_amd import _lib, ops
-from l4p_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_DENSE, EPI_MASKDOT, L4P_BF16, GemmDesc
+from l4p_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, EPI_DENSE, EPI_MASKDOT, L4P_BF16, L4P_F16, GemmDesc
 from tests.test_kernels_gpu import as_mode, check, rnd
 
-MODE = L4P_BF16
+MODE = L4P_BF16  # (set per test by the fixture below: every test of this file runs on both 16-bit engine types)
+
+
+@pytest.fixture(autouse=True, params=[L4P_BF16, L4P_F16], ids=["bf16", "f16"])
+def _engine_mode(request, monkeypatch):
+    import sys
+
+    monkeypatch.setattr(sys.modules[__name__], "MODE", request.param)
+
+
 FORM_TAG = " 8p "  # the kernel form every test here asserts (tests/test_gemm4w_gpu.py re-runs some of them on the " 4w " form)
 
 
@@ -201,9 +210,9 @@ def test_gemm8p_qkv_epilogue_and_batch4_attention(dev):
     full = (x_ref @ w_ref.t() + bp.view(-1)).view(B, S, 3, H, ops.DP)
     check(q.view(B, S, H, ops.DP), full[:, :, 0] * qs, MODE, True)
     check(vt, full[:, :, 2].permute(0, 2, 3, 1), MODE, True)
-    check(kt, ops.k_tile_order(full[:, :, 1].contiguous().to(torch.bfloat16)).float(), MODE, True)
+    check(kt, ops.k_tile_order(full[:, :, 1].contiguous().to(ops.torch_dtype(MODE))).float(), MODE, True)
     q_ref = q.float().cpu().view(B, S, H, ops.DP).permute(0, 2, 1, 3)
-    k_ref = full[:, :, 1].to(torch.bfloat16).float().permute(0, 2, 1, 3)
+    k_ref = full[:, :, 1].to(ops.torch_dtype(MODE)).float().permute(0, 2, 1, 3)
     v_ref = vt.float().cpu().permute(0, 1, 3, 2)
     out = ops.attention(q, kt, vt, Dh, scale=0.0)
     for b in range(B):  # one clip at a time: the score matrices of a clip are 16 x 2048 x 2048 floats

@@ -25,7 +25,7 @@ DENSE = ["depth", "flow_2d_backward", "dyn_mask"]
 KEYS = ["depth_est_b1thw", "flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw"]
 
 
-@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+@pytest.mark.parametrize("precision", ["32-true", "bf16", "16-mixed"])
 def test_three_window_stitch_vs_reference_goldens(dev, precision):
     from oracle.l4p_oracle import OracleModel
 
@@ -54,7 +54,7 @@ def test_three_window_stitch_vs_reference_goldens(dev, precision):
         # the bf16 engine against the reference's OWN autocast drift over these 3 windows (tools/gen_golden_full_autocast.py)
         from tests.golden_utils import assert_bf16_within_reference_drift
 
-        assert_bf16_within_reference_drift(drift, "mini_T32_stitch")
+        assert_bf16_within_reference_drift(drift, "mini_T32_stitch", precision=precision)
 
 
 def _safe_inverse(x):

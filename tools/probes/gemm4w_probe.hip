@@ -26,7 +26,7 @@ static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (uns
 
 template <int DBG, int PSTEP = 3>
 static void run4w(const GemmParams& p, int lds) {
-    auto kern = gemm4w_kernel<false, DBG, PSTEP>;
+    auto kern = gemm4w_kernel<bf16_t, false, DBG, PSTEP>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int grid = ((p.M + 255) / 256) * ((p.N + 127) / 128);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, p);
