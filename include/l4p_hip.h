@@ -56,6 +56,9 @@ int l4p_stream_destroy(l4p_stream stream);
  * environment variable (read ONCE, at first use) and can be changed at run time through l4p_set_knob - no getenv on a launch path.
  *   "conv_halo"  (L4P_CONV_HALO, default 1): 0 = implicit-GEMM forms for every 3x3x3 conv, 1 = the LDS-halo kernel where it fits
  *   "gemm_4w"    (L4P_GEMM_4W,   default 0): the two-workgroups-per-CU GEMM: 0 never, 1 on the shapes it won, 2 wherever it fits
+ *   "maskdot_mfma" (L4P_MASKDOT_MFMA, default 1): L4P_EPI_MASKDOT of the 16-bit engines contracts the activated row with the
+ *                hyper-network vectors on the matrix pipe (the row rounded to T first, as the reference's autocast holds it);
+ *                0 = the all-VALU form (float row, float dot products)
  * l4p_set_knob returns L4P_E_INVALID for an unknown name; l4p_get_knob returns the current value (or -1). */
 int l4p_set_knob(const char* name, int value);
 int l4p_get_knob(const char* name);
@@ -149,7 +152,8 @@ typedef struct l4p_gemm_desc {
     /* tuning aid, normally 0.  bit 0: use the generic run-time-dispatched epilogue even where a lean specialisation exists
      * (set by the launcher when L4P_EPI_GENERIC=1: in-run A/B of the two forms).  bit 1: a split-K launch leaves its float
      * partials [splitk][M][N] to the caller and runs no finish pass (bias / residual / outputs of the descriptor are ignored):
-     * the encoder sums them in the LayerNorm that follows the batch-1 MLP-out projection. */
+     * the encoder sums them in the LayerNorm that follows the batch-1 MLP-out projection.  bit 2: L4P_EPI_MASKDOT in its all-VALU
+     * form (set by the launcher when the "maskdot_mfma" knob is 0). */
     int tuning;
     /* Row-grouped weights (0 = off; dense GEMM without split-K, w_gr a multiple of 128): rows [g * w_gr, (g + 1) * w_gr) of A
      * multiply their OWN weight matrix W + g * w_gs (elements, same ldw) and add their own bias row bias + g * b_gs (b_gs = 0: one

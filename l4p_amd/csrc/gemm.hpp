@@ -50,10 +50,127 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, float (&v
 // L4P_EPI_MASKDOT epilogue (see include/l4p_hip.h): activated outputs x the three hyper-network vectors of the row's
 // query, summed over the 32-column chunk the lane shares with 1 (NV = 16) or 3 (NV = 8) neighbours.  Kept apart from
 // gemm_epilogue so that its 3 x NV hyper-vector registers never weigh on the ordinary epilogues.
+// 16-bit engines, NV = 16 (the 8-phase / two-workgroup kernels' wave tile of 64 columns), GELU: the form the tracker runs a
+// million rows through per clip.  Round 5: (1) the activation is compile time (the generic form tested p.act per VALUE: ~115
+// scalar branches per 16-row block); (2) GELU is the clamped polynomial evaluated on PAIRS (v_pk_fma_f32: 7 issues per value
+// against 13; the clamp is a bare v_med3_f32 - fmed3 through the compiler canonicalises its operand first, two more v_max per
+// value); (3) the 3 x 64 dot products of a row with its query's hyper-network vectors are a matrix product and run on the matrix
+// pipe: the activated row, rounded to T as the reference's autocast holds it (mask_decoder.py:136-139), IS an MFMA operand
+// fragment - lane (row li, column group kg) holds 16 consecutive channels = two 8-element fragments under the k-slot map
+// (kg, e) <-> channel 16 kg + e (+ 8) - and hyper^T [16 (3 used) x 64 channels] the other operand under the same map, so
+// D = hyper^T x G^T leaves d0..d2 of row li in ONE lane (kg = 0) with no cross-lane sum.  The two 32-column chunks of the
+// contract (include/l4p_hip.h) come from two products whose hyper operand is zeroed for the other chunk's lanes: 4 MFMAs
+// 16x16x32 per 16 rows replace 48 FMAs + 6 lane exchanges per lane.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float med3_bare(float x, float lo, float hi) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "s"(hi));
+    return r;
+}
+// gelu_poly (common.hpp) on NP pairs at once, coefficient by coefficient: a pair's Horner chain is serially dependent and a dependent
+// packed op needs a wait state (one pair at a time the compiler emitted an s_nop behind each of its 12 packed ops); NP independent
+// chains interleaved fill those slots.  xc = x clamped to [-4.5, 4.5].
+template <int NP>
+__device__ __forceinline__ void gelu_poly2(f32x2_t (&x)[NP], const f32x2_t (&xc)[NP]) {
+    f32x2_t u[NP], q[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) u[k] = xc[k] * xc[k];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) q[k] = __builtin_elementwise_fma((f32x2_t){-1.405532334e-12f, -1.405532334e-12f}, u[k], (f32x2_t){1.702386847e-10f, 1.702386847e-10f});
+    constexpr float cf[8] = {-9.213366003e-09f, 2.962938120e-07f, -6.369978978e-06f, 9.790158587e-05f, -1.122762531e-03f, 9.833131509e-03f,
+                             -6.633633733e-02f, 3.988829162e-01f};
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) q[k] = __builtin_elementwise_fma(q[k], u[k], (f32x2_t){cf[c], cf[c]});
+#pragma unroll
+    for (int k = 0; k < NP; ++k) q[k] = __builtin_elementwise_fma(xc[k], q[k], (f32x2_t){0.5f, 0.5f});
+#pragma unroll
+    for (int k = 0; k < NP; ++k) x[k] = x[k] * q[k];
+}
+template <typename T, int TM>
+__device__ __forceinline__ void gemm_epilogue_maskdot_mfma(const GemmParams& p, f32x4 (&acc)[TM][4], int m_wave0, int n_wave0, int li,
+                                                           int kg) {
+    static_assert(sizeof(T) == 2, "16-bit engines");
+    if (n_wave0 >= p.N) return;  // (N % 64 == 0 is checked by the launcher: a wave's 64 columns are in or out together)
+    const int nb = n_wave0 + 16 * kg;
+    const int co = n_wave0 % p.Cout;  // first channel of the wave's 64 columns inside their tap (Cout % 64 == 0)
+    f32x2_t bv[8];
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + nb + c) : z;
+        bv[c / 2] = (f32x2_t){b4[0], b4[1]};
+        bv[c / 2 + 1] = (f32x2_t){b4[2], b4[3]};
+    }
+    const float neg = -4.5f;
+    int hq = -1;
+    vec8<T> he[2], ho[2];  // hyper^T fragments (row h = li of hyper^T, channels co + 16 kg + 8 ks + e): chunk 0 (kg < 2) / chunk 1
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m_wave0 + i * 16;  // (hyper_rows % 16 == 0, checked by the launcher: one query per 16-row block)
+        const int qn = (mb < p.M ? mb : p.M - 1) / p.hyper_rows;
+        if (qn != hq) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+                if (li < 3) {
+                    const float* hp = p.hyper + ((long long)qn * 3 + li) * p.Cout + co + 16 * kg + 8 * ks;
+                    a = *(const f32x4*)hp;
+                    b = *(const f32x4*)(hp + 4);
+                }
+                vec8<T> f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = (T)a[e], f[4 + e] = (T)b[e];
+                const vec8<T> zf = {};
+                he[ks] = kg < 2 ? f : zf;
+                ho[ks] = kg < 2 ? zf : f;
+            }
+            hq = qn;
+        }
+        vec8<T> g[2];
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {  // 8 values = 4 pairs = one operand fragment at a time
+            f32x2_t x[4], xc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = 2 * jh + (k >> 1), h2 = k & 1;
+                x[k] = (f32x2_t){acc[i][j][2 * h2], acc[i][j][2 * h2 + 1]} + bv[2 * j + h2];
+                xc[k] = (f32x2_t){med3_bare(x[k][0], neg, 4.5f), med3_bare(x[k][1], neg, 4.5f)};
+            }
+            gelu_poly2<4>(x, xc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[jh][2 * k] = (T)x[k][0], g[jh][2 * k + 1] = (T)x[k][1];
+        }
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
+        d0 = mma16(he[0], g[0], d0);
+        d0 = mma16(he[1], g[1], d0);
+        d1 = mma16(ho[0], g[0], d1);
+        d1 = mma16(ho[1], g[1], d1);
+        const int m = mb + li;
+        if (kg == 0 && m < p.M) {  // D[h][row]: lane (column = row li, kg = 0) holds h = 0 .. 3
+            float* op = p.out_f32 + (long long)(n_wave0 >> 5) * 3 * p.M + m;  // [chunk][i][m]: 16 consecutive rows per store
+            op[0] = d0[0];
+            op[(long long)p.M] = d0[1];
+            op[2 * (long long)p.M] = d0[2];
+            op[3 * (long long)p.M] = d1[0];
+            op[4 * (long long)p.M] = d1[1];
+            op[5 * (long long)p.M] = d1[2];
+        }
+    }
+}
+
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_maskdot(const GemmParams& p, f32x4 (&acc)[TM][TN], int m_wave0, int n_wave0, int li,
                                                       int kg) {
     constexpr int NV = 4 * TN;
+    if constexpr (sizeof(T) == 2 && TN == 4) {
+        // (wave uniform; Cout % 64: a wave's 64 columns lie inside one tap; hyper_rows % 16: one query per 16-row block)
+        if (p.act == ACT_GELU && p.Cout % 64 == 0 && p.N % 64 == 0 && p.hyper_rows % 16 == 0 && !(p.tuning & 4)) {
+            gemm_epilogue_maskdot_mfma<T, TM>(p, acc, m_wave0, n_wave0, li, kg);
+            return;
+        }
+    }
     const int nb = n_wave0 + NV * kg;
     if (nb >= p.N) return;  // (N % 32 == 0: the lanes sharing a chunk leave together)
     const int co = nb % p.Cout;

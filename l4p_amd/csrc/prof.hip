@@ -19,7 +19,8 @@ struct KnobDef {
     const char* env;
     int dflt;
 };
-const KnobDef kKnobs[KNOB_NUM] = {{"conv_halo", "L4P_CONV_HALO", 1}, {"gemm_4w", "L4P_GEMM_4W", 0}};
+const KnobDef kKnobs[KNOB_NUM] = {{"conv_halo", "L4P_CONV_HALO", 1}, {"gemm_4w", "L4P_GEMM_4W", 0},
+                                   {"maskdot_mfma", "L4P_MASKDOT_MFMA", 1}};
 std::atomic<int> g_knob[KNOB_NUM];
 std::once_flag g_knob_once;
 void knobs_init() {

@@ -56,8 +56,8 @@ def test_gemm4w_conv_transpose_upscaling(dev):
     t8.test_gemm8p_conv_transpose_upscaling(dev)
 
 
-def test_gemm4w_maskdot_large(dev):
-    t8.test_gemm8p_maskdot_large(dev)
+def test_gemm4w_maskdot_large(dev, knob):
+    t8.test_gemm8p_maskdot_large(dev, knob)
 
 
 def test_gemm4w_equals_8p_bitwise_and_is_deterministic(dev, monkeypatch, knob):

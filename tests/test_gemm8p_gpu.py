@@ -237,9 +237,12 @@ def test_gemm8p_conv_transpose_upscaling(dev):
     check(y, ref, MODE, True)
 
 
-def test_gemm8p_maskdot_large(dev):
+def test_gemm8p_maskdot_large(dev, knob):
     """L4P_EPI_MASKDOT on the 8-phase kernel (M = 65536 >= the 256-tile threshold): GELU(ConvTranspose(1,2,2)) contracted
-    with the per-query hyper-network vectors (mask_decoder.py:136-139), against the unfused statement."""
+    with the per-query hyper-network vectors (mask_decoder.py:136-139), against the unfused statement.  Two forms: the
+    matrix-pipe contraction (default; the activated row and the hyper vectors are rounded to the engine type first, as the
+    reference's autocast holds them) against the statement on operands rounded the same way, and the all-VALU form
+    (knob maskdot_mfma = 0: float row, float dot products) against the unrounded statement."""
     Nq, T, h, w_, Cin, d1 = 4, 16, 32, 32, 352, 176
     x, x_ref = as_mode(rnd((Nq, T, h, w_, Cin), 90), MODE)
     wt = rnd((Cin, d1, 1, 2, 2), 91, Cin ** -0.5)
@@ -271,12 +274,26 @@ def test_gemm8p_maskdot_large(dev):
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
     masks = torch.empty(Nq, 3, T, 2 * h, 2 * w_, dtype=torch.float32, device="cuda")
-    with prof_tags() as p:
-        _lib.check(lib.l4p_gemm(st, MODE, C.byref(d)), "l4p_gemm(maskdot)")
-    p.assert_8p()
-    _lib.check(lib.l4p_mask_gather(st, partial.data_ptr(), masks.data_ptr(), Nq, T, h, w_, cpt), "l4p_mask_gather")
-    torch.cuda.synchronize()
-    check(masks, ref, MODE, False)
+    td = ops.torch_dtype(MODE)
+    ref_rounded = torch.einsum("nic,nctyx->nityx", hyper.to(td).float(), up.to(td).float())
+    for mfma, want in ((1, ref_rounded), (0, ref)):
+        knob("maskdot_mfma", mfma)
+        partial.fill_(float("nan"))
+        with prof_tags() as p:
+            _lib.check(lib.l4p_gemm(st, MODE, C.byref(d)), "l4p_gemm(maskdot)")
+        p.assert_8p()
+        _lib.check(lib.l4p_mask_gather(st, partial.data_ptr(), masks.data_ptr(), Nq, T, h, w_, cpt), "l4p_mask_gather")
+        torch.cuda.synchronize()
+        if mfma:
+            # (the kernel rounds ITS float GELU values to the engine type, the statement rounds torch's: values next to a rounding
+            #  boundary land on either side - an ulp of one term in a 176-term sum)
+            err = float((masks.cpu() - want).abs().max() / want.abs().max())
+            assert err <= (3e-3 if td == torch.bfloat16 else 4e-4), err
+        else:
+            check(masks, want, MODE, False)
+        # (both forms are the same function up to the operand rounding: a 176-term dot product of values rounded to 8 / 11 bits)
+        rel = float((masks.cpu() - ref).norm() / ref.norm())
+        assert rel <= (6e-3 if td == torch.bfloat16 else 8e-4), (mfma, rel)
 
 
 def _conv_rows_reference(x_ref, w_ref, bias, rows, stride=(1, 1, 1)):
