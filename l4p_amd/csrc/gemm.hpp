@@ -596,14 +596,31 @@ __device__ __forceinline__ void gemm_epilogue_dense(const GemmParams& p, f32x4 (
             for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r];
         const int m = m_wave0 + i * 16 + li;
         if (m >= p.M) return;  // (rows only run out at the bottom of the matrix: nothing after this row either)
+        if constexpr (ACT == ACT_GELU && std::is_same<T, bf16_t>::value && NV % 8 == 0) {
+            // gelu_poly on four interleaved pairs (gelu_poly2: same operations per element, bit for bit; one pair at a time the
+            // compiler put a wait state behind every packed op of the serial Horner chain)
 #pragma unroll
-        for (int c = 0; c < NV; ++c) {
-            float x = v[c] + bv[c];
-            if (ACT == ACT_GELU)
-                x = gelu_for<T>(x);
-            else if (ACT == ACT_RELU)
-                x = fmaxf(x, 0.f);
-            v[c] = x;
+            for (int c = 0; c < NV; c += 8) {
+                f32x2_t x[4], xc[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    x[k] = (f32x2_t){v[c + 2 * k] + bv[c + 2 * k], v[c + 2 * k + 1] + bv[c + 2 * k + 1]};
+                    xc[k] = (f32x2_t){med3_bare(x[k][0], -4.5f, 4.5f), med3_bare(x[k][1], -4.5f, 4.5f)};
+                }
+                gelu_poly2<4>(x, xc);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[c + 2 * k] = x[k][0], v[c + 2 * k + 1] = x[k][1];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                float x = v[c] + bv[c];
+                if (ACT == ACT_GELU)
+                    x = gelu_for<T>(x);
+                else if (ACT == ACT_RELU)
+                    x = fmaxf(x, 0.f);
+                v[c] = x;
+            }
         }
         if (RES == 1) {
 #pragma unroll
