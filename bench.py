@@ -219,7 +219,8 @@ def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 0, sample_queri
             t_track = (time.time() - t0) * nq / ns
             track_note = f" + tracker {ns}/{nq} queries scaled x{nq / ns:g} = {t_track:.2f}s"
     dt = t_embed + t_blocks * cfg.depth + t_heads + t_track
-    return {"value": round(16.0 / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+    # "cores" = the threads the port actually ran on (torch intra-op pool); "host_cores" = what the box has (os.cpu_count())
+    return {"value": round(16.0 / dt, 4), "unit": "frames/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
             "sample": (f"1 clip (16x224x224), tasks={'+'.join(tasks)}: oracle (plain PyTorch fp32 port of the reference) on the host CPU; "
                        f"timed patch-embed {t_embed:.2f}s + {sample_blocks}/{cfg.depth} encoder blocks ({t_blocks:.2f}s each{'' if sample_blocks == cfg.depth else f', scaled x{cfg.depth}'}) "
                        f"+ dense heads in full {t_heads:.2f}s{track_note} -> {dt:.1f}s per clip")}
