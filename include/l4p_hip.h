@@ -43,7 +43,7 @@ typedef void* l4p_stream; /* hipStream_t */
 typedef struct l4p_engine l4p_engine;
 
 const char* l4p_last_error(void);
-int l4p_abi_version(void); /* 7: L4P_F16; 6: l4p_set_knob / l4p_get_knob; 5: l4p_layernorm_res(out_stats), l4p_layernorm_chain, l4p_stream_create_cu_mask; 4: l4p_gemm_desc.o_gs, l4p_i2t_delta,
+int l4p_abi_version(void); /* 8: l4p_gemm_desc.ups_hi / ups_wi; 7: L4P_F16; 6: l4p_set_knob / l4p_get_knob; 5: l4p_layernorm_res(out_stats), l4p_layernorm_chain, l4p_stream_create_cu_mask; 4: l4p_gemm_desc.o_gs, l4p_i2t_delta,
                               * l4p_t2i_probs, l4p_t2i_context; 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs,
                               * l4p_t2i_attn_scores, l4p_split_hilo, l4p_transpose_pad */
 
@@ -59,6 +59,10 @@ int l4p_stream_destroy(l4p_stream stream);
  *   "maskdot_mfma" (L4P_MASKDOT_MFMA, default 1): L4P_EPI_MASKDOT of the 16-bit engines contracts the activated row with the
  *                hyper-network vectors on the matrix pipe (the row rounded to T first, as the reference's autocast holds it);
  *                0 = the all-VALU form (float row, float dot products)
+ *   "conv_ups"   (L4P_CONV_UPS, default 0): 1 = l4p_dpt_forward forms the up-sampling in front of the head conv inside that conv's
+ *                loader (l4p_gemm_desc.ups_hi) where the shape allows - the same result bit for bit, 822 MB per head never written,
+ *                but MEASURED SLOWER (round 5: head conv 2190 -> 3404 us against 290 us of up-sampling saved: with one pass of four
+ *                taps in flight - all the registers the kernel has left - the taps' latency is not hidden); 0 = up-sample, then convolve
  * l4p_set_knob returns L4P_E_INVALID for an unknown name; l4p_get_knob returns the current value (or -1). */
 int l4p_set_knob(const char* name, int value);
 int l4p_get_knob(const char* name);
@@ -167,6 +171,12 @@ typedef struct l4p_gemm_desc {
     /* ... and write to out_T / out_f32 + g * o_gs (elements; with the c_* row map rows of all groups can land on the same physical rows
      * in their own column blocks: the per-head value projection of the folded token -> image attention, l4p_t2i_context) */
     long long o_gs;
+    /* l4p_conv3d_k3 with the bilinear up-sampling of its input fused into the loader (ups_hi > 0; 16-bit engines, stride 1, the
+     * LDS-halo kernel's shapes: N == 128, Cin % 32 == 0, To % 2 == Ho % 16 == Wo % 16 == 0): A is the LOW-resolution volume
+     * [B][Ti][ups_hi][ups_wi][Cin]; the conv reads F.interpolate(A, (Ti, Hi, Wi), trilinear, align_corners=True) - the time axis is
+     * not resized - rounded to T exactly as l4p_upsample_trilinear would have stored it, without that tensor ever existing
+     * (dpt_head.py:79-84: interpolate -> head conv).  l4p_conv3d_k3 returns L4P_E_INVALID for shapes the fused loader does not take. */
+    int ups_hi, ups_wi;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);

@@ -121,12 +121,15 @@ struct Ctx {
         return o;
     }
     // 3x3x3 conv, pad 1; optional bias / ReLU output / two T residuals / relu copy
-    Vol conv3(const Vol& x, const char* wk, const char* bk, int cout, const int s[3], int act, const void* r1, const void* r2,
-              Vol* relu_copy) {
+    // ups_h / ups_w > 0: the conv reads x up-sampled (bilinear, align_corners) to ups_h x ups_w, formed in its loader
+    Vol conv3(const Vol& x_in, const char* wk, const char* bk, int cout, const int s[3], int act, const void* r1, const void* r2,
+              Vol* relu_copy, int ups_h = 0, int ups_w = 0) {
+        Vol x = x_in;
+        if (ups_h > 0) x.h = ups_h, x.w = ups_w;
         Vol o = vol((x.t - 1) / s[0] + 1, (x.h - 1) / s[1] + 1, (x.w - 1) / s[2] + 1, cout);
         if (relu_copy) *relu_copy = vol(o.t, o.h, o.w, cout);
         const long long M = o.vox(B);
-        const int sk = splitk_for(M, cout, 27 * x.c, es);
+        const int sk = ups_h > 0 ? 1 : splitk_for(M, cout, 27 * x.c, es);
         float* partial = sk > 1 ? (float*)alloc((size_t)sk * M * cout * 4) : nullptr;
         if (rc || dry) return o;
         GemmParams p;
@@ -160,6 +163,7 @@ struct Ctx {
         p.out_relu_T = relu_copy ? relu_copy->p : nullptr;
         p.splitk = sk;
         p.partial = partial;
+        if (ups_h > 0) p.ups_hi = x_in.h, p.ups_wi = x_in.w;
         if (!rc) rc = launch_gemm(dt, 1, p, st);
         return o;
     }
@@ -229,8 +233,20 @@ int run(Ctx& c, const l4p_dpt_cfg* cfg, const void* const* hooks, float* out) {
         if (c.rc) return c.rc;
     }
     Vol h1 = c.conv3(path, "head1.w", "head1.b", F / 2, one, ACT_NONE, nullptr, nullptr, nullptr);
-    Vol h1u = c.resize(h1, cfg->out_t, cfg->out_h, cfg->out_w);
-    Vol h2 = c.conv3(h1u, "head2.w", "head2.b", cfg->last_dim, one, ACT_RELU, nullptr, nullptr, nullptr);
+    // dpt_head.py:79-84: interpolate -> head conv.  Knob conv_ups = 1 (off by default: measured slower, include/l4p_hip.h): where the
+    // LDS-halo kernel's fused loader takes the shape (16-bit engines, time axis not resized, 128 output channels, whole 2 x 16 x 16
+    // blocks: the full geometry) the up-sampled volume never exists
+    Vol h2;
+    const bool fuse = is16(c.dt) && knob(KNOB_CONV_UPS) && cfg->out_t == h1.t && (cfg->out_h != h1.h || cfg->out_w != h1.w) &&
+                      cfg->last_dim == 128 && h1.c % 32 == 0 && cfg->out_t % 2 == 0 && cfg->out_h % 16 == 0 && cfg->out_w % 16 == 0 &&
+                      (long long)c.B * cfg->out_t * cfg->out_h * cfg->out_w / 512 >= 192 &&
+                      (long long)c.B * cfg->out_t * cfg->out_h * cfg->out_w * h1.c * 2 < (1ll << 32);
+    if (fuse && !c.dry) {  // (the workspace is sized for the un-fused form: the knob may change between sizing and a forward)
+        h2 = c.conv3(h1, "head2.w", "head2.b", cfg->last_dim, one, ACT_RELU, nullptr, nullptr, nullptr, cfg->out_h, cfg->out_w);
+    } else {
+        Vol h1u = c.resize(h1, cfg->out_t, cfg->out_h, cfg->out_w);
+        h2 = c.conv3(h1u, "head2.w", "head2.b", cfg->last_dim, one, ACT_RELU, nullptr, nullptr, nullptr);
+    }
     if (c.rc || c.dry) return c.rc;
     return launch_head_out(c.dt, h2.p, (const float*)c.W("out.w"), (const float*)c.W("out.b"), out,
                            (long long)h2.t * h2.h * h2.w, c.B, cfg->last_dim, cfg->out_ch, cfg->post_exp, c.st);

@@ -46,7 +46,14 @@ struct ConvHaloCfg {
     static constexpr int H_PASS = (PRP * 4 + 511) / 512;   // ... per halo plane
 };
 
-template <typename T, int WR, int WC>
+// UPS (round 5): the halo block is not copied but COMPUTED - the conv's input is the bilinear (align_corners) up-sampling of the
+// low-resolution volume p.A [B][Ti][ups_hi][ups_wi][Cin] to (Hi, Wi) (dpt_head.py:79-84: interpolate -> head conv), which then never
+// exists in memory (822 MB written and read per dense head and step at the full geometry).  A halo slot = 8 channels of one voxel:
+// its lane requests the four source taps (4 x 16 bytes) where the copy form issued one LDS-DMA, and one k-tile later - the loads have
+// landed behind that k-tile's MFMAs - forms sum w_ab * v_ab in the order and with the rounding of upsample_line (dpt_ops.hip: the
+// fused conv equals up-sample + conv bit for bit) and writes the 16 bytes into the halo with ds_write_b128.  The refill schedule and
+// its hazards are the copy form's with every write one k-tile later (later than a plane's last read, >= 5 k-tiles before its first).
+template <typename T, int WR, int WC, bool UPS = false>
 __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
     static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
     typedef ConvHaloCfg<WR, WC> Cfg;
@@ -114,8 +121,87 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
         const int c = (s & 3) ^ (((hw >> 2) & 1) << 1);  // logical chunk held by this physical slot
         h_off[i] = h_ok[i] ? (unsigned)(((long long)gh * p.Wi + gw) * p.Cin * 2 + c * 16) : 0u;
     }
-    const long long plane_bytes = (long long)p.Hi * p.Wi * p.Cin * 2;
+    const long long plane_bytes = UPS ? (long long)p.ups_hi * p.ups_wi * p.Cin * 2 : (long long)p.Hi * p.Wi * p.Cin * 2;
     const char* zero = (const char*)g_zero_chunk;
+    // UPS: source taps of this lane's slot of pass i: byte offset of tap (y0, x0) inside a low-resolution (b, t) plane, the byte
+    // steps to y1 / x1 (0 at the border) and the two interpolation weights (ATen's index / lambda arithmetic, dpt_ops.hip src_index)
+    unsigned u_off[UPS ? H_PASS : 1];  // (a multiple of 16: bit 0 = the y1 tap is one row on, bit 1 = the x1 tap is one voxel on)
+    float u_lh[UPS ? H_PASS : 1], u_lw[UPS ? H_PASS : 1];
+    if constexpr (UPS) {
+#pragma unroll
+        for (int i = 0; i < H_PASS; ++i) {
+            const int s = i * 512 + tid, r = s >> 2;
+            const int hh = r / HW, hw = r - hh * HW;
+            const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+            const int c = (s & 3) ^ (((hw >> 2) & 1) << 1);
+            auto src_index = [](int dst, int in, int out, int& i0, int& i1, float& lam) {
+                const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+                const float src = scale * (float)dst;
+                i0 = (int)src;
+                if (i0 > in - 1) i0 = in - 1;
+                lam = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+                i1 = i0 + (i0 < in - 1 ? 1 : 0);
+            };
+            int y0 = 0, y1 = 0, x0 = 0, x1 = 0;
+            float lh = 0.f, lw = 0.f;
+            if (h_ok[i]) {
+                src_index(gh, p.ups_hi, p.Hi, y0, y1, lh);
+                src_index(gw, p.ups_wi, p.Wi, x0, x1, lw);
+            }
+            u_off[i] = (unsigned)(((long long)y0 * p.ups_wi + x0) * p.Cin * 2 + c * 16) | (y1 > y0 ? 1u : 0u) | (x1 > x0 ? 2u : 0u);
+            u_lh[i] = lh, u_lw[i] = lw;
+        }
+    }
+    // a pass = this lane's four taps, where the slot goes and whether it lies inside the volume
+    struct UpsPass {
+        u32x4 v[4];
+        int lds;  // LDS byte offset of the slot (-1: nothing pending)
+        bool ok;
+        float lh, lw;
+    };
+    auto ups_load = [&](int plane, int cs, int pass, UpsPass& u) {
+#pragma unroll
+        for (int i = 0; i < H_PASS; ++i) {
+            if (i != pass) continue;
+            if (i * 512 + wave * 64 >= PRP * 4) continue;
+            const int gt = t0 - 1 + plane;
+            u.ok = h_ok[i] && (unsigned)gt < (unsigned)p.Ti;
+            const char* src = (const char*)p.A + ((long long)bb * p.Ti + (u.ok ? gt : 0)) * plane_bytes + (u_off[i] & ~15u) + cs * 64;
+            const unsigned dy = (u_off[i] & 1u) ? (unsigned)(p.ups_wi * p.Cin * 2) : 0u, dx = (u_off[i] & 2u) ? (unsigned)(p.Cin * 2) : 0u;
+            u.v[0] = *(const u32x4*)src;
+            u.v[1] = *(const u32x4*)(src + dx);
+            u.v[2] = *(const u32x4*)(src + dy);
+            u.v[3] = *(const u32x4*)(src + dy + dx);
+            u.lh = u_lh[i], u.lw = u_lw[i];
+            u.lds = (plane * PRP * 4 + i * 512 + tid) * 16;
+        }
+    };
+    auto ups_store = [&](UpsPass& u) {
+        if (u.lds < 0) return;
+        // upsample_line<T, .., NT = 1, NH>: acc += (wh[a] * ww[b]) * v[a][b] over (a, b) = (0,0) (0,1) (1,0) (1,1), fused multiply-adds;
+        // a zero weight adds exactly nothing, as the tap that form skips
+        const float wh[2] = {1.f - u.lh, u.lh}, ww[2] = {1.f - u.lw, u.lw};
+        vec8<T> o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const vec8<T> v = __builtin_bit_cast(vec8<T>, u.v[2 * a + b]);
+                    acc = __builtin_fmaf(wh[a] * ww[b], (float)v[k], acc);
+                }
+            o[k] = (T)acc;
+        }
+        const u32x4 zz = {0u, 0u, 0u, 0u};
+        *(u32x4*)(smem + u.lds) = u.ok ? __builtin_bit_cast(u32x4, o) : zz;
+        u.lds = -1;
+    };
+    UpsPass ub;  // the pass in flight in the main loop
+    ub.lds = -1;
+    auto ups_issue = [&](int plane, int cs, int pass) { ups_load(plane, cs, pass, ub); };
+    auto ups_finish = [&]() { ups_store(ub); };
     auto stage_halo = [&](int plane, int cs, int pass) {  // one LDS-DMA instruction (per lane) of a halo plane
 #pragma unroll
         for (int i = 0; i < H_PASS; ++i) {
@@ -177,14 +263,32 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
     };
 
     // ---- prologue: the whole halo of slice 0 and W(0..2) ----
-#pragma unroll
-    for (int pl = 0; pl < Cfg::NPL; ++pl)
-#pragma unroll
-        for (int i = 0; i < H_PASS; ++i) stage_halo(pl, 0, i);
     const int tap_bytes = p.Cin * 2;
-    stage_w(0, 0);
-    stage_w(1, tap_bytes);
-    stage_w(2, 2 * tap_bytes);
+    if constexpr (UPS) {
+        stage_w(0, 0);
+        stage_w(1, tap_bytes);
+        stage_w(2, 2 * tap_bytes);
+        // (the accumulators are not live yet: two planes' passes are requested together before the first is consumed)
+#pragma unroll
+        for (int pl = 0; pl < Cfg::NPL; ++pl) {
+            UpsPass pb[H_PASS];
+#pragma unroll
+            for (int i = 0; i < H_PASS; ++i) {
+                pb[i].lds = -1;
+                ups_load(pl, 0, i, pb[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < H_PASS; ++i) ups_store(pb[i]);
+        }
+    } else {
+#pragma unroll
+        for (int pl = 0; pl < Cfg::NPL; ++pl)
+#pragma unroll
+            for (int i = 0; i < H_PASS; ++i) stage_halo(pl, 0, i);
+        stage_w(0, 0);
+        stage_w(1, tap_bytes);
+        stage_w(2, 2 * tap_bytes);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -206,6 +310,31 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
         bar();
         // ---- P2 ----
         read_a(1, abase);
+        if constexpr (UPS) {
+            // one pass in flight (its four taps = 16 registers; the kernel sits at 256), requested at an EVEN tap and consumed two
+            // k-tiles later: plane 2 of this slice at taps 0 2 4 (written by 6, first read at 9), plane 3 at 6 8 10 (by 12, read at 18),
+            // the next slice's plane 0 at 12 14 16 (free since tap 9, written by 18) and plane 1 at 18 20 22 (free since 18, written by
+            // 24); H_PASS == 3.  (Consumed ONE k-tile later the loads were still in flight: 2226 -> 3566 us.)
+            static_assert(H_PASS == 3, "the fused loader's schedule is laid out for three passes per plane");
+            bool issued = false;
+            if ((tap & 1) == 0) {
+                ups_finish();
+                const int q = tap >> 1;  // 0 .. 13
+                if (q < 3) {
+                    if (cs > 0) ups_issue(2, cs, q), issued = true;
+                } else if (q < 6) {
+                    if (cs > 0) ups_issue(3, cs, q - 3), issued = true;
+                } else if (q < 9) {
+                    if (cs + 1 < ncs) ups_issue(0, cs + 1, q - 6), issued = true;
+                } else if (q < 12) {
+                    if (cs + 1 < ncs) ups_issue(1, cs + 1, q - 9), issued = true;
+                }
+            }
+            // W(t+1) has landed: the two youngest W tiles - and the four tap loads of a pass in flight - may stay in flight
+            if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W_PASS + 4) : "memory");
+            else if (ub.lds >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W_PASS + 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W_PASS) : "memory");
+        } else {
         if (cs + 1 < ncs) {  // next slice's planes 0 / 1 once the current slice no longer reads them
             if (tap >= 9 && tap < 9 + H_PASS) stage_halo(0, cs + 1, tap - 9);
             if (tap >= 18 && tap < 18 + H_PASS) stage_halo(1, cs + 1, tap - 18);
@@ -215,6 +344,7 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
             else if (tap < 2 * H_PASS) stage_halo(3, cs, tap - H_PASS);
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * W_PASS) : "memory");  // W(t+1) (and everything older) has landed
+        }
         bar();
         mfma16(1);
         bar();

@@ -11,6 +11,10 @@ int launch_gemm(int dtype, int mode, const GemmParams& p, hipStream_t stream) {
     if ((p.K * es) % 16 || (p.ldw * es) % 16) { l4p_set_error("gemm: K/ldw not 16-byte aligned"); return L4P_E_INVALID; }
     if (mode == 0 && (p.lda * es) % 16) { l4p_set_error("gemm: lda not 16-byte aligned"); return L4P_E_INVALID; }
     if (mode == 1 && (p.Cin % (128 / es) || p.K != 27 * p.Cin)) { l4p_set_error("conv3d: Cin=%d must be a multiple of %d and K=27*Cin", p.Cin, 128 / es); return L4P_E_INVALID; }
+    if (p.ups_hi > 0 && (mode != 1 || !is16(dtype) || p.ups_wi <= 0 || p.To != p.Ti)) {
+        l4p_set_error("conv3d: the fused up-sampling loader (ups_hi / ups_wi) exists for l4p_conv3d_k3 on the 16-bit engines, time axis not resized");
+        return L4P_E_INVALID;
+    }
     if (p.splitk > 1) {
         const int bk = 128 / es, nk = (p.K + bk - 1) / bk;
         if (p.epi != L4P_EPI_DENSE || !p.partial || p.splitk > nk || p.c_gr > 0) {

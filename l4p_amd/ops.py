@@ -184,11 +184,16 @@ def patch_gather(rgb: torch.Tensor, patch: Tuple[int, int, int], kp: int, dtype:
 
 def conv3d_k3(x: torch.Tensor, w: torch.Tensor, cout: int, *, stride: Tuple[int, int, int] = (1, 1, 1),
               bias: Optional[torch.Tensor] = None, relu_in: bool = False, act: int = ACT_NONE,
-              res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, relu_copy: bool = False):
+              res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, relu_copy: bool = False,
+              ups_to: Optional[Tuple[int, int]] = None):
     """3x3x3 conv, pad 1, channels-last: x [B,T,H,W,Cin] -> [B,To,Ho,Wo,cout]; w [ceil128(cout)][27*Cin].
-    ``relu_copy=True`` additionally returns relu(out) (written by the same epilogue)."""
+    ``relu_copy=True`` additionally returns relu(out) (written by the same epilogue).  ``ups_to=(H, W)``: the conv reads the
+    bilinear (align_corners) up-sampling of x to (H, W), formed in its loader (l4p_gemm_desc.ups_hi / ups_wi)."""
     dtype = code_of(x.dtype)
     B, Ti, Hi, Wi, Cin = x.shape
+    lo = None
+    if ups_to is not None:
+        lo, (Hi, Wi) = (Hi, Wi), ups_to
     st, sh, sw = stride
     To, Ho, Wo = (Ti - 1) // st + 1, (Hi - 1) // sh + 1, (Wi - 1) // sw + 1
     out = torch.empty((B, To, Ho, Wo, cout), dtype=x.dtype, device=x.device)
@@ -201,9 +206,11 @@ def conv3d_k3(x: torch.Tensor, w: torch.Tensor, cout: int, *, stride: Tuple[int,
     if res1 is not None:
         d.res1, d.res2, d.res_f32, d.ldr = _p(res1), _p(res2), 0, cout
     d.out_T, d.ldc = _p(out), cout
+    if lo is not None:
+        d.ups_hi, d.ups_wi = lo
     out_relu = torch.empty_like(out) if relu_copy else None
     d.out_relu_T = _p(out_relu)
-    sk = splitk_for(d.M, cout, 27 * Cin, x.element_size())
+    sk = splitk_for(d.M, cout, 27 * Cin, x.element_size()) if lo is None else 1
     if sk > 1:
         partial = torch.empty((sk, d.M, cout), dtype=torch.float32, device=x.device)
         d.splitk, d.partial = sk, _p(partial)

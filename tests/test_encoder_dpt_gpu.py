@@ -105,3 +105,37 @@ def test_native_dpt_call_equals_python_composition(dev, mini, precision, monkeyp
     torch.cuda.synchronize()
     for k in ("depth_est_b1thw", "traj3d_est_b16t"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("precision", ["bf16", "16-mixed"])
+def test_dpt_head_with_the_upsampling_fused_into_the_head_conv(dev, mini, precision, knob):
+    """l4p_dpt_forward: interpolate -> head conv (dpt_head.py:79-84) with the up-sampling formed in the conv's loader (knob conv_ups,
+    default) against up-sample-then-convolve: every dense output bit for bit, and the fused form is the one that ran."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+
+    cfg, sd = mini
+    model = build(cfg, sd, precision)
+    batch = make_batch(16, 2)
+    tasks = ["depth", "flow_2d_backward", "dyn_mask"]
+    lib = _lib.load()
+    outs = {}
+    for v in (1, 0):
+        knob("conv_ups", v)
+        torch.cuda.synchronize()
+        lib.l4p_prof_reset()
+        lib.l4p_prof_enable(1)
+        with torch.no_grad():
+            o = model.forward({k: t.clone() for k, t in batch.items()}, tasks)
+        torch.cuda.synchronize()
+        lib.l4p_prof_enable(0)
+        n = lib.l4p_prof_detail(None, 0)
+        buf = C.create_string_buffer(int(n) + 16)
+        lib.l4p_prof_detail(buf, len(buf))
+        tags = buf.value.decode()
+        lib.l4p_prof_reset()
+        assert (" halo ups " in tags) == bool(v), tags[:2000]
+        outs[v] = {k: t.clone() for k, t in o.items() if torch.is_tensor(t)}
+    for k in outs[1]:
+        assert torch.equal(outs[1][k], outs[0][k]), k

@@ -425,3 +425,28 @@ def test_conv3_halo_equals_implicit_gemm_form(dev, knob):
     d = (a.float() - b.float()).abs()
     assert float(d.max()) <= 2 ** -6 * float(b.float().abs().max()), float(d.max())  # <= 2 bf16 ulp of the maximum, everywhere
     assert float((a.float() - b.float()).norm() / b.float().norm()) <= 3e-3
+
+
+@pytest.mark.parametrize("B,T,lo,hi", [(1, 16, (128, 128), (224, 224)), (2, 4, (60, 72), (112, 128))])
+def test_conv3_halo_fused_upsample_equals_upsample_then_conv(dev, B, T, lo, hi):
+    """l4p_gemm_desc.ups_hi / ups_wi: the bilinear (align_corners) up-sampling in front of a 3x3x3 conv formed inside the LDS-halo
+    kernel's loader (dpt_head.py:79-84: interpolate -> head conv) - equal, bit for bit, to l4p_upsample_trilinear followed by the
+    conv on the stored volume: the loader reproduces that kernel's arithmetic and rounding.  Full-size head shape and a small,
+    non-square one with a fractional scale in both axes."""
+    Cin, cout = 128, 128
+    x, _ = as_mode(rnd((B, T, lo[0], lo[1], Cin), 400), MODE)
+    w = rnd((cout, Cin, 3, 3, 3), 401, (27 * Cin) ** -0.5)
+    wT, _ = as_mode(w.permute(0, 2, 3, 4, 1).reshape(cout, 27 * Cin), MODE)
+    wp = ops.pad_rows(wT, 256)
+    bias = rnd((cout,), 402).cuda()
+    up = ops.upsample_trilinear(x, (T, hi[0], hi[1]), align_corners=True)
+    with prof_tags() as p:
+        want = ops.conv3d_k3(up, wp, cout, bias=bias, act=ACT_RELU)
+    assert any(" halo " in ln[1] for ln in p.lines), p.lines
+    with prof_tags() as p:
+        got = ops.conv3d_k3(x, wp, cout, bias=bias, act=ACT_RELU, ups_to=hi)
+    assert any(" halo ups " in ln[1] for ln in p.lines), p.lines
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    again = ops.conv3d_k3(x, wp, cout, bias=bias, act=ACT_RELU, ups_to=hi)
+    assert torch.equal(got, again)
