@@ -23,6 +23,10 @@ python bench.py --workload c5 --steps 3 --warmup 1 > $O/${TAG}_c5_bench_line.jso
 python bench.py --workload demo --steps 3 --warmup 1 > $O/${TAG}_demo_bench_line.json 2> $O/${TAG}_demo.err
 python bench.py --workload prep --steps 50 --warmup 10 > $O/${TAG}_prep_bench_line.json 2> $O/${TAG}_prep.err
 python bench.py --batch 8 --steps 10 --warmup 3 > $O/${TAG}_c3_batch8_bench_line.json 2> $O/${TAG}_c3_batch8.err
+# the other two engines on the same workload: IEEE half (the reference demo's own "16-mixed") and the exact-f32 parity engine (priced
+# against the 157 TF f32-input MFMA peak)
+python bench.py --precision 16-mixed --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_c3_f16_bench_line.json 2> $O/${TAG}_c3_f16.err
+python bench.py --precision 32-true --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_c3_f32_bench_line.json 2> $O/${TAG}_c3_f32.err
 python tools/prof_detail.py c3 5 > $O/${TAG}_c3_per_shape_event_profile.txt 2>/dev/null
 python tools/prof_detail.py c2 10 > $O/${TAG}_c2_per_shape_event_profile.txt 2>/dev/null
 cd /tmp
@@ -36,6 +40,12 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $O/pmc
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_${TAG}_grbm -o out -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
 cd $R
 bash tools/probes/power_probe.sh > $O/${TAG}_power_probe.txt 2>&1
+# FETCH_SIZE / WRITE_SIZE calibration by access width (the x2 of FETCH_SIZE is measured here, not assumed)
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_${TAG}_calib_f -- $R/tools/probes/fetch_calib > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_${TAG}_calib_w -- $R/tools/probes/fetch_calib > /dev/null 2>&1
+cd $R
+python tools/pmc_fetch_calibration.py $O/pmc_${TAG}_calib_f $O/pmc_${TAG}_calib_w > $O/${TAG}_fetch_size_calibration.md 2>/dev/null
 python tools/pmc_mfma_util.py $O/pmc_${TAG}_sq $O/pmc_${TAG}_grbm $O/${TAG}_power_probe.txt > $O/${TAG}_c3_mfma_util.md 2> $O/${TAG}_mfma_util.err
 python tools/rocprof_summary.py $(find $O/prof_${TAG}_c3 -name "*.db" | head -1) "L4P_TRACK_STREAMS=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof (c3: 7 steps, every kernel serialised on one stream)" > $O/${TAG}_c3_kernel_stats.md
 python tools/rocprof_summary.py $(find $O/prof_${TAG}_c2 -name "*.db" | head -1) "python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-prof (c2: 13 steps)" > $O/${TAG}_c2_kernel_stats.md
