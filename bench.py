@@ -660,7 +660,9 @@ def main():
             with open(tpath) as f:
                 tj = json.load(f)
             # only figures measured on THESE kernels: the file carries the hash of the kernel sources it was taken on
-            if tj.get("kernel_tree") == _lib.kernel_tree_hash():
+            if ENGINE_PRECISION != "bf16":
+                traffic_note = f"profiles/{os.path.basename(tpath)} was measured on the bf16 engine: not attached to a {PRECISION[ENGINE_PRECISION][0]} line"
+            elif tj.get("kernel_tree") == _lib.kernel_tree_hash():
                 traffic = {k: v["hbm_total"] for k, v in tj["per_class_bytes_per_launch"].items()}
                 traffic_note = f"profiles/{os.path.basename(tpath)} (kernel tree {tj['kernel_tree']})"
             else:
