@@ -181,6 +181,13 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
         // upsample_line<T, .., NT = 1, NH>: acc += (wh[a] * ww[b]) * v[a][b] over (a, b) = (0,0) (0,1) (1,0) (1,1), fused multiply-adds;
         // a zero weight adds exactly nothing, as the tap that form skips
         const float wh[2] = {1.f - u.lh, u.lh}, ww[2] = {1.f - u.lw, u.lw};
+        // (the four products as single v_mul_f32: the vectoriser made packed multiplies with a swizzled operand of them - the form
+        //  tools/check_isa.py bans)
+        float wgt[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) asm("v_mul_f32 %0, %1, %2" : "=v"(wgt[a][b]) : "v"(wh[a]), "v"(ww[b]));
         vec8<T> o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const vec8<T> v = __builtin_bit_cast(vec8<T>, u.v[2 * a + b]);
-                    acc = __builtin_fmaf(wh[a] * ww[b], (float)v[k], acc);
+                    acc = __builtin_fmaf(wgt[a][b], (float)v[k], acc);
                 }
             o[k] = (T)acc;
         }
