@@ -42,7 +42,7 @@ def test_ckpt_to_arena_roundtrip(tmp_path):
     sd = seeded_state_dict(cfg)
     ckpt = tmp_path / "mini.ckpt"
     torch.save({"state_dict": {"l4p_model." + k: v for k, v in sd.items()}, "epoch": 3}, ckpt)  # Lightning layout
-    for precision, td in (("bf16", torch.bfloat16), ("32-true", torch.float32)):
+    for precision, td in (("bf16", torch.bfloat16), ("16-mixed", torch.float16), ("32-true", torch.float32)):
         out = tmp_path / f"mini.{precision}.l4parena"
         info = convert(str(ckpt), str(out), precision, cfg=cfg)
         assert PackedWeights.is_arena_file(str(out)) and not PackedWeights.is_arena_file(str(ckpt))

@@ -26,7 +26,7 @@ def _forward(model, tasks, nq=5):
     return {k: out[k].clone() for k in KEYS if k in out}
 
 
-@pytest.mark.parametrize("precision", ["bf16", "32-true"])
+@pytest.mark.parametrize("precision", ["bf16", "16-mixed", "32-true"])
 def test_prepare_model_from_ckpt_and_arena_mini(dev, tmp_path, precision):
     from tools.ckpt_to_arena import convert
 

@@ -1,7 +1,7 @@
 """Offline checkpoint ingest: reference Lightning checkpoint -> packed weight arena.
 
   python tools/ckpt_to_arena.py weights/l4p_depth_flow_2d3dtrack_camray_dynseg_v1.ckpt weights/l4p.bf16.l4parena
-         [--precision bf16|32-true] [--tasks depth,flow_2d_backward,...] [--mini]
+         [--precision bf16|16-mixed|32-true] [--tasks depth,flow_2d_backward,...] [--mini]
 
 Reads {"state_dict": {916 keys prefixed "l4p_model."}} (l4p/models/utils.py:52-53), checks it strictly against the
 schema (l4p_amd.weights.state_dict_schema == the reference's key set and shapes), repacks every tensor into the kernel
@@ -33,9 +33,10 @@ def convert(ckpt_path: str, out_path: str, precision: str = "bf16", tasks=None, 
     if missing or bad:
         raise SystemExit(f"checkpoint does not match the model schema: missing={missing[:5]} ({len(missing)}), "
                          f"shape mismatch={bad[:5]} ({len(bad)})")
-    td = torch.bfloat16 if precision in ("bf16", "16-mixed", "bf16-mixed") else torch.float32
+    td = (torch.bfloat16 if precision in ("bf16", "bf16-mixed", "bf16-true") else
+          torch.float16 if precision in ("16-mixed", "16-true", "f16", "fp16") else torch.float32)
     pw = pack_state_dict(sd, cfg, td, torch.device("cpu"), tasks=tasks)
-    extra = {"dtype": "bfloat16" if td == torch.bfloat16 else "float32", "geometry": cfg.describe(),
+    extra = {"dtype": {torch.bfloat16: "bfloat16", torch.float16: "float16", torch.float32: "float32"}[td], "geometry": cfg.describe(),
              "tasks": list(tasks) if tasks else None, "source": os.path.basename(ckpt_path)}
     pw.save(out_path, extra)
     return {"tensors": len(pw.layout), "bytes": int(pw.arena.numel()), **extra}
