@@ -514,6 +514,8 @@ def main():
                     "16-mixed (IEEE half: the reference demo's own mode), 32-true (exact-f32 parity engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--host-io", action="store_true", help="c2 / c3: after the timed steps, K more with the inputs coming from and every output going to "
+                                                           "pinned host memory; reported as pcie_inclusive (never as value)")
     args = ap.parse_args()
     global ENGINE_PRECISION
     ENGINE_PRECISION = args.precision
@@ -578,6 +580,35 @@ def main():
         os.environ.pop("L4P_TRACK_STREAMS", None)
     if world > 1:
         dist.barrier()
+    # ---- the same K steps once more with the boundary handed HOST buffers (what a DataLoader delivers, l4p.py:54-66 moves them to
+    #      the device): inputs start in pinned host memory, every output tensor ends in pinned host memory.  Reported beside
+    #      `value` as "pcie_inclusive"; never `value` itself.
+    pcie = None
+    if not c5 and args.host_io:
+        hbatch = {k: (v.cpu().pin_memory() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        hout = {}
+
+        def host_step():
+            with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
+                out = model.forward({k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in hbatch.items()}, tasks)
+            for k, v in out.items():
+                if torch.is_tensor(v):
+                    if k not in hout:
+                        hout[k] = torch.empty(v.shape, dtype=v.dtype).pin_memory()
+                    hout[k].copy_(v, non_blocking=True)
+
+        host_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            host_step()
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t1
+        pcie = {"value": round(world * B * 16 * args.steps / dth, 3), "unit": "frames/s (this rank's rate x ranks)", "ms_per_step": round(dth / args.steps * 1e3, 3),
+                "h2d_bytes_per_step": int(sum(v.numel() * v.element_size() for v in hbatch.values() if torch.is_tensor(v))),
+                "d2h_bytes_per_step": int(sum(v.numel() * v.element_size() for v in hout.values())),
+                "note": "inputs from pinned host memory, all outputs copied to pinned host memory, inside the timed steps"}
+        del hbatch, hout
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -604,6 +635,8 @@ def main():
                    "parallelism": (f"windows sharded over {world} rank(s); all-gather of the last-layer features after the encoders, query-sharded tracker beside the decoders, all-gather of the decoded windows, stitching replicated" if c5
                                    else f"dp{world} (clips sharded, no collective in the step)")},
     }
+    if pcie:
+        res["pcie_inclusive"] = pcie
     if phases:
         res.update(phases)
         if world == 1 and "implied_8gpu_ms_tracker_beside_decoders" in phases:
