@@ -63,6 +63,10 @@ int l4p_stream_destroy(l4p_stream stream);
  *                loader (l4p_gemm_desc.ups_hi) where the shape allows - the same result bit for bit, 822 MB per head never written,
  *                but MEASURED SLOWER (round 5: head conv 2190 -> 3404 us against 290 us of up-sampling saved: with one pass of four
  *                taps in flight - all the registers the kernel has left - the taps' latency is not hidden); 0 = up-sample, then convolve
+ *   "ln_tracks"  (L4P_LN_TRACKS, default 1): the tracker's key LayerNorms (l4p_layernorm_res / l4p_layernorm_chain with a positional
+ *                addend of period P = add_mod over whole tracks) run laid out by TOKEN: a wave owns one token and walks its tracks,
+ *                the shared float rows stay in registers and the parameter vectors in LDS (bit-identical to the row kernels;
+ *                473 -> 223 us and 485 -> 309 us for 64 tracks x 2048 tokens); 0 = one wave per row
  * l4p_set_knob returns L4P_E_INVALID for an unknown name; l4p_get_knob returns the current value (or -1). */
 int l4p_set_knob(const char* name, int value);
 int l4p_get_knob(const char* name);

@@ -1,6 +1,7 @@
 // HBM-bound kernels of the encoder path: LayerNorm, tubelet im2col (patch embed gather), casts.
 // All are one-pass, 16-byte vectorised, one wave per row where a row reduction is needed.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -208,6 +209,13 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
     return 0;
 }
 
+// (the token-ordered form of the first window's key LayerNorms: key_ln_tracks_kernel below)
+static bool key_ln_tracks_fits(int M, int C, int x_mod, int add_mod, const void* add, const void* out_T, const void* out_T2);
+template <typename T, bool CHAIN>
+static void launch_key_ln_tracks(const float* xs, int P, const void* dprev, const float* stats_in, const float* g0, const float* b0,
+                                 const void* delta, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M, int C,
+                                 const float* add, void* out_T2, float* out_stats, hipStream_t stream);
+
 // y = LayerNorm(x[row % x_mod] + delta[row]) with the tracker's outputs (see layernorm_kernel RES); out_sum (may alias x when
 // x_mod = 0): the float sum itself - the encoder's pre-norm residual stream, where y is only the next linear's input;
 // part / nsplit / pbias: the addend is bias + nsplit float partials [nsplit][M][C] of a split-K projection instead of delta
@@ -229,6 +237,13 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
         return L4P_E_INVALID;
     }
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d res T2%d f32%d", M, C, out_T2 != nullptr, out_f32 != nullptr);
+    if (!x_shared && !part && !out_sum && delta_T && key_ln_tracks_fits(M, C, x_mod, add_mod, add, out_T, out_T2)) {
+        if (is16(dtype)) L4P_WITH_T16(dtype, T16, (launch_key_ln_tracks<T16, false>(x, x_mod, nullptr, nullptr, nullptr, nullptr, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, out_stats, stream)));
+        else
+            launch_key_ln_tracks<float, false>(x, x_mod, nullptr, nullptr, nullptr, nullptr, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, out_stats, stream);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((M + 3) / 4);
     if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
         if (C <= 512)
@@ -354,6 +369,164 @@ __global__ __launch_bounds__(256) void layernorm_chain_kernel(const float* __res
         }
     }
 }
+// ---------------------------------------------------------------------------------------------
+// The two key LayerNorms of a FIRST window again (layer 0: layernorm_kernel<RES> with every float row shared; layer 1:
+// layernorm_chain_kernel), with the work laid out by TOKEN instead of by row (round 5).  In the row kernels a wave reads, beside
+// the 5.6 - 11 KB that belong to its (track, token) row, the token's shared float key row and positional row (11 KB, from L2 /
+// the Infinity Cache: the 2 x 11.5 MB sets do not fit the 4 MB L2) and two or four parameter vectors (11 - 22 KB through the
+// vector L1): three to five times the unique bytes through the CU's 64 B/clk memory pipe.  tools/probes/stream_bw: the unique
+// traffic alone streams in 183 / 250 us, with the two shared rows per row 301 / 371 us; the row kernels took 474 / 495 us.
+// Here a wave owns ONE token p and walks tracks n0 .. n0 + nt - 1 of it (rows n * P + p): the shared rows are loaded ONCE into
+// registers, the parameter vectors ONCE per workgroup into LDS, and the per-track operands of track n + 1 are requested before
+// track n is reduced.  Per-row arithmetic is the row kernels' statement for statement (ln_affine, the uncontracted variance,
+// the same summation order): bit-identical outputs (tests/test_track_gpu.py).
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool CHAIN>
+__global__ __launch_bounds__(256) void key_ln_tracks_kernel(const float* __restrict__ xs, int P, const T* __restrict__ dprev,
+                                                            const float* __restrict__ stats_in, const float* __restrict__ g0,
+                                                            const float* __restrict__ b0, const T* __restrict__ delta,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            T* __restrict__ out_T, float* __restrict__ out_f32, int N, int C,
+                                                            const float* __restrict__ add, T* __restrict__ out_T2,
+                                                            float* __restrict__ out_stats, int tpw) {
+    constexpr int MAXV = 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [gamma | beta | g0 | b0][C] floats
+    f32x4* const sp = (f32x4*)smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    const int ptiles = P >> 2;
+    const int p = ((int)blockIdx.x % ptiles) * 4 + wave;
+    const int n0 = ((int)blockIdx.x / ptiles) * tpw;
+    const int n1 = n0 + tpw < N ? n0 + tpw : N;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        sp[i] = ((const f32x4*)gamma)[i];
+        sp[nv + i] = ((const f32x4*)beta)[i];
+        if constexpr (CHAIN) {
+            sp[2 * nv + i] = ((const f32x4*)g0)[i];
+            sp[3 * nv + i] = ((const f32x4*)b0)[i];
+        }
+    }
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 xv[MAXV], av[MAXV];
+    typedef typename std::conditional<sizeof(T) == 2, vec4h<T>, f32x4>::type op_t;
+    op_t dp[MAXV], dl[MAXV];
+    float mean0 = 0.f, rstd0 = 0.f;
+    const f32x4* xr = (const f32x4*)(xs + (long long)p * C);
+    const f32x4* ar = (const f32x4*)(add + (long long)p * C);
+    auto request = [&](int n, op_t* dpv, op_t* dlv, float& m0, float& r0) {
+        const long long row = (long long)n * P + p;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + i * 64;
+            const int ci = idx < nv ? idx : 0;
+            if constexpr (CHAIN) dpv[i] = ((const op_t*)(dprev + row * C))[ci];
+            dlv[i] = ((const op_t*)(delta + row * C))[ci];
+        }
+        if constexpr (CHAIN) m0 = stats_in[2 * row], r0 = stats_in[2 * row + 1];
+    };
+    request(n0, dp, dl, mean0, rstd0);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        xv[i] = idx < nv ? xr[idx] : z;
+        av[i] = idx < nv ? ar[idx] : z;
+    }
+    __syncthreads();
+    for (int n = n0; n < n1; ++n) {
+        const long long row = (long long)n * P + p;
+        f32x4 v[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + i * 64;
+            const bool in = idx < nv;
+            if constexpr (CHAIN) {
+                // the previous layer's float result (x + its update, normalised with the stored statistics) + this layer's update
+                f32x4 t = xv[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] += in ? (float)dp[i][k] : 0.f;
+                if (in) {
+                    const f32x4 gg = sp[2 * nv + idx], bb = sp[3 * nv + idx];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[i][k] = ln_affine(t[k], mean0, rstd0, gg[k], bb[k]) + (float)dl[i][k];
+                } else {
+                    v[i] = z;
+                }
+            } else {
+                v[i] = xv[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] += in ? (float)dl[i][k] : 0.f;
+            }
+        }
+        // (the operand registers are free once the row is formed: the next track's operands travel under this track's
+        //  reductions and stores)
+        if (n + 1 < n1) request(n + 1, dp, dl, mean0, rstd0);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (lane + i * 64 < nv) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = v[i][k] - mean;
+                    {
+#pragma clang fp contract(off)
+                        q += d * d;
+                    }
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        if constexpr (!CHAIN) {
+            if (out_stats && lane == 0) {
+                out_stats[2 * row] = mean;
+                out_stats[2 * row + 1] = rstd;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int idx = lane + i * 64;
+            if (idx < nv) {
+                const f32x4 gg = sp[idx], bb = sp[nv + idx];
+                f32x4 y;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = ln_affine(v[i][k], mean, rstd, gg[k], bb[k]);
+                if (out_f32) ((f32x4*)(out_f32 + row * C))[idx] = y;
+                if (sizeof(T) == 2) {
+                    vec4h<T> o, o2;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (vec4e<T>)y[k], o2[k] = (vec4e<T>)(y[k] + av[i][k]);
+                    ((vec4h<T>*)((vec4e<T>*)out_T + row * C))[idx] = o;
+                    ((vec4h<T>*)((vec4e<T>*)out_T2 + row * C))[idx] = o2;
+                } else {
+                    ((f32x4*)((float*)out_T + row * C))[idx] = y;
+                    f32x4 o2;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o2[k] = y[k] + av[i][k];
+                    ((f32x4*)((float*)out_T2 + row * C))[idx] = o2;
+                }
+            }
+        }
+    }
+}
+// the token-ordered form applies when every float row is shared with period P = add_mod, both T outputs are wanted and the
+// rows are whole tracks; tracks per wave: 8 (4096 workgroups for 64 tracks of 2048 tokens)
+static bool key_ln_tracks_fits(int M, int C, int x_mod, int add_mod, const void* add, const void* out_T, const void* out_T2) {
+    return knob(KNOB_LN_TRACKS) && x_mod > 0 && x_mod == add_mod && x_mod % 4 == 0 && M % x_mod == 0 && C % 4 == 0 && C <= 1536 && add &&
+           out_T && out_T2;
+}
+template <typename T, bool CHAIN>
+static void launch_key_ln_tracks(const float* xs, int P, const void* dprev, const float* stats_in, const float* g0, const float* b0,
+                                 const void* delta, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M, int C,
+                                 const float* add, void* out_T2, float* out_stats, hipStream_t stream) {
+    const int N = M / P, tpw = N < 8 ? N : 8;
+    const dim3 grid((P / 4) * ((N + tpw - 1) / tpw));
+    hipLaunchKernelGGL((key_ln_tracks_kernel<T, CHAIN>), grid, dim3(256), (size_t)(CHAIN ? 4 : 2) * C * sizeof(float), stream, xs, P, (const T*)dprev,
+                       stats_in, g0, b0, (const T*)delta, gamma, beta, eps, (T*)out_T, out_f32, N, C, add, (T*)out_T2, out_stats, tpw);
+}
+
 int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dprev_T, const float* stats, const float* g0, const float* b0,
                            const void* delta_T, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M, int C,
                            const float* add, int add_mod, void* out_T2, hipStream_t stream) {
@@ -362,6 +535,13 @@ int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dp
         return L4P_E_INVALID;
     }
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d chain T2%d f32%d", M, C, out_T2 != nullptr, out_f32 != nullptr);
+    if (key_ln_tracks_fits(M, C, x_mod, add_mod, add, out_T, out_T2)) {
+        if (is16(dtype)) L4P_WITH_T16(dtype, T16, (launch_key_ln_tracks<T16, true>(xs, x_mod, dprev_T, stats, g0, b0, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, nullptr, stream)));
+        else
+            launch_key_ln_tracks<float, true>(xs, x_mod, dprev_T, stats, g0, b0, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, nullptr, stream);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((M + 3) / 4);
     if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(layernorm_chain_kernel<T16>, grid, dim3(256), 0, stream, xs, x_mod, (const T16*)dprev_T, stats, g0, b0,
                            (const T16*)delta_T, gamma, beta, eps, (T16*)out_T, out_f32, M, C, add, add_mod, (T16*)out_T2));

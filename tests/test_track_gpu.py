@@ -491,6 +491,93 @@ def test_layernorm_chain_equals_two_layernorms_bitwise(dev, precision):
     assert float((st[:, 0] - mean).abs().max()) <= 1e-5 and float((st[:, 1] - torch.rsqrt(var + 1e-5)).abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("precision", ["32-true", "bf16", "16-mixed"])
+@pytest.mark.parametrize("N,P,Cc", [(19, 100, 1408), (3, 8, 352), (8, 2048, 1408)])
+def test_token_ordered_key_layernorms_equal_the_row_kernels_bitwise(dev, knob, precision, N, P, Cc):
+    """The first window's two key LayerNorms laid out by token (key_ln_tracks_kernel, knob "ln_tracks": a wave owns one token and
+    walks its tracks - shared float rows in registers, parameters in LDS) against the row kernels (layernorm_kernel<RES> +
+    layernorm_chain_kernel) on the same operands: every output and the stored statistics bit-identical; track counts that are
+    not a multiple of the tracks per wave, the optional float outputs, every engine dtype."""
+    from l4p_amd import _lib
+    from l4p_amd._lib import L4P_BF16, L4P_F16, L4P_F32
+    from l4p_amd.ops import _p, _stream
+
+    lib = _lib.load()
+    dt = {"bf16": L4P_BF16, "16-mixed": L4P_F16}.get(precision, L4P_F32)
+    td = {"bf16": torch.bfloat16, "16-mixed": torch.float16}.get(precision, torch.float32)
+    M = N * P
+    g = torch.Generator().manual_seed(22)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    xs, pos = r(P, Cc).cuda(), r(P, Cc).cuda()
+    d0, d1 = (0.5 * r(M, Cc)).to(td).cuda(), (0.5 * r(M, Cc)).to(td).cuda()
+    g0, b0, g1, b1 = (1 + 0.1 * r(Cc)).cuda(), (0.1 * r(Cc)).cuda(), (1 + 0.1 * r(Cc)).cuda(), (0.1 * r(Cc)).cuda()
+
+    def run(tracks: int, with_f32: bool):
+        knob("ln_tracks", tracks)
+        e = lambda dtype=td: torch.full((M, Cc), 7.0, dtype=dtype, device="cuda")  # noqa: E731
+        st = torch.zeros(M, 2, device="cuda")
+        T0, P0, T1, P1 = e(), e(), e(), e()
+        f0 = e(torch.float32) if with_f32 else None
+        f1 = e(torch.float32) if with_f32 else None
+        _lib.check(lib.l4p_layernorm_res(_stream(), dt, _p(xs), P, _p(d0), _p(g0), _p(b0), 1e-5, _p(T0), _p(f0), M, Cc, _p(pos), P, _p(P0),
+                                         None, 1, 0, _p(st)), "l4p_layernorm_res(stats)")
+        _lib.check(lib.l4p_layernorm_chain(_stream(), dt, _p(xs), P, _p(d0), _p(st), _p(g0), _p(b0), _p(d1), _p(g1), _p(b1), 1e-5, _p(T1),
+                                           _p(f1), M, Cc, _p(pos), P, _p(P1)), "l4p_layernorm_chain")
+        torch.cuda.synchronize()
+        return [t for t in (T0, P0, T1, P1, st, f0, f1) if t is not None]
+
+    for with_f32 in (False, True):
+        rows, toks = run(0, with_f32), run(1, with_f32)
+        for i, (a, b) in enumerate(zip(rows, toks)):
+            assert torch.equal(a, b), (with_f32, i)
+    ref0 = torch.nn.functional.layer_norm(xs.repeat(N, 1) + d0.float(), (Cc,), g0, b0, 1e-5)
+    ref1 = torch.nn.functional.layer_norm(ref0 + d1.float(), (Cc,), g1, b1, 1e-5)
+    assert float((toks[-1] - ref1).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16", "16-mixed"])
+@pytest.mark.parametrize("half_shared", [False, True])
+def test_token_ordered_key_layernorm_of_later_windows_equals_the_row_kernel_bitwise(dev, knob, precision, half_shared):
+    """The key LayerNorm of a LATER window (the tracks' own float key master, normalised in place; in a half-shared layer 0 the
+    tokens p >= P / 2 still read the common rows) in the token-ordered form against the row kernel: the engine-dtype outputs and
+    the float master bit-identical; 11 tracks (8 + 3 per wave)."""
+    from l4p_amd import _lib
+    from l4p_amd._lib import L4P_BF16, L4P_F16, L4P_F32
+    from l4p_amd.ops import _p, _stream
+
+    lib = _lib.load()
+    dt = {"bf16": L4P_BF16, "16-mixed": L4P_F16}.get(precision, L4P_F32)
+    td = {"bf16": torch.bfloat16, "16-mixed": torch.float16}.get(precision, torch.float32)
+    N, P, Cc = 11, 64, 1408
+    M = N * P
+    g = torch.Generator().manual_seed(23)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    x0, pos, xh = r(M, Cc).cuda(), r(P, Cc).cuda(), r(P // 2, Cc).cuda()
+    d0 = (0.5 * r(M, Cc)).to(td).cuda()
+    g0, b0 = (1 + 0.1 * r(Cc)).cuda(), (0.1 * r(Cc)).cuda()
+
+    def run(tracks: int, in_place: bool):
+        knob("ln_tracks", tracks)
+        x = x0.clone()
+        o32 = x if in_place else None
+        T0, P0 = (torch.full((M, Cc), 7.0, dtype=td, device="cuda") for _ in range(2))
+        _lib.check(lib.l4p_layernorm_res(_stream(), dt, _p(x), 0, _p(d0), _p(g0), _p(b0), 1e-5, _p(T0), _p(o32), M, Cc, _p(pos), P, _p(P0),
+                                         _p(xh) if half_shared else None, P, P // 2, None), "l4p_layernorm_res")
+        torch.cuda.synchronize()
+        return T0, P0, x
+
+    for in_place in (True, False):
+        rows, toks = run(0, in_place), run(1, in_place)
+        for i, (a, b) in enumerate(zip(rows, toks)):
+            assert torch.equal(a, b), (in_place, i)
+    src = x0.view(N, P, Cc).clone()
+    if half_shared:
+        src[:, P // 2:] = xh
+    ref = torch.nn.functional.layer_norm(src.view(M, Cc) + d0.float(), (Cc,), g0, b0, 1e-5)
+    assert torch.equal(toks[2], x0)  # (the last run was not in place: its x is untouched ...)
+    assert float((run(1, True)[2] - ref).abs().max()) <= 1e-4  # (... and in place it holds the normalised rows)
+
+
 @pytest.mark.parametrize("P,Cc", [(256, 1408), (272, 256)])
 def test_i2t_delta_kernel_equals_grouped_gemm(dev, P, Cc):
     """l4p_i2t_delta (delta = P x V' + b of the folded image -> token attention as a streaming kernel, bf16) against the
