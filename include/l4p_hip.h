@@ -67,6 +67,9 @@ int l4p_stream_destroy(l4p_stream stream);
  *                addend of period P = add_mod over whole tracks) run laid out by TOKEN: a wave owns one token and walks its tracks,
  *                the shared float rows stay in registers and the parameter vectors in LDS (bit-identical to the row kernels;
  *                473 -> 223 us and 485 -> 309 us for 64 tracks x 2048 tokens); 0 = one wave per row
+ *   "ln_rows16"  (L4P_LN_ROWS16, default 1): l4p_layernorm_t on short rows (C <= 512, >= 4096 of them: the tracker's LayerNorm3d + GELU)
+ *                gives a row to one DPP row of 16 lanes - four rows per wave at a time, statistics by rotations inside the DPP row,
+ *                gamma / beta in registers over 16 rows per wave; 0 = one wave per row.  Equal to float rounding, not bit for bit.
  * l4p_set_knob returns L4P_E_INVALID for an unknown name; l4p_get_knob returns the current value (or -1). */
 int l4p_set_knob(const char* name, int value);
 int l4p_get_knob(const char* name);

@@ -33,7 +33,7 @@
 __device__ __forceinline__ float ln_affine(float v, float mean, float rstd, float g, float b) {
     return __builtin_fmaf((v - mean) * rstd, g, b);
 }
-template <typename T, int MAXV, bool XT = false, int ROWS = 1, bool RES = false>
+template <typename T, int MAXV, bool XT = false, int ROWS = 1, bool RES = false, bool PART = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, T* out_T, float* out_f32, int M,
                                                         int C, const float* __restrict__ add, int add_mod, T* out_T2, int act,
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                 v[r][i] = in ? LN_LD(xr + idx) : z;
             }
             if constexpr (RES) {
-                if (part) {  // the addend is bias + the float partials of a split-K projection, summed in slice order
+#ifdef LN_OLD_PART  // (A/B aid: the round-4 shape - one instantiation, run-time branch, one slice per round trip)
+                if (part) {
                     f32x4 d = pbias ? ((const f32x4*)pbias)[in ? idx : 0] : z;
                     for (int sl = 0; sl < nsplit; ++sl) {
                         const f32x4 t = ((const f32x4*)(part + ((long long)sl * M + row) * C))[in ? idx : 0];
@@ -83,7 +84,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[r][i][k] += in ? d[k] : 0.f;
-                } else if (sizeof(T) == 2) {
+                } else
+#endif
+                if constexpr (PART) {  // the addend is bias + the float partials of a split-K projection, summed in slice order
+                    f32x4 d = pbias ? ((const f32x4*)pbias)[in ? idx : 0] : z;
+                    // (four slices requested at a time - a slice past the last is a clamped duplicate that is not added: with a plain
+                    //  loop over a run-time nsplit every slice was its own memory round trip, 24 in a row per lane at batch 1)
+                    for (int sl = 0; sl < nsplit; sl += 4) {
+                        f32x4 t[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int su = sl + u < nsplit ? sl + u : sl;
+                            t[u] = ((const f32x4*)(part + ((long long)su * M + row) * C))[in ? idx : 0];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (sl + u < nsplit) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) d[k] += t[u][k];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[r][i][k] += in ? d[k] : 0.f;
+                } else if constexpr (sizeof(T) == 2) {
                     const vec4h<T> t = LN_LD((const vec4h<T>*)((const vec4e<T>*)delta + (long long)row * C) + (in ? idx : 0));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[r][i][k] += in ? (float)t[k] : 0.f;
@@ -211,10 +235,11 @@ int launch_layernorm_ex(int dtype, const float* x, const float* gamma, const flo
 
 // (the token-ordered form of the first window's key LayerNorms: key_ln_tracks_kernel below)
 static bool key_ln_tracks_fits(int M, int C, int x_mod, int add_mod, const void* add, const void* out_T, const void* out_T2);
-template <typename T, bool CHAIN>
+template <typename T, bool CHAIN, bool XT = false>
 static void launch_key_ln_tracks(const float* xs, int P, const void* dprev, const float* stats_in, const float* g0, const float* b0,
                                  const void* delta, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M, int C,
-                                 const float* add, void* out_T2, float* out_stats, hipStream_t stream);
+                                 const float* add, void* out_T2, float* out_stats, hipStream_t stream, const float* x_track = nullptr,
+                                 const float* x_half = nullptr, int x_split = 0);
 
 // y = LayerNorm(x[row % x_mod] + delta[row]) with the tracker's outputs (see layernorm_kernel RES); out_sum (may alias x when
 // x_mod = 0): the float sum itself - the encoder's pre-norm residual stream, where y is only the next linear's input;
@@ -237,29 +262,46 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
         return L4P_E_INVALID;
     }
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d res T2%d f32%d", M, C, out_T2 != nullptr, out_f32 != nullptr);
-    if (!x_shared && !part && !out_sum && delta_T && key_ln_tracks_fits(M, C, x_mod, add_mod, add, out_T, out_T2)) {
-        if (is16(dtype)) L4P_WITH_T16(dtype, T16, (launch_key_ln_tracks<T16, false>(x, x_mod, nullptr, nullptr, nullptr, nullptr, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, out_stats, stream)));
-        else
-            launch_key_ln_tracks<float, false>(x, x_mod, nullptr, nullptr, nullptr, nullptr, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, out_stats, stream);
+    if (!part && !out_sum && delta_T && key_ln_tracks_fits(M, C, x_mod, add_mod, add, out_T, out_T2) &&
+        (x_mod > 0 ? !x_shared : (!x_shared || x_period == add_mod))) {
+        if (x_mod > 0) {
+            if (is16(dtype)) L4P_WITH_T16(dtype, T16, (launch_key_ln_tracks<T16, false>(x, add_mod, nullptr, nullptr, nullptr, nullptr, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, out_stats, stream)));
+            else
+                launch_key_ln_tracks<float, false>(x, add_mod, nullptr, nullptr, nullptr, nullptr, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, out_stats, stream);
+        } else {  // the tracks' own float rows (possibly normalised in place), the common rows of a half-shared layer from x_shared
+            if (is16(dtype)) L4P_WITH_T16(dtype, T16, (launch_key_ln_tracks<T16, false, true>(nullptr, add_mod, nullptr, nullptr, nullptr, nullptr, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, out_stats, stream, x, x_shared, x_split)));
+            else
+                launch_key_ln_tracks<float, false, true>(nullptr, add_mod, nullptr, nullptr, nullptr, nullptr, delta_T, gamma, beta, eps, out_T, out_f32, M, C, add, out_T2, out_stats, stream, x, x_shared, x_split);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     }
     const dim3 grid((M + 3) / 4);
+#define LN_RES_LAUNCH(TT, MV, PT)                                                                                                          \
+    hipLaunchKernelGGL((layernorm_kernel<TT, MV, false, 1, true, PT>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (TT*)out_T, out_f32, M, \
+                       C, add, add_mod, (TT*)out_T2, (int)L4P_ACT_NONE, (const TT*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part,  \
+                       nsplit, pbias, out_stats)
+    // (the split-K-partials form is its own instantiation: its four-slices-at-a-time requests double the register count, which the
+    //  delta form - the encoder's and the tracker's rows at 8 waves per SIMD - must not pay)
+#ifdef LN_OLD_PART
+    const float* const part_sel = nullptr;
+#else
+    const float* const part_sel = part;
+#endif
     if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
-        if (C <= 512)
-            hipLaunchKernelGGL((layernorm_kernel<T16, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (T16*)out_T,
-                               out_f32, M, C, add, add_mod, (T16*)out_T2, (int)L4P_ACT_NONE, (const T16*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
-        else
-            hipLaunchKernelGGL((layernorm_kernel<T16, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (T16*)out_T,
-                               out_f32, M, C, add, add_mod, (T16*)out_T2, (int)L4P_ACT_NONE, (const T16*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
+        if (C <= 512) {
+            if (part_sel) LN_RES_LAUNCH(T16, 2, true); else LN_RES_LAUNCH(T16, 2, false);
+        } else {
+            if (part_sel) LN_RES_LAUNCH(T16, 6, true); else LN_RES_LAUNCH(T16, 6, false);
+        }
     }); else {
-        if (C <= 512)
-            hipLaunchKernelGGL((layernorm_kernel<float, 2, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
-        else
-            hipLaunchKernelGGL((layernorm_kernel<float, 6, false, 1, true>), grid, dim3(256), 0, stream, x, gamma, beta, eps, (float*)out_T,
-                               out_f32, M, C, add, add_mod, (float*)out_T2, (int)L4P_ACT_NONE, (const float*)delta_T, x_mod, x_shared, x_period, x_split, out_sum, part, nsplit, pbias, out_stats);
+        if (C <= 512) {
+            if (part_sel) LN_RES_LAUNCH(float, 2, true); else LN_RES_LAUNCH(float, 2, false);
+        } else {
+            if (part_sel) LN_RES_LAUNCH(float, 6, true); else LN_RES_LAUNCH(float, 6, false);
+        }
     }
+#undef LN_RES_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -381,14 +423,19 @@ __global__ __launch_bounds__(256) void layernorm_chain_kernel(const float* __res
 // track n is reduced.  Per-row arithmetic is the row kernels' statement for statement (ln_affine, the uncontracted variance,
 // the same summation order): bit-identical outputs (tests/test_track_gpu.py).
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool CHAIN>
-__global__ __launch_bounds__(256) void key_ln_tracks_kernel(const float* __restrict__ xs, int P, const T* __restrict__ dprev,
+// XT (later windows, layernorm_kernel<RES> with x_mod = 0): the float rows are the tracks' own key master x_track[row] (normalised
+// in place when out_f32 aliases it) - or, for tokens p >= x_split of a half-shared layer 0, still the common rows x_half[p - x_split]:
+// a wave-uniform choice, its token decides.  Per-track float rows travel with the track's update.
+template <typename T, bool CHAIN, bool XT = false>
+__global__ __launch_bounds__(256) void key_ln_tracks_kernel(const float* xs, int P, const T* __restrict__ dprev,
                                                             const float* __restrict__ stats_in, const float* __restrict__ g0,
                                                             const float* __restrict__ b0, const T* __restrict__ delta,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                            T* __restrict__ out_T, float* __restrict__ out_f32, int N, int C,
+                                                            T* __restrict__ out_T, float* out_f32, int N, int C,
                                                             const float* __restrict__ add, T* __restrict__ out_T2,
-                                                            float* __restrict__ out_stats, int tpw) {
+                                                            float* __restrict__ out_stats, int tpw, const float* x_track = nullptr,
+                                                            const float* __restrict__ x_half = nullptr, int x_split = 0) {
+    static_assert(!(CHAIN && XT), "the chained form exists for first windows only");
     constexpr int MAXV = 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [gamma | beta | g0 | b0][C] floats
     f32x4* const sp = (f32x4*)smem;
@@ -411,7 +458,9 @@ __global__ __launch_bounds__(256) void key_ln_tracks_kernel(const float* __restr
     typedef typename std::conditional<sizeof(T) == 2, vec4h<T>, f32x4>::type op_t;
     op_t dp[MAXV], dl[MAXV];
     float mean0 = 0.f, rstd0 = 0.f;
-    const f32x4* xr = (const f32x4*)(xs + (long long)p * C);
+    const float* xsrc = XT ? (x_half && p >= x_split ? x_half + (long long)(p - x_split) * C : nullptr) : xs + (long long)p * C;
+    const bool per_track = XT && xsrc == nullptr;  // (wave-uniform)
+    const f32x4* xr = (const f32x4*)xsrc;
     const f32x4* ar = (const f32x4*)(add + (long long)p * C);
     auto request = [&](int n, op_t* dpv, op_t* dlv, float& m0, float& r0) {
         const long long row = (long long)n * P + p;
@@ -421,6 +470,9 @@ __global__ __launch_bounds__(256) void key_ln_tracks_kernel(const float* __restr
             const int ci = idx < nv ? idx : 0;
             if constexpr (CHAIN) dpv[i] = ((const op_t*)(dprev + row * C))[ci];
             dlv[i] = ((const op_t*)(delta + row * C))[ci];
+            if constexpr (XT) {
+                if (per_track) xv[i] = idx < nv ? ((const f32x4*)(x_track + row * C))[idx] : z;
+            }
         }
         if constexpr (CHAIN) m0 = stats_in[2 * row], r0 = stats_in[2 * row + 1];
     };
@@ -428,7 +480,7 @@ __global__ __launch_bounds__(256) void key_ln_tracks_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + i * 64;
-        xv[i] = idx < nv ? xr[idx] : z;
+        if (!per_track) xv[i] = idx < nv ? xr[idx] : z;
         av[i] = idx < nv ? ar[idx] : z;
     }
     __syncthreads();
@@ -514,17 +566,20 @@ __global__ __launch_bounds__(256) void key_ln_tracks_kernel(const float* __restr
 // the token-ordered form applies when every float row is shared with period P = add_mod, both T outputs are wanted and the
 // rows are whole tracks; tracks per wave: 8 (4096 workgroups for 64 tracks of 2048 tokens)
 static bool key_ln_tracks_fits(int M, int C, int x_mod, int add_mod, const void* add, const void* out_T, const void* out_T2) {
-    return knob(KNOB_LN_TRACKS) && x_mod > 0 && x_mod == add_mod && x_mod % 4 == 0 && M % x_mod == 0 && C % 4 == 0 && C <= 1536 && add &&
-           out_T && out_T2;
+    // (x_mod = 0: the tracks' own float rows; else every float row is shared with the positional rows' period)
+    return knob(KNOB_LN_TRACKS) && (x_mod == 0 || x_mod == add_mod) && add_mod > 0 && add_mod % 4 == 0 && M % add_mod == 0 && C % 4 == 0 &&
+           C <= 1536 && add && out_T && out_T2;
 }
-template <typename T, bool CHAIN>
+template <typename T, bool CHAIN, bool XT>
 static void launch_key_ln_tracks(const float* xs, int P, const void* dprev, const float* stats_in, const float* g0, const float* b0,
                                  const void* delta, const float* gamma, const float* beta, float eps, void* out_T, float* out_f32, int M, int C,
-                                 const float* add, void* out_T2, float* out_stats, hipStream_t stream) {
-    const int N = M / P, tpw = N < 8 ? N : 8;
+                                 const float* add, void* out_T2, float* out_stats, hipStream_t stream, const float* x_track, const float* x_half,
+                                 int x_split) {
+    const int N = M / P, tpw = N < 8 ? N : 8;  // (4 / 8 / 16 tracks per wave measure the same: c3 LayerNorm class 6.38 / 6.38 / 6.41 ms)
     const dim3 grid((P / 4) * ((N + tpw - 1) / tpw));
-    hipLaunchKernelGGL((key_ln_tracks_kernel<T, CHAIN>), grid, dim3(256), (size_t)(CHAIN ? 4 : 2) * C * sizeof(float), stream, xs, P, (const T*)dprev,
-                       stats_in, g0, b0, (const T*)delta, gamma, beta, eps, (T*)out_T, out_f32, N, C, add, (T*)out_T2, out_stats, tpw);
+    hipLaunchKernelGGL((key_ln_tracks_kernel<T, CHAIN, XT>), grid, dim3(256), (size_t)(CHAIN ? 4 : 2) * C * sizeof(float), stream, xs, P, (const T*)dprev,
+                       stats_in, g0, b0, (const T*)delta, gamma, beta, eps, (T*)out_T, out_f32, N, C, add, (T*)out_T2, out_stats, tpw, x_track,
+                       x_half, x_split);
 }
 
 int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dprev_T, const float* stats, const float* g0, const float* b0,
@@ -552,6 +607,94 @@ int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dp
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (+ GELU) of SHORT rows stored in the engine dtype, C <= 512 (round 5): the tracker's LayerNorm3d after its first
+// up-scaling, [N * 8 P][352] in place.  One wave per row leaves 20 of 64 lanes idle in the second slot of a 352-wide row, pays
+// two 6-step wave reductions per row and reads gamma / beta (2.8 KB) through the L1 for every 1.4 KB row.  Here a row belongs to
+// ONE DPP ROW of 16 lanes (lane k holds the quads k, k + 16, ...: 88 quads = 5.5 slots, 92 % of the lanes busy), the statistics are
+// two 4-step rotations inside the DPP row, a wave works on 4 rows at a time and walks RPW / 4 such groups with gamma / beta in
+// registers, the next group's rows requested as soon as the current ones are converted.  Row sums are formed in a different
+// order than layernorm_kernel's: equal to it to float rounding, not bit for bit.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_sum(float v) {
+    // rotations inside a row of 16 lanes: every lane ends with the row's sum (same order in every lane's view up to rotation)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v;
+}
+template <typename T, int SLOTS, int RPW>
+__global__ __launch_bounds__(256) void ln_rows16_kernel(const T* x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        T* out, long long M, int C, int act) {
+    static_assert(sizeof(T) == 2 && RPW % 4 == 0, "16-bit rows, four at a time");
+    const int lane = threadIdx.x & 63, k = lane & 15, sub = lane >> 4;
+    const int nv = C >> 2;
+    const long long row_base = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row_base >= M) return;
+    f32x4 g[SLOTS], bb[SLOTS];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int q = k + 16 * j;
+        g[j] = q < nv ? ((const f32x4*)gamma)[q] : z;
+        bb[j] = q < nv ? ((const f32x4*)beta)[q] : z;
+    }
+    vec4h<T> raw[SLOTS];
+    auto request = [&](long long row) {
+        const long long rr = row < M ? row : M - 1;  // (a clamped duplicate row is loaded but never stored)
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int q = k + 16 * j;
+            raw[j] = ((const vec4h<T>*)((const vec4e<T>*)x + rr * C))[q < nv ? q : 0];
+        }
+    };
+    request(row_base + sub);
+    for (int it = 0; it < RPW / 4; ++it) {
+        const long long row = row_base + 4 * it + sub;
+        f32x4 v[SLOTS];
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const bool in = k + 16 * j < nv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = in ? (float)raw[j][e] : 0.f;
+        }
+        if (it + 1 < RPW / 4 && row_base + 4 * (it + 1) < M) request(row + 4);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        const float mean = row16_sum(s) / (float)C;
+        float qq = 0.f;
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            if (k + 16 * j < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[j][e] - mean;
+                    qq += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(row16_sum(qq) / (float)C + eps);
+        if (row < M) {
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) {
+                const int q = k + 16 * j;
+                if (q < nv) {
+                    vec4h<T> o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float y = ln_affine(v[j][e], mean, rstd, g[j][e], bb[j][e]);
+                        if (act == L4P_ACT_GELU) y = gelu_for<T>(y);
+                        o[e] = (vec4e<T>)y;
+                    }
+                    ((vec4h<T>*)((vec4e<T>*)out + row * C))[q] = o;
+                }
+            }
+        }
+    }
+}
+
 // LayerNorm of rows stored in the engine dtype (bf16 engine: bf16 in, bf16 out, possibly in place; f32 engine: the plain kernel)
 int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const float* beta, float eps, void* out_T, int M, int C,
                        int act, hipStream_t stream) {
@@ -562,6 +705,18 @@ int launch_layernorm_T(int dtype, const void* x_T, const float* gamma, const flo
         return L4P_E_INVALID;
     }
     ProfScope prof(PROF_LAYERNORM, stream, "M%d C%d inT act%d", M, C, act);
+    if (knob(KNOB_LN_ROWS16) && C <= 512 && C % 4 == 0 && M >= 4096) {  // short rows, many of them: one DPP row of 16 lanes per row
+        constexpr int RPW = 16;
+        const dim3 grid16((unsigned)(((long long)M + 4 * RPW - 1) / (4 * RPW)));
+        L4P_WITH_T16(dtype, T16, {
+            if (C <= 384)
+                hipLaunchKernelGGL((ln_rows16_kernel<T16, 6, RPW>), grid16, dim3(256), 0, stream, (const T16*)x_T, gamma, beta, eps, (T16*)out_T, (long long)M, C, act);
+            else
+                hipLaunchKernelGGL((ln_rows16_kernel<T16, 8, RPW>), grid16, dim3(256), 0, stream, (const T16*)x_T, gamma, beta, eps, (T16*)out_T, (long long)M, C, act);
+        });
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((M + 3) / 4);
     const float* xf = (const float*)x_T;  // (re-typed inside the kernel)
     L4P_WITH_T16(dtype, T16, {

@@ -419,7 +419,8 @@ def test_full_size_four_windows_joint_vs_reference_goldens(dev, full_sd, precisi
         assert_bf16_within_reference_drift({k: report[k][1] for k in ("flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw")},
                                            "full_T24_windows", what="4 windows, dense", precision=precision)
         assert_bf16_within_reference_drift({k: report[k][1] for k in report if k.startswith("track_2d")}, "full_T40_track24",
-                                           keymap={k: k + "[:8]" for k in report}, what="4 windows, tracks", precision=precision)
+                                           keymap={k: k + "[:8]" for k in report}, what="4 windows, tracks", precision=precision,
+                                           small=[k for k in report if k.startswith("track_2d") and out[k].numel() < 4096])  # (8 tracks x 40 frames)
     # frames 0..7 are written by window 0 only: independent of the draws -> the reference's own values (full tensors are not
     # in the fixture; the sampled positions that fall into the first 8 frames are compared)
     first_win = {}

@@ -59,6 +59,38 @@ def test_layernorm(dev, mode, M, C):
     check(yT, ref, mode, True)
 
 
+@pytest.mark.parametrize("mode", [L4P_BF16, L4P_F16])
+@pytest.mark.parametrize("M,C", [(8192 + 37, 352), (4096, 512), (5000, 64), (4099, 176)])
+@pytest.mark.parametrize("act", [ACT_NONE, ACT_GELU])
+def test_layernorm_of_engine_dtype_rows_in_place(dev, knob, mode, M, C, act):
+    """l4p_layernorm_t (LayerNorm3d + GELU of the tracker's up-scaling, mask_decoder.py:145-157, on rows stored in the engine
+    dtype, in place): the short-row kernel (knob "ln_rows16": one DPP row of 16 lanes per row, four rows per wave at a time,
+    ragged row counts) and the one-wave-per-row kernel against torch on the same rounded rows; the two agree to an output ulp."""
+    import ctypes as C_
+
+    from l4p_amd import _lib
+    from l4p_amd.ops import _p, _stream
+
+    lib = _lib.load()
+    xT, xf = as_mode(rnd((M, C), 5, 2.0) + 0.3, mode)
+    g, b = rnd((C,), 6) * 0.2 + 1.0, rnd((C,), 7) * 0.1
+    ref = F.layer_norm(xf, (C,), g, b, 1e-6)
+    if act == ACT_GELU:
+        ref = F.gelu(ref)
+    outs = []
+    gd, bd = g.cuda(), b.cuda()
+    for rows16 in (0, 1):
+        knob("ln_rows16", rows16)
+        y = xT.clone()
+        _lib.check(lib.l4p_layernorm_t(_stream(), mode, _p(y), _p(gd), _p(bd), C_.c_float(1e-6), _p(y), M, C, act), "l4p_layernorm_t")
+        torch.cuda.synchronize()
+        check(y, ref, mode, True)
+        outs.append(y.float())
+    ulp = 2.0 ** (-7 if mode == L4P_BF16 else -10)
+    big = torch.maximum(outs[0].abs(), outs[1].abs())
+    assert bool(((outs[0] - outs[1]).abs() <= 1.01 * ulp * big + 1e-4).all())  # (one output ulp where a value sits on a rounding boundary)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("M,N,K", [(2048, 1408, 1408), (2048, 6144, 1408), (2048, 1408, 6144), (300, 704, 1408),
                                      (2048, 1408, 1216), (70, 176, 352), (256, 256, 176)])
