@@ -66,3 +66,15 @@ def test_c5_workload_line_at_full_length(dev):
     assert abs(r["implied_8gpu_ms_tracker_beside_decoders"] - t8) < 0.01
     assert abs(r["implied_8gpu_speedup_tracker_beside_decoders"] - r["ms_per_step"] / t8) < 0.01
     assert r["implied_8gpu_speedup_tracker_beside_decoders"] >= r["implied_8gpu_speedup_tracker_after_decoders"]
+
+
+def test_host_io_pass_is_reported_beside_value_never_as_value(dev):
+    """--host-io (c2, three steps): the PCIe-inclusive pass - inputs from pinned host memory, every output copied back inside the
+    step - is its own object of the line; `value` stays the resident-input rate and is not slower than it."""
+    r = _run(["--workload", "c2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--host-io"])
+    _check_common(r, 3, 1)
+    pc = r["pcie_inclusive"]
+    assert pc["h2d_bytes_per_step"] >= 3 * 16 * 224 * 224 * 4 and pc["d2h_bytes_per_step"] >= 16 * 224 * 224 * 4
+    assert pc["value"] > 0 and pc["ms_per_step"] > 0
+    assert abs(r["value"] - 16 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-2
+    assert pc["value"] <= r["value"] * 1.05
