@@ -456,7 +456,7 @@ def bench_demo(args, rank, world, device, lib, selftest):
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    os.environ["L4P_TRACK_STREAMS"] = "0"
+    os.environ["L4P_TRACK_STREAMS"] = os.environ["L4P_HEAD_STREAMS"] = "0"
     lib.l4p_prof_reset()
     lib.l4p_prof_enable(1)
     for _ in range(args.steps):
@@ -570,7 +570,8 @@ def main():
     #      stream.  Kept out of the timed region because the event packets themselves cost ~13 % of a step at batch 1
     #      (15.1 ms -> 17.5 ms measured); kernel durations are unaffected up to a few %.
     if not args.no_prof and rank == 0:
-        os.environ["L4P_TRACK_STREAMS"] = "0"  # kernel durations are taken with the clips' trackers serialised on one stream
+        # kernel durations are taken with the clips' trackers and the side-stream decoders serialised on one stream
+        os.environ["L4P_TRACK_STREAMS"] = os.environ["L4P_HEAD_STREAMS"] = "0"
         lib.l4p_prof_reset()
         lib.l4p_prof_enable(1)
         for _ in range(args.steps):
@@ -578,6 +579,7 @@ def main():
         torch.cuda.synchronize()
         lib.l4p_prof_enable(0)
         os.environ.pop("L4P_TRACK_STREAMS", None)
+        os.environ.pop("L4P_HEAD_STREAMS", None)
     if world > 1:
         dist.barrier()
     # ---- the same K steps once more with the boundary handed HOST buffers (what a DataLoader delivers, l4p.py:54-66 moves them to

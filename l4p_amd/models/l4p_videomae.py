@@ -253,16 +253,60 @@ class L4P_VideoMAE(torch.nn.Module):
         try:
             return self._stitch_windows(out, feats2d, data, tasks, time_strides, joint_possible)
         finally:
+            self._join_head_streams()
             if trk is not None and hasattr(trk, "join_streams"):
                 trk.join_streams()
                 trk.defer_join = False
+
+    def _heads_on_streams(self, feats2d) -> bool:
+        """dyn_mask / flow decoders beside the depth / camray ones (L4P_HEAD_STREAMS=0: one after the other, A/B and test aid).
+        Only where the windows still have to be decoded (EncoderFeatures): windows decoded elsewhere (parallel.DecodedWindow)
+        leave nothing but copies.  Measured, round 5, same call x 3: c3 953.8 -> 963.0 frames/s at batch 4, 992.7 -> 994.5 at
+        batch 8; the depth decoder beside the camray one as well: no further gain (961.2), not built."""
+        return (self.device.type == "cuda" and os.environ.get("L4P_HEAD_STREAMS", "1") != "0"
+                and all(isinstance(f, EncoderFeatures) for f in feats2d))
+
+    def _run_heads_on_streams(self, names, out, feats2d, data, time_strides) -> None:
+        main = torch.cuda.current_stream()
+        pool = getattr(self, "_head_streams", None)
+        if pool is None or len(pool) < len(names):
+            pool = [torch.cuda.Stream(device=self.device) for _ in names]
+            self._head_streams = pool
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for st, task in zip(pool, names):
+            st.wait_event(ready)  # (the encoder features and the batch exist; nothing the main stream queues later is waited for)
+            with torch.cuda.stream(st):
+                o = self.task_heads[task].forward_windowed(enc_features_bpc_2dlist=feats2d, time_strides=time_strides, **data)
+            for v in o.values():
+                if torch.is_tensor(v):
+                    v.record_stream(main)  # allocated on the side stream, consumed by the caller on the main one after the join
+            out.update(o)
+        self._pending_heads = (main, pool[:len(names)])
+
+    def _join_head_streams(self) -> None:
+        pend = getattr(self, "_pending_heads", None)
+        if pend is not None:
+            main, pool = pend
+            for st in pool:
+                main.wait_stream(st)
+            self._pending_heads = None
 
     def _stitch_windows(self, out, feats2d, data, tasks, time_strides, joint_possible):
         if self.joint_alignment and joint_possible:
             from .task_heads.dense_heads import joint_windowed_estimation
 
-            for task in ("track_2d", "dyn_mask", "flow_2d_backward"):
-                if task in tasks:
+            if "track_2d" in tasks:
+                out.update(self.task_heads["track_2d"].forward_windowed(
+                    enc_features_bpc_2dlist=feats2d, time_strides=time_strides, **data))
+            side = [t for t in ("dyn_mask", "flow_2d_backward") if t in tasks]
+            if len(side) > 0 and self._heads_on_streams(feats2d):
+                # the two decoders that take no part in the joint alignment run on streams of their own BESIDE the depth / camray
+                # decoders below (joined in stitch_windows): the low-resolution levels of a DPT decoder are launches of 30 - 130
+                # workgroups, and four decoders in a row leave the chip to them one at a time
+                self._run_heads_on_streams(side, out, feats2d, data, time_strides)
+            else:
+                for task in side:
                     out.update(self.task_heads[task].forward_windowed(
                         enc_features_bpc_2dlist=feats2d, time_strides=time_strides, **data))
             out.update(joint_windowed_estimation(["depth", "camray"], self.task_heads, enc_features_bpc_2dlist=feats2d,

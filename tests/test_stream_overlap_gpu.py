@@ -164,3 +164,27 @@ def test_sharded_two_clips_two_emulated_ranks(dev, mini, monkeypatch, beside):
                 else:
                     for r in range(world):
                         assert torch.equal(outs[r][key], val), (key, r, rep)
+
+
+@pytest.mark.parametrize("T", [16, 32])
+def test_dense_decoders_on_their_own_streams_equal_serial(dev, mini, monkeypatch, T):
+    """The motion-mask and flow decoders run on streams of their own beside the depth / camray decoders and the tracker's clip
+    streams (L4P_VideoMAE._run_heads_on_streams; L4P_HEAD_STREAMS=0 = one after the other): every output bit-identical to the
+    serial order, over one window and over three (their seam alignment runs on the side streams too), B = 2, twenty forwards -
+    no buffer goes back to the allocator under a stream that still reads it."""
+    cfg, sd = mini
+    model = build(cfg, sd, "bf16")
+    batch = two_clip_batch(T, 5)
+    with torch.no_grad():
+        monkeypatch.setenv("L4P_HEAD_STREAMS", "0")
+        serial = model.forward({k: v.clone() for k, v in batch.items()}, TASKS)
+        serial = {k: v.clone() for k, v in serial.items() if torch.is_tensor(v)}
+        monkeypatch.setenv("L4P_HEAD_STREAMS", "1")
+        for it in range(20):
+            out = model.forward({k: v.clone() for k, v in batch.items()}, TASKS)
+            junk = [torch.randn(1 << 20, device="cuda") for _ in range(4)]  # (allocator pressure on the main stream's pool)
+            torch.cuda.synchronize()
+            for k, v in serial.items():
+                assert torch.equal(out[k], v), (it, k)
+            del out, junk
+    assert getattr(model.l4p_model, "_head_streams", None), "the side streams were never used"

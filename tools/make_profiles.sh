@@ -34,7 +34,7 @@ CMD3="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"
 CMD2="python $R/bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-prof"
 # (tracker clips serialised on one stream, as in bench.py's own event-timed pass: with the clips on their own streams and the
 #  dense decoders beside them, concurrent kernels share the chip and every one of them reports the shared interval)
-L4P_TRACK_STREAMS=0 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_c3 -o out -- $CMD3 > $O/prof_${TAG}_c3.log 2>&1
+L4P_TRACK_STREAMS=0 L4P_HEAD_STREAMS=0 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_c3 -o out -- $CMD3 > $O/prof_${TAG}_c3.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_c2 -o out -- $CMD2 > $O/prof_${TAG}_c2.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $O/pmc_${TAG}_sq -o out -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_${TAG}_grbm -o out -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
@@ -47,6 +47,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_${TAG}_c
 cd $R
 python tools/pmc_fetch_calibration.py $O/pmc_${TAG}_calib_f $O/pmc_${TAG}_calib_w > $O/${TAG}_fetch_size_calibration.md 2>/dev/null
 python tools/pmc_mfma_util.py $O/pmc_${TAG}_sq $O/pmc_${TAG}_grbm $O/${TAG}_power_probe.txt > $O/${TAG}_c3_mfma_util.md 2> $O/${TAG}_mfma_util.err
-python tools/rocprof_summary.py $(find $O/prof_${TAG}_c3 -name "*.db" | head -1) "L4P_TRACK_STREAMS=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof (c3: 7 steps, every kernel serialised on one stream)" > $O/${TAG}_c3_kernel_stats.md
+python tools/rocprof_summary.py $(find $O/prof_${TAG}_c3 -name "*.db" | head -1) "L4P_TRACK_STREAMS=0 L4P_HEAD_STREAMS=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof (c3: 7 steps, every kernel serialised on one stream)" > $O/${TAG}_c3_kernel_stats.md
 python tools/rocprof_summary.py $(find $O/prof_${TAG}_c2 -name "*.db" | head -1) "python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-prof (c2: 13 steps)" > $O/${TAG}_c2_kernel_stats.md
 ls -la $O | grep ${TAG}_ | head -30

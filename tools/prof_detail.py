@@ -6,7 +6,7 @@ import ctypes as C
 import os
 import sys
 
-os.environ["L4P_TRACK_STREAMS"] = "0"  # serialise the clips: overlapping streams inflate per-kernel event durations
+os.environ["L4P_TRACK_STREAMS"] = os.environ["L4P_HEAD_STREAMS"] = "0"  # serialise: overlapping streams inflate per-kernel event durations
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
