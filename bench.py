@@ -571,6 +571,7 @@ def main():
     #      (15.1 ms -> 17.5 ms measured); kernel durations are unaffected up to a few %.
     if not args.no_prof and rank == 0:
         # kernel durations are taken with the clips' trackers and the side-stream decoders serialised on one stream
+        saved = {k: os.environ.get(k) for k in ("L4P_TRACK_STREAMS", "L4P_HEAD_STREAMS")}  # (an A/B run may have set them)
         os.environ["L4P_TRACK_STREAMS"] = os.environ["L4P_HEAD_STREAMS"] = "0"
         lib.l4p_prof_reset()
         lib.l4p_prof_enable(1)
@@ -578,8 +579,11 @@ def main():
             step()
         torch.cuda.synchronize()
         lib.l4p_prof_enable(0)
-        os.environ.pop("L4P_TRACK_STREAMS", None)
-        os.environ.pop("L4P_HEAD_STREAMS", None)
+        for k, v in saved.items():  # the --host-io pass below runs in the configuration `value` was measured in
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     if world > 1:
         dist.barrier()
     # ---- the same K steps once more with the boundary handed HOST buffers (what a DataLoader delivers, l4p.py:54-66 moves them to

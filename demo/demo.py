@@ -33,9 +33,11 @@ def main():
     ap.add_argument("--max-queries", type=int, default=128)
     ap.add_argument("--spacing", type=float, default=0.04, help="track_2d_querry_sampling_spacing (625 queries at 0.04)")
     ap.add_argument("--save", default=None, help="directory for <seq_name>.npz")
+    ap.add_argument("--precision", default="16-mixed",
+                    help="engine: 16-mixed (the reference demo's own, IEEE half; default) | bf16 (what bench.py measures) | 32-true")
     args = ap.parse_args()
 
-    precision, accelerator = "16-mixed", "gpu"  # demo.py:22-23
+    precision, accelerator = args.precision, "gpu"  # demo.py:22-23 hard-codes "16-mixed"
     tasks = ["depth", "flow_2d_backward", "dyn_mask", "track_2d"]  # demo.py:82,99
     frames = None
     if args.synthetic:

@@ -70,6 +70,10 @@ int l4p_stream_destroy(l4p_stream stream);
  *   "ln_rows16"  (L4P_LN_ROWS16, default 1): l4p_layernorm_t on short rows (C <= 512, >= 4096 of them: the tracker's LayerNorm3d + GELU)
  *                gives a row to one DPP row of 16 lanes - four rows per wave at a time, statistics by rotations inside the DPP row,
  *                gamma / beta in registers over 16 rows per wave; 0 = one wave per row.  Equal to float rounding, not bit for bit.
+ *   "attn64"     (L4P_ATTN64, default 1): l4p_attention of the 16-bit engines on chip-filling launches (>= 256 tiles of 256 query rows,
+ *                S % 256 == 0): one wave per SIMD with 64 query rows (csrc/attention64.hip: every K / V^T fragment read feeds two
+ *                MFMAs); 0 = the 8-wave form with 32 rows per wave.  Equal to the rounding of P, not bit for bit (the rare rescale of
+ *                the deferred maximum is decided per wave).
  * l4p_set_knob returns L4P_E_INVALID for an unknown name; l4p_get_knob returns the current value (or -1). */
 int l4p_set_knob(const char* name, int value);
 int l4p_get_knob(const char* name);

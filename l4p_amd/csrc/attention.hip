@@ -30,6 +30,9 @@
 
 #include "common.hpp"
 
+int launch_attention64(int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, int Dh, float scale,
+                       hipStream_t stream);  // attention64.hip
+
 __device__ __attribute__((aligned(16))) static const unsigned short g_ones_bf16[8] = {0x3F80, 0x3F80, 0x3F80, 0x3F80,
                                                                                          0x3F80, 0x3F80, 0x3F80, 0x3F80};
 __device__ __attribute__((aligned(16))) static const unsigned short g_ones_f16[8] = {0x3C00, 0x3C00, 0x3C00, 0x3C00,
@@ -744,6 +747,9 @@ int launch_attention(int dtype, const void* q, const void* kt, const void* vt, v
     // too few workgroups for two per CU (256 CUs): split the KV range over two wave groups inside each workgroup
     const bool split = (long long)(S / 128) * H * B < 512 && (S / 64) % 2 == 0;
     static const int variant = getenv("L4P_ATTN_VARIANT") ? atoi(getenv("L4P_ATTN_VARIANT")) : 0;  // tuning aid: 1 = compiler-scheduled body
+    // chip-filling 16-bit launches: one wave per SIMD, 64 query rows per wave (attention64.hip)
+    if (is16(dtype) && variant == 0 && knob(KNOB_ATTN64) && S % 256 == 0 && (S / 64) % 2 == 0 && S / 64 >= 4 && (long long)(S / 256) * H * B >= 256)
+        return launch_attention64(dtype, q, kt, vt, out, B, S, H, Dh, scale, stream);
     if (is16(dtype)) L4P_WITH_T16(dtype, T16, return launch_attention16<T16>(variant, split, q, kt, vt, out, B, S, H, Dh, scale, stream));
     if (Dh == 88) return launch_attn_t<float, 32, 88, 1>(q, kt, vt, out, B, S, H, scale, stream);
     return launch_attn_t<float, 32, 64, 1>(q, kt, vt, out, B, S, H, scale, stream);

@@ -31,6 +31,8 @@ int launch_patch_gather(int dtype, const float* rgb, void* out, int B, int Cin, 
                         int pw, int Kp, hipStream_t stream);
 int launch_attention(int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, int Dh, float scale,
                      hipStream_t stream);
+int launch_attention64(int dtype, const void* q, const void* kt, const void* vt, void* out, int B, int S, int H, int Dh, float scale,
+                       hipStream_t stream);  // attention64.hip
 int launch_upsample(int dtype, const void* x, void* y, int B, int Ti, int Hi, int Wi, int To, int Ho, int Wo, int C,
                     int align, hipStream_t stream);
 int launch_head_out(int dtype, const void* x, const float* w, const float* bias, float* y, long long vox_per_b, int B,

@@ -138,7 +138,14 @@ __device__ __forceinline__ void gemm_epilogue_maskdot_mfma(const GemmParams& p, 
                 x[k] = (f32x2_t){acc[i][j][2 * h2], acc[i][j][2 * h2 + 1]} + bv[2 * j + h2];
                 xc[k] = (f32x2_t){med3_bare(x[k][0], neg, 4.5f), med3_bare(x[k][1], neg, 4.5f)};
             }
-            gelu_poly2<4>(x, xc);
+            // (the polynomial's 8e-5 absolute error is below a bf16 ulp but a sixth of a half ulp at 1: the half engine evaluates its
+            //  own GELU - gelu_for<f16_t>, the erfc form - as every other f16 kernel and the all-VALU form of this epilogue do)
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                gelu_poly2<4>(x, xc);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = (f32x2_t){gelu_for<T>(x[k][0]), gelu_for<T>(x[k][1])};
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[jh][2 * k] = (T)x[k][0], g[jh][2 * k + 1] = (T)x[k][1];
         }

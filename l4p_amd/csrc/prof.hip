@@ -23,7 +23,8 @@ const KnobDef kKnobs[KNOB_NUM] = {{"conv_halo", "L4P_CONV_HALO", 1}, {"gemm_4w",
                                    {"maskdot_mfma", "L4P_MASKDOT_MFMA", 1},
                                    {"conv_ups", "L4P_CONV_UPS", 0},
                                    {"ln_tracks", "L4P_LN_TRACKS", 1},
-                                   {"ln_rows16", "L4P_LN_ROWS16", 1}};
+                                   {"ln_rows16", "L4P_LN_ROWS16", 1},
+                                   {"attn64", "L4P_ATTN64", 1}};
 std::atomic<int> g_knob[KNOB_NUM];
 std::once_flag g_knob_once;
 void knobs_init() {

@@ -274,6 +274,10 @@ class L4P_VideoMAE(torch.nn.Module):
             self._head_streams = pool
         ready = torch.cuda.Event()
         ready.record(main)
+        # recorded BEFORE anything is queued: if a head (or a native call inside it) raises with an earlier side stream already at
+        # work, the join in forward()'s finally block still makes the main stream wait for every stream that may have been touched -
+        # the next forward reuses the per-task workspaces and the encoder feature blocks
+        self._pending_heads = (main, pool[:len(names)])
         for st, task in zip(pool, names):
             st.wait_event(ready)  # (the encoder features and the batch exist; nothing the main stream queues later is waited for)
             with torch.cuda.stream(st):
@@ -282,7 +286,6 @@ class L4P_VideoMAE(torch.nn.Module):
                 if torch.is_tensor(v):
                     v.record_stream(main)  # allocated on the side stream, consumed by the caller on the main one after the join
             out.update(o)
-        self._pending_heads = (main, pool[:len(names)])
 
     def _join_head_streams(self) -> None:
         pend = getattr(self, "_pending_heads", None)

@@ -71,7 +71,10 @@ def prepare_model(model_config_path: str, ckpt_path: Optional[str], max_queries:
         want = {0: "bfloat16", 1: "float32", 2: "float16"}[net.engine_dtype]
         have = getattr(pw, "extra", {}).get("dtype")
         if have != want:
-            raise ValueError(f"{ckpt_path} was packed for {have}, the model was built with precision={precision!r} ({want})")
+            flag = {"bfloat16": "bf16", "float16": "16-mixed", "float32": "32-true"}
+            raise ValueError(f"{ckpt_path} was packed for {have}, the model was built with precision={precision!r} ({want}): pass "
+                             f"precision={flag.get(have, have)!r} here (demo/demo.py --precision {flag.get(have, have)}), or repack with "
+                             f"tools/ckpt_to_arena.py --precision {flag[want]}")
         if getattr(pw, "extra", {}).get("geometry") != net.cfg.describe():
             raise ValueError(f"{ckpt_path} was packed for another model geometry")
         net.set_weights(pw)

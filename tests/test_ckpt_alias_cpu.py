@@ -52,6 +52,20 @@ def test_ckpt_to_arena_roundtrip(tmp_path):
         assert info["bytes"] == want.arena.numel() and got.extra["geometry"] == cfg.describe()
         for name, _, _, _ in want.layout:
             assert torch.equal(got[name].view(torch.uint8), want[name].view(torch.uint8)), name
+    # the tool's default precision is prepare_model's / build_model's default (an arena packed with defaults loads with defaults),
+    # every spelling the model accepts means the same dtype here, and an unknown string is an error (not float32)
+    import inspect
+
+    from l4p_amd.models import utils as mutils
+
+    dflt = inspect.signature(convert).parameters["precision"].default
+    assert dflt == inspect.signature(mutils.prepare_model).parameters["precision"].default == \
+        inspect.signature(mutils.build_model).parameters["precision"].default
+    info = convert(str(ckpt), str(tmp_path / "default.l4parena"), cfg=cfg)
+    assert info["dtype"] == "float16"
+    assert convert(str(ckpt), str(tmp_path / "x.l4parena"), "16", cfg=cfg)["dtype"] == "float16"
+    with pytest.raises(ValueError):
+        convert(str(ckpt), str(tmp_path / "x.l4parena"), "fp8", cfg=cfg)
     # a checkpoint with a missing / mis-shaped tensor is refused
     bad = dict(sd)
     bad.pop("video_encoder.norm.weight")

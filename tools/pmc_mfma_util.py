@@ -16,14 +16,22 @@ import sqlite3
 import sys
 
 SIMDS = 256 * 4
-# (rocprofv3 stores some kernel names demangled and some mangled: both spellings are listed)
-HOT = ((("gemm8p_kernel<0", "gemm8p_kernelILi0"), "gemm8p<0> (linear GEMMs, 256x256 tiles)"),
-       (("gemm8p_kernel<1", "gemm8p_kernelILi1"), "gemm8p<1> (3x3x3 conv, 256x256 tiles)"),
-       (("conv3_halo",), "conv3_halo (3x3x3 conv, LDS halo)"),
-       (("_Z11gemm_kernelIDF16bLi128ELi128ELi2ELi2ELi1", "gemm_kernel<__bf16, 128, 128, 2, 2, 1"), "gemm_kernel 128x128 MODE1 (3x3x3 conv)"),
-       (("_Z11gemm_kernelIDF16bLi128ELi128ELi2ELi2ELi0", "gemm_kernel<__bf16, 128, 128, 2, 2, 0"), "gemm_kernel 128x128 MODE0"),
-       (("_Z11gemm_kernelIDF16bLi128ELi64", "gemm_kernel<__bf16, 128, 64"), "gemm_kernel 128x64 (token-side GEMMs)"),
-       (("_Z11attn_kernel", "void attn_kernel<"), "attn_kernel (encoder attention)"))
+# (rocprofv3 stores some kernel names demangled and some mangled: the patterns are regular expressions over either spelling; the
+#  engine-dtype template parameter - DF16b / DF16_ / f, "__bf16" / "_Float16" / "float" - comes first in every GEMM / conv family)
+import re
+
+_T = r"(?:DF16b|DF16_|f|__bf16, |_Float16, |float, )?"
+HOT = ((rf"gemm8p_kernel(?:I{_T}Li0ELi2ELi4E|<{_T}0, 2, 4)", "gemm8p<0,2,4> (linear GEMMs, 256x256 tiles)"),
+       (rf"gemm8p_kernel(?:I{_T}Li0ELi4ELi2E|<{_T}0, 4, 2)", "gemm8p<0,4,2> (linear GEMMs, 256x192 tiles)"),
+       (rf"gemm8p_kernel(?:I{_T}Li0E|<{_T}0,)", "gemm8p<0> (both instantiations)"),
+       (rf"gemm8p_kernel(?:I{_T}Li1E|<{_T}1,)", "gemm8p<1> (3x3x3 conv, implicit GEMM)"),
+       (r"conv3_halo", "conv3_halo (3x3x3 conv, LDS halo)"),
+       (rf"(?:11gemm_kernelI{_T}Li128ELi128ELi2ELi2ELi1|gemm_kernel<{_T}128, 128, 2, 2, 1)", "gemm_kernel 128x128 MODE1 (3x3x3 conv)"),
+       (rf"(?:11gemm_kernelI{_T}Li128ELi128ELi2ELi2ELi0|gemm_kernel<{_T}128, 128, 2, 2, 0)", "gemm_kernel 128x128 MODE0"),
+       (rf"(?:11gemm_kernelI{_T}Li128ELi64|gemm_kernel<{_T}128, 64)", "gemm_kernel 128x64 (token-side GEMMs)"),
+       (r"attn64_kernel", "attn64_kernel (encoder attention, 64 query rows per wave)"),
+       (r"(?:_Z11attn_kernelI\w+Li96E|void attn_kernel<\w+, 96)", "attn_kernel (encoder attention, 32 query rows per wave)"))
+HOT = tuple((re.compile(k), label) for k, label in HOT)
 
 
 def load(d):
@@ -65,7 +73,7 @@ def main():
     print("|---|---|---|---|---|---|---|---|---|")
     for key, label in HOT:
         def agg(src, counter):
-            vals = [x for k, cs in src.items() if any(kk in k for kk in key) for c, lst in cs.items() if counter in c for x in lst]
+            vals = [x for k, cs in src.items() if key.search(k) for c, lst in cs.items() if counter in c for x in lst]
             if not vals:
                 return None
             return len(vals), sum(v[0] for v in vals) / len(vals), sum(v[1] for v in vals) / len(vals), sum(v[0] for v in vals), sum(v[1] for v in vals)
