@@ -181,19 +181,31 @@ def read_prof(lib):
     return out
 
 
-def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 0, sample_queries: int = 8):
-    """Oracle (plain PyTorch fp32 port of the reference algorithm) on the host cores, 1 clip of the SAME workload, BOUNDED
-    sample (~20 s of CPU work): patch embed + EVERY encoder block (``sample_blocks`` = 0; n > 0: the first n of the ``depth``
-    identical blocks are timed and scaled by depth / n) and the dense heads are timed in full; the tracker port is timed on
-    ``sample_queries`` of the clip's queries and scaled by N / sample_queries (tracks are independent: its cost is linear
-    in N)."""
+def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 0, sample_queries: int = 0):
+    """Oracle (plain PyTorch fp32 port of the reference algorithm) on the host cores, 1 clip of the SAME workload, a bounded
+    sample (~30 s of CPU work) timed IN FULL: patch embed + every encoder block + the dense heads + the tracker on every query
+    (``sample_blocks`` / ``sample_queries`` > 0 restrict the encoder blocks / queries timed and scale the rest - not the default).
+    Threads: torch's CPU kernels stop scaling far below a 256-core host's count, so two encoder blocks are timed on min(64, cores)
+    and on ALL cores first and the measurement runs on the faster setting; both probe times are reported."""
     from oracle import l4p_oracle as orc
 
-    threads = min(os.cpu_count() or 1, 64)  # torch CPU ops stop scaling (and regress) far below 256 threads
-    torch.set_num_threads(threads)
+    host = os.cpu_count() or 1
     rgb = batch_cpu["rgb_b3thw"]
     dense = [t for t in tasks if t != "track_2d"]
     with torch.no_grad():
+        torch.set_num_threads(min(host, 64))
+        feats = orc.encoder_forward(sd, rgb, cfg, upto=0)
+        x0 = feats[0]
+        probe = {}
+        for th in sorted({min(host, 64), host}):
+            torch.set_num_threads(th)
+            orc.encoder_block(sd, "video_encoder.blocks.0.", x0, cfg.heads, cfg.ln_eps)  # (warm the pool)
+            t0 = time.time()
+            for i in range(2):
+                orc.encoder_block(sd, f"video_encoder.blocks.{i}.", x0, cfg.heads, cfg.ln_eps)
+            probe[th] = (time.time() - t0) / 2
+        threads = min(probe, key=probe.get)
+        torch.set_num_threads(threads)
         t0 = time.time()
         feats = orc.encoder_forward(sd, rgb, cfg, upto=0)
         t_embed = time.time() - t0
@@ -213,15 +225,18 @@ def cpu_baseline(sd, cfg, tasks, batch_cpu, sample_blocks: int = 0, sample_queri
         if "track_2d" in tasks:
             q = batch_cpu["track_2d_pointquerries_bn3"]
             nq = q.shape[1]
-            ns = min(sample_queries, nq)
+            ns = nq if sample_queries <= 0 else min(sample_queries, nq)
             t0 = time.time()
             orc.track_windowed(sd, cfg, [x], q[:, :ns], batch_cpu["track_2d_pointlabels_bn"][:, :ns], [0])
             t_track = (time.time() - t0) * nq / ns
-            track_note = f" + tracker {ns}/{nq} queries scaled x{nq / ns:g} = {t_track:.2f}s"
+            track_note = (f" + tracker, all {nq} queries, {t_track:.2f}s" if ns == nq else
+                          f" + tracker {ns}/{nq} queries scaled x{nq / ns:g} = {t_track:.2f}s")
     dt = t_embed + t_blocks * cfg.depth + t_heads + t_track
     # "cores" = the threads the port actually ran on (torch intra-op pool); "host_cores" = what the box has (os.cpu_count())
-    return {"value": round(16.0 / dt, 4), "unit": "frames/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
-            "sample": (f"1 clip (16x224x224), tasks={'+'.join(tasks)}: oracle (plain PyTorch fp32 port of the reference) on the host CPU; "
+    return {"value": round(16.0 / dt, 4), "unit": "frames/s", "cores": threads, "host_cores": host, "kind": "port",
+            "thread_probe_s_per_block": {str(k): round(v, 3) for k, v in probe.items()},
+            "sample": (f"1 clip (16x224x224), tasks={'+'.join(tasks)}: oracle (plain PyTorch fp32 port of the reference) on the host CPU, "
+                       f"{threads} threads (the faster of {sorted(probe)} on a 2-block probe: {', '.join(f'{k}: {v:.2f}s/block' for k, v in sorted(probe.items()))}); "
                        f"timed patch-embed {t_embed:.2f}s + {sample_blocks}/{cfg.depth} encoder blocks ({t_blocks:.2f}s each{'' if sample_blocks == cfg.depth else f', scaled x{cfg.depth}'}) "
                        f"+ dense heads in full {t_heads:.2f}s{track_note} -> {dt:.1f}s per clip")}
 

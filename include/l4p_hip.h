@@ -43,7 +43,7 @@ typedef void* l4p_stream; /* hipStream_t */
 typedef struct l4p_engine l4p_engine;
 
 const char* l4p_last_error(void);
-int l4p_abi_version(void); /* 8: l4p_gemm_desc.ups_hi / ups_wi; 7: L4P_F16; 6: l4p_set_knob / l4p_get_knob; 5: l4p_layernorm_res(out_stats), l4p_layernorm_chain, l4p_stream_create_cu_mask; 4: l4p_gemm_desc.o_gs, l4p_i2t_delta,
+int l4p_abi_version(void); /* 9: l4p_similarity_prefix, knobs attn64 / probe_kernels; 8: l4p_gemm_desc.ups_hi / ups_wi; 7: L4P_F16; 6: l4p_set_knob / l4p_get_knob; 5: l4p_layernorm_res(out_stats), l4p_layernorm_chain, l4p_stream_create_cu_mask; 4: l4p_gemm_desc.o_gs, l4p_i2t_delta,
                               * l4p_t2i_probs, l4p_t2i_context; 3: l4p_gemm_desc.w_gr / w_gs / b_gs, l4p_i2t_probs,
                               * l4p_t2i_attn_scores, l4p_split_hilo, l4p_transpose_pad */
 
@@ -74,6 +74,8 @@ int l4p_stream_destroy(l4p_stream stream);
  *                S % 256 == 0): one wave per SIMD with 64 query rows (csrc/attention64.hip: every K / V^T fragment read feeds two
  *                MFMAs); 0 = the 8-wave form with 32 rows per wave.  Equal to the rounding of P, not bit for bit (the rare rescale of
  *                the deferred maximum is decided per wave).
+ *   "probe_kernels" (read-only): 1 when the library was built with PROBES=1 and contains the measured-and-not-adopted kernels the knobs
+ *                "gemm_4w" and "conv_ups" select; in the shipped build (0) those two knobs stay 0 and setting them is an error.
  * l4p_set_knob returns L4P_E_INVALID for an unknown name; l4p_get_knob returns the current value (or -1). */
 int l4p_set_knob(const char* name, int value);
 int l4p_get_knob(const char* name);
@@ -307,6 +309,13 @@ int l4p_similarity_ransac(l4p_stream stream, const float* src, const float* dst,
 
 /* aligner.apply (aligner.py:239-265): pose [16][T] <- T pose with the 3x3 block / s ; depth[n] *= s */
 int l4p_similarity_apply(l4p_stream stream, const float* sim, float* pose, int T, float* depth, long long n);
+
+/* Prefix composition of per-seam similarities (l4p_similarity_ransac records): rel [n][B][18], seam i = window i + 1 aligned to the
+ * RAW window i; out [n + 1][B][18], out[0] = identity, out[w] = out[w - 1] o rel[w - 1] = window w in window 0's frame (applying two
+ * records in a row = applying the 4x4 product with the product of the scales: l4p_similarity_apply divides the rotation block by
+ * the scale after each product).  The sharded long-video path's seam-local exchange (reference loop
+ * dense_heads.py:444-467, which aligns every window to the accumulated buffer one after the other). */
+int l4p_similarity_prefix(l4p_stream stream, const float* rel, float* out, int n, int B);
 
 /* ------------------------------------------------------------------------------------------------
  * SAM-style point tracker (sparse_heads.py, sam/{prompt_encoder,transformer,mask_decoder}.py).

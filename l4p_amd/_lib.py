@@ -117,6 +117,7 @@ SIGNATURES = {
     "l4p_point_map_samples": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, C.c_uint]),
     "l4p_similarity_ransac": (_I, [_VP, _VP, _VP, _I, _VP, _F, _I, _I, C.c_uint, _VP, _VP]),
     "l4p_similarity_apply": (_I, [_VP, _VP, _VP, _I, _VP, _LL]),
+    "l4p_similarity_prefix": (_I, [_VP, _VP, _VP, _I, _I]),
     "l4p_layernorm_ex": (_I, [_VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I, _VP, _I, _VP, _I]),
     "l4p_gemm_group": (_I, [_VP, _I, _VP, _I]),
     "l4p_layernorm_res": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _VP, _I, _I, _VP, _I, _VP, _VP, _I, _I, _VP]),

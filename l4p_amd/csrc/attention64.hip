@@ -382,7 +382,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // a P pair in two halves: X = the two exponentials, C = the pack (issued one pair later, behind the next pair's X)
             float xa[NP], xb[NP];
             auto X = [&](auto p_, f32x16 (*s)[NST]) __attribute__((always_inline)) {
-#ifdef ATTN64_DBG_NOSOFTMAX
+#ifdef ATTN64_DBG_NOSOFTMAX  // (probe: wrong results - P = 1 everywhere)
+                xa[decltype(p_)::value] = xb[decltype(p_)::value] = 1.0f;
                 return;
 #endif
                 constexpr int p = decltype(p_)::value, e4 = p & 3, b = (p >> 2) % QB, tj = p / (4 * QB), t = tj >> 1, j = tj & 1, r = 8 * j + 2 * e4;
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             unsigned pe[E_];  // the early pairs of P_{it+1}: they replace pw[0 .. E-1] once the PV MFMAs have consumed those
             auto Cw = [&](auto p_) __attribute__((always_inline)) {  // the pack of a pair of P_it
 #ifdef ATTN64_DBG_NOSOFTMAX
+                pw[decltype(p_)::value] = 0x3F803F80u;
                 return;
 #endif
                 constexpr int p = decltype(p_)::value;
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             };
             auto Ce = [&](auto p_) __attribute__((always_inline)) {  // the pack of an early pair of P_{it+1}
 #ifdef ATTN64_DBG_NOSOFTMAX
+                pe[decltype(p_)::value] = 0x3F803F80u;
                 return;
 #endif
                 constexpr int p = decltype(p_)::value;
@@ -407,6 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             float mxn[QB] = {-INFINITY, -INFINITY};
             auto M = [&](auto u_) __attribute__((always_inline)) {  // two more scores into the running maximum of their query block: u = 0 .. 31, tile 0 first
 #ifdef ATTN64_DBG_NOSOFTMAX
+                mxn[0] = mxn[1] = 0.f;
                 return;
 #endif
                 constexpr int u = decltype(u_)::value, b = u & 1, t = u >> 4, e = ((u >> 1) & 7) * 2;

@@ -24,13 +24,24 @@ const KnobDef kKnobs[KNOB_NUM] = {{"conv_halo", "L4P_CONV_HALO", 1}, {"gemm_4w",
                                    {"conv_ups", "L4P_CONV_UPS", 0},
                                    {"ln_tracks", "L4P_LN_TRACKS", 1},
                                    {"ln_rows16", "L4P_LN_ROWS16", 1},
-                                   {"attn64", "L4P_ATTN64", 1}};
+                                   {"attn64", "L4P_ATTN64", 1},
+                                   {"probe_kernels", "", 0}};
 std::atomic<int> g_knob[KNOB_NUM];
 std::once_flag g_knob_once;
+#ifdef L4P_PROBE_KERNELS
+constexpr bool kProbeKernels = true;
+#else
+constexpr bool kProbeKernels = false;
+#endif
+// knobs that select a measured-and-not-adopted kernel: they exist only in a PROBES=1 build of the library
+bool probe_only(int i) { return i == KNOB_GEMM_4W || i == KNOB_CONV_UPS; }
 void knobs_init() {
     for (int i = 0; i < KNOB_NUM; ++i) {
-        const char* e = getenv(kKnobs[i].env);
-        g_knob[i].store(e ? atoi(e) : kKnobs[i].dflt, std::memory_order_relaxed);
+        const char* e = kKnobs[i].env[0] ? getenv(kKnobs[i].env) : nullptr;
+        int v = e ? atoi(e) : kKnobs[i].dflt;
+        if (i == KNOB_PROBE_KERNELS) v = kProbeKernels ? 1 : 0;  // read-only: what this build contains
+        if (probe_only(i) && !kProbeKernels) v = 0;
+        g_knob[i].store(v, std::memory_order_relaxed);
     }
 }
 }  // namespace
@@ -83,6 +94,11 @@ int l4p_set_knob(const char* name, int value) {
     std::call_once(g_knob_once, knobs_init);
     for (int i = 0; i < KNOB_NUM; ++i)
         if (name && !strcmp(name, kKnobs[i].name)) {
+            if (i == KNOB_PROBE_KERNELS || (probe_only(i) && !kProbeKernels && value != 0)) {
+                l4p_set_error("l4p_set_knob: '%s' %s", name, i == KNOB_PROBE_KERNELS ? "is read-only (1 in a PROBES=1 build of the library)"
+                                                                                       : "selects a kernel this build does not contain (make PROBES=1)");
+                return L4P_E_INVALID;
+            }
             g_knob[i].store(value, std::memory_order_relaxed);
             return L4P_OK;
         }

@@ -408,6 +408,36 @@ __global__ void similarity_apply_pose_kernel(const float* __restrict__ sim, floa
     for (int k = 0; k < 16; ++k) pose[(long long)k * T + t] = R[k];
 }
 
+// prefix composition of per-seam similarities (the seam-local exchange of the sharded long video, l4p_amd/parallel.py): applying
+// (sim_a, s_a) after (sim_r, s_r) is applying (sim_a sim_r, s_a s_r) - the rotation block of a pose is divided by the scale after
+// each product, so it stays a rotation and the scales multiply.  rel: [n][B][18] seam records (seam i aligns window i + 1 to RAW
+// window i), out: [n + 1][B][18]: out[0] = identity, out[w] = out[w - 1] o rel[w - 1] = the transform of window w into window 0's
+// frame.  One thread per clip walks the seams in order (double accumulation, one rounding per record).
+__global__ void similarity_prefix_kernel(const float* __restrict__ rel, float* __restrict__ out, int n, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double A[16], s = 1.0;
+    for (int k = 0; k < 16; ++k) A[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    float* o = out + (long long)b * 18;
+    for (int k = 0; k < 16; ++k) o[k] = (float)A[k];
+    o[16] = 1.f, o[17] = 0.f;
+    for (int w = 0; w < n; ++w) {
+        const float* r = rel + ((long long)w * B + b) * 18;
+        double C[16];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double a = 0.0;
+                for (int k = 0; k < 4; ++k) a += A[i * 4 + k] * (double)r[k * 4 + j];
+                C[i * 4 + j] = a;
+            }
+        for (int k = 0; k < 16; ++k) A[k] = C[k];
+        s *= (double)r[16];
+        o = out + ((long long)(w + 1) * B + b) * 18;
+        for (int k = 0; k < 16; ++k) o[k] = (float)A[k];
+        o[16] = (float)s, o[17] = r[17];
+    }
+}
+
 __global__ void scale_by_device_scalar_kernel(float* __restrict__ x, long long n, const float* __restrict__ s) {
     const float v = s[0];
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= v;
@@ -512,6 +542,19 @@ int l4p_similarity_ransac(l4p_stream s_, const float* src, const float* dst, int
     hipLaunchKernelGGL(ransac_trials_kernel, dim3(trials), dim3(256), 0, s, src, dst, n, q98, thr_rel, min_samples, seed, scores,
                        models);
     hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(256), 0, s, src, dst, n, q98, thr_rel, trials, scores, models, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* out[0] = identity, out[w] = out[w - 1] o rel[w - 1]: rel [n][B][18], out [n + 1][B][18] (see similarity_prefix_kernel) */
+int l4p_similarity_prefix(l4p_stream s_, const float* rel, float* out, int n, int B) {
+    hipStream_t s = (hipStream_t)s_;
+    if (n < 0 || B < 1) {
+        l4p_set_error("l4p_similarity_prefix: need n >= 0 seams and B >= 1 clips (n=%d B=%d)", n, B);
+        return L4P_E_INVALID;
+    }
+    ProfScope prof(PROF_ELEMENTWISE, s, "l4p_similarity_prefix");
+    hipLaunchKernelGGL(similarity_prefix_kernel, dim3((B + 63) / 64), dim3(64), 0, s, rel, out, n, B);
     HIP_TRY(hipGetLastError());
     return 0;
 }

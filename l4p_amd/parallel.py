@@ -302,7 +302,8 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
       1b  DPT decoders of its windows, queued on the main stream         (sharded)
       T   the tracker recursion over ALL windows on this rank's query shard, queued on the tracker's own streams, which wait for
           x1 only: a chain of ~31 x 130 small dependent launches (host-issue-bound at 8 queries per rank) that runs BESIDE 1b
-      x2  all-gather of the decoded dense windows
+      x2  all-gather of the decoded dense windows (L4P_C5_EXCHANGE=seam: the seam-local exchange below instead - K broadcast, one
+          tail per chunk boundary, 18 floats per seam; steps 3 then runs on the rank's own windows only)
       J   join the tracker streams
       3   dense stitching / seam alignment / pose chaining               (replicated, identical inputs on every rank)
       x3  all-gather of the query shards
@@ -357,7 +358,15 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
                 wins_t = [DecodedWindow(net.cfg.depth, {}, g["last"]) for g in lasts]
                 trk_out = trk.forward_windowed(enc_features_bpc_2dlist=wins_t, time_strides=strides, **d_trk)
         out: dict = {}
-        if dense:
+        seam_local = dense and os.environ.get("L4P_C5_EXCHANGE", "gather") == "seam" and seam_local_supported(net, dense)
+        if seam_local:
+            # SURVEY.md 8e's exchange: K broadcast + one tail per chunk boundary + 18 floats per seam instead of every decoded window
+            own = {w: DecodedWindow(net.cfg.depth, {k[4:]: v for k, v in g.items() if k.startswith("dec.")}, None)
+                   for w, g in local.items()}
+            if trk is not None and hasattr(trk, "join_streams") and os.environ.get("L4P_TRACK_BESIDE_STITCH", "0") != "1":
+                trk.join_streams()
+            out = stitch_seam_local(net, data, dense, own, rank, world)
+        elif dense:
             gathered = all_gather_windows(local, nwin, rank, world)  # the exchange step of the dense path
             windows = [DecodedWindow(net.cfg.depth, {k[4:]: v for k, v in g.items() if k.startswith("dec.")}, None)
                        for g in gathered]
@@ -379,6 +388,275 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
             if key not in out:  # rank without queries
                 out[key] = torch.zeros(data["rgb_b3thw"].shape[0], 0, shp, T, dtype=torch.float32, device=net.device)
             out[key] = all_gather_queries(out[key], nq, rank, world, dim=1)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Seam-local exchange of the dense path (option of forward_windows_sharded, L4P_C5_EXCHANGE=seam).
+#
+# The reference aligns every window to the ACCUMULATED buffer, one window after the other (dense_heads.py:444-467) - a chain
+# over all windows that the default schedule above reproduces bit for bit by gathering every decoded window (12.9 MB each) on
+# every rank and repeating the stitch there.  A similarity estimate is equivariant under a similarity of its target, though:
+# aligning window w to the accumulated window w - 1 is aligning it to the RAW window w - 1 and composing with window w - 1's
+# accumulated transform.  So:
+#   1. window 0's owner estimates K (the camray head's fixed intrinsics)                 -> broadcast, 16 floats per clip
+#   2. every rank runs the heads of its own windows (raw depth / poses, flow, mask)
+#   3. the last 8 frames of a chunk's last window (depth + poses + K, one flow frame) go to the NEXT rank  -> P2P, 2.0 MB per clip
+#   4. every rank solves its own seams against the raw predecessor (l4p_similarity_ransac)
+#   5. all-gather of the seam records                                                     -> 18 floats per seam and clip
+#   6. prefix composition (l4p_similarity_prefix), applied to the rank's own windows; the frames a window is the last to write
+#      stay on the rank that produced them (outputs are gathered only if the caller asks for whole tensors)
+# Not the reference's arithmetic to the bit: the RANSAC threshold is 0.01 x q98 of the raw predicted depth either way, but the
+# residuals are measured in the target's units - raw here, accumulated there - so seams whose accumulated scale is far from 1
+# draw a (slightly) different consensus set; on well-posed windows the two schedules agree to 1e-3
+# (tests/test_seam_local_gpu.py), and the gather schedule stays the default until an N > 1 run decides.
+# The phases are plain functions of one rank's state; `_SeamComm` moves the three messages through torch.distributed, the tests
+# run the same phases for every emulated rank of one process and hand the messages over by hand.
+# ---------------------------------------------------------------------------------------------------------------------
+class SeamLocalState:
+    """What one rank holds between the phases: its decoded windows, their head outputs, its seam records."""
+
+    def __init__(self, rank: int, world: int, windows: dict, strides, ws: int):
+        self.rank, self.world, self.windows, self.strides, self.ws = rank, world, windows, [int(s) for s in strides], ws
+        self.s0, self.e0 = window_chunks(len(self.strides), world)[rank]
+        self.cur: dict = {}    # window id -> {"depth","camray","camray_intrinsics_est","flow_2d_backward","dyn_mask"}
+        self.rel: dict = {}    # seam id w (window w against window w - 1) -> [B, 18]
+
+
+def seam_local_supported(net, tasks: List[str]) -> bool:
+    """The joint depth + camera path with the shipped aligner; flow / mask ride along (pure copies)."""
+    dense = [t for t in tasks if t != "track_2d"]
+    return (net.joint_alignment and "depth" in dense and "camray" in dense and
+            all(t in ("depth", "camray", "flow_2d_backward", "dyn_mask") for t in dense))
+
+
+def seam_phase_k0(net, st: SeamLocalState, data: dict, img_info) -> Optional[torch.Tensor]:
+    """Phase 1 on window 0's owner: the camray head on window 0 (estimates K when the head does) -> K [B,4,4,T] or None."""
+    cam = net.task_heads["camray"]
+    if st.s0 != 0 or st.e0 == 0 or cam.use_intrinsics or not cam.fixed_intrinsics:
+        return None
+    cam.forward(st.windows[0], img_info=img_info, intrinsics_b44t=data["intrinsics_b44t"][..., :st.ws], win_id=0)
+    return cam.first_window_intrinsics_b44t.clone()
+
+
+def seam_phase_heads(net, st: SeamLocalState, data: dict, tasks: List[str], img_info, k0: Optional[torch.Tensor]) -> Optional[dict]:
+    """Phase 2: head outputs of this rank's windows, each in its own frame.  Returns the message for the NEXT rank (None on the
+    last rank / a rank without windows): the tail of this chunk's last window."""
+    cam = net.task_heads["camray"]
+    K_in = data["intrinsics_b44t"]
+    for w in range(st.s0, st.e0):
+        t0 = st.strides[w]
+        cur = {}
+        for name in [t for t in tasks if t != "track_2d"]:
+            head = net.task_heads[name]
+            if name == "camray" and w > 0 and k0 is not None:
+                cam.first_window_intrinsics_b44t = k0  # (a later window reports window 0's estimate, dense_heads.py:327-333)
+            o = head.forward(st.windows[w], img_info=img_info, intrinsics_b44t=K_in[..., t0:t0 + st.ws], win_id=w)
+            cur[name] = o[f"{head.task_name}_est_{head.task_suffix}"]
+            if name == "camray":
+                kkey = f"{head.task_name}_intrinsics_est_{head.task_suffix}"
+                cur["camray_intrinsics_est"] = (o[kkey] if kkey in o else K_in[..., t0:t0 + st.ws].clone().reshape(-1, 16, st.ws))
+        st.cur[w] = cur
+    if st.e0 == st.s0 or st.e0 == len(st.strides):
+        return None
+    last, nxt = st.e0 - 1, st.e0
+    ov = st.strides[last] + st.ws - st.strides[nxt]
+    c = st.cur[last]
+    msg = {"depth": c["depth"][:, :, st.ws - ov:].contiguous(), "camray": c["camray"][:, :, st.ws - ov:].contiguous(),
+           "camray_intrinsics_est": c["camray_intrinsics_est"][:, :, st.ws - ov:].contiguous()}
+    if "flow_2d_backward" in c:  # the first frame of a later window's flow is invalid: it keeps the predecessor's (dense_heads.py:139)
+        msg["flow_frame"] = c["flow_2d_backward"][:, :, st.ws - ov:st.ws - ov + 1].contiguous()
+    return msg
+
+
+def seam_phase_solve(st: SeamLocalState, prev_tail: Optional[dict], img_info) -> dict:
+    """Phase 4: the similarity of each of this rank's windows w > 0 against the RAW window w - 1 (its tail came from the previous
+    rank for the chunk's first window).  -> {w: [B, 18]}"""
+    from .models.aligner import KabaschUmeyama3DAligner
+
+    st.prev_tail = prev_tail
+    for w in range(max(st.s0, 1), st.e0):
+        ov = st.strides[w - 1] + st.ws - st.strides[w]
+        if w - 1 >= st.s0:
+            p = st.cur[w - 1]
+            tgt = {"depth": p["depth"][:, :, st.ws - ov:], "camray": p["camray"][:, :, st.ws - ov:],
+                   "camray_intrinsics": p["camray_intrinsics_est"][:, :, st.ws - ov:].reshape(-1, 4, 4, ov)}
+        else:
+            assert prev_tail is not None, f"rank {st.rank}: the tail of window {w - 1} did not arrive"
+            tgt = {"depth": prev_tail["depth"], "camray": prev_tail["camray"],
+                   "camray_intrinsics": prev_tail["camray_intrinsics_est"].reshape(-1, 4, 4, ov)}
+        c = st.cur[w]
+        pred = {"depth": c["depth"][:, :, :ov], "camray": c["camray"][:, :, :ov],
+                "camray_intrinsics": c["camray_intrinsics_est"][:, :, :ov].reshape(-1, 4, 4, ov).clone()}
+        al = KabaschUmeyama3DAligner()
+        al.solve(pred, tgt, img_info)
+        st.rel[w] = al.rel_T_b44
+    return st.rel
+
+
+def seam_phase_apply(st: SeamLocalState, rel_all: torch.Tensor) -> dict:
+    """Phases 6: ``rel_all`` [n_windows - 1, B, 18] (seam w - 1 = window w against raw window w - 1) -> prefix composition ->
+    this rank's windows in window 0's frame -> the frames this rank is the last to write: {key: [B, C, frames, ...]} plus
+    "frame_range": (f0, f1).  Window w is the last writer of frames [stride_w, stride_{w+1}) (the last window: to the end)."""
+    from . import _lib
+    from .ops import _p, _stream
+    from .utils.umeyama import apply_window_similarity
+
+    nwin = len(st.strides)
+    if st.e0 == st.s0:
+        return {"frame_range": (0, 0)}
+    B = rel_all.shape[1]
+    acc = torch.empty(nwin, B, 18, dtype=torch.float32, device=rel_all.device)
+    _lib.check(_lib.load().l4p_similarity_prefix(_stream(), _p(rel_all.contiguous()), _p(acc), nwin - 1, B), "l4p_similarity_prefix")
+    f0 = st.strides[st.s0]
+    f1 = st.strides[st.e0] if st.e0 < nwin else st.strides[-1] + st.ws
+    out = {}
+    for w in range(st.s0, st.e0):
+        c = st.cur[w]
+        al = apply_window_similarity(acc[w], {"depth": c["depth"], "camray": c["camray"]}) if w > 0 else c
+        a = st.strides[w] - f0
+        n = (st.strides[w + 1] if w + 1 < nwin else st.strides[w] + st.ws) - st.strides[w]
+        parts = {"depth": al["depth"], "camray": al["camray"], "camray_intrinsics_est": c["camray_intrinsics_est"]}
+        for k in ("flow_2d_backward", "dyn_mask"):
+            if k in c:
+                parts[k] = c[k]
+        for k, v in parts.items():
+            if k not in out:
+                shp = list(v.shape)
+                shp[2] = f1 - f0
+                out[k] = torch.zeros(*shp, dtype=v.dtype, device=v.device)
+            out[k][:, :, a:a + n] = v[:, :, :n]
+        if "flow_2d_backward" in c and w > 0:  # frame 0 of a later window's flow is the predecessor's frame at that time
+            src = st.cur[w - 1]["flow_2d_backward"][:, :, st.strides[w] - st.strides[w - 1]] if w - 1 >= st.s0 else st.prev_tail["flow_frame"][:, :, 0]
+            out["flow_2d_backward"][:, :, a] = src
+    out["frame_range"] = (f0, f1)
+    return out
+
+
+def seam_exchange_bytes(B: int, nwin: int, world: int, ws: int = 16, H: int = 224, W: int = 224, ov: int = 8,
+                        tasks=("depth", "camray", "flow_2d_backward", "dyn_mask")) -> dict:
+    """Bytes one (interior) rank RECEIVES for the dense path under the two schedules (float32 tensors)."""
+    per_win = 0
+    for t in tasks:
+        per_win += {"depth": ws * H * W, "dyn_mask": ws * H * W, "flow_2d_backward": 2 * ws * H * W, "camray": 6 * 16 * 16 * 16}[t] * 4
+    own = window_chunks(nwin, world)[min(1, world - 1)]
+    gather = B * per_win * (nwin - (own[1] - own[0]))
+    tail = B * ((ov * H * W + 2 * 16 * ov) * 4 + (2 * H * W * 4 if "flow_2d_backward" in tasks else 0))
+    seam = B * (16 * ws * 4 + tail + (nwin - 1) * 18 * 4)
+    return {"gather_schedule": int(gather), "seam_local_schedule": int(seam)}
+
+
+class _SeamComm:
+    """The three messages of the seam-local schedule through torch.distributed (gloo in the CPU tests, RCCL on a node)."""
+
+    def __init__(self, rank: int, world: int, device: torch.device):
+        self.rank, self.world, self.device = rank, world, device
+
+    def bcast_k0(self, k0: Optional[torch.Tensor], B: int, T: int) -> torch.Tensor:
+        buf = k0.contiguous() if k0 is not None else torch.empty(B, 4, 4, T, dtype=torch.float32, device=self.device)
+        dist.broadcast(buf, src=0)
+        return buf
+
+    def pass_tail(self, msg: Optional[dict], like: Optional[dict], has_prev: bool, has_next: bool) -> Optional[dict]:
+        """Send ``msg`` to rank + 1 (if any), receive the previous rank's into tensors shaped ``like``."""
+        ops, got = [], None
+        if has_next and msg is not None:
+            for k in sorted(msg):
+                ops.append(dist.P2POp(dist.isend, msg[k], self.rank + 1))
+        if has_prev:
+            got = {k: torch.empty_like(v) for k, v in like.items()}
+            for k in sorted(got):
+                ops.append(dist.P2POp(dist.irecv, got[k], self.rank - 1))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        return got
+
+    def gather_seams(self, rel: dict, nwin: int, B: int) -> torch.Tensor:
+        chunks = window_chunks(nwin, self.world)
+        cmax = max(e - s for s, e in chunks)
+        s0, e0 = chunks[self.rank]
+        block = torch.zeros(cmax, B, 18, dtype=torch.float32, device=self.device)
+        for j, w in enumerate(range(s0, e0)):
+            if w in rel:
+                block[j].copy_(rel[w])
+        parts = [torch.empty_like(block) for _ in range(self.world)]
+        dist.all_gather(parts, block)
+        rows = [parts[r][j] for r, (s, e) in enumerate(chunks) for j, w in enumerate(range(s, e)) if w > 0]
+        return torch.stack(rows, dim=0) if rows else torch.zeros(0, B, 18, dtype=torch.float32, device=self.device)
+
+
+def stitch_seam_local(net, data: dict, tasks: List[str], windows: dict, rank: int, world: int, gather_outputs: bool = True) -> dict:
+    """The dense path of one rank under the seam-local schedule (``windows``: {window id: DecodedWindow} of this rank's chunk).
+    ``gather_outputs``: all-gather the frame blocks into whole [B, C, T, ...] tensors on every rank (what the caller of
+    L4P_VideoMAE.forward expects); False: every rank keeps the frames it produced ("frame_range")."""
+    T = data["rgb_b3thw"].shape[2]
+    B = data["rgb_b3thw"].shape[0]
+    img_info = tuple(data.get("img_info", net.window_size))
+    strides = net.time_strides(T)
+    nwin = len(strides)
+    st = SeamLocalState(rank, world, windows, strides, net.window_size[0])
+    on = _collectives_on(world)
+    comm = _SeamComm(rank, world, net.device) if on else None
+    k0 = seam_phase_k0(net, st, data, img_info)
+    cam = net.task_heads["camray"]
+    if comm is not None and not cam.use_intrinsics and cam.fixed_intrinsics:
+        k0 = comm.bcast_k0(k0, B, st.ws)
+    msg = seam_phase_heads(net, st, data, tasks, img_info, k0)
+    prev = None
+    if comm is not None:
+        chunks = window_chunks(nwin, world)
+        has_prev = rank > 0 and st.e0 > st.s0 and st.s0 > 0
+        has_next = msg is not None and rank + 1 < world and chunks[rank + 1][1] > chunks[rank + 1][0]
+        like = None
+        if has_prev:
+            ov = st.strides[st.s0 - 1] + st.ws - st.strides[st.s0]
+            c = st.cur[st.s0]
+            like = {"depth": c["depth"][:, :, :ov], "camray": c["camray"][:, :, :ov],
+                    "camray_intrinsics_est": c["camray_intrinsics_est"][:, :, :ov]}
+            if "flow_2d_backward" in c:
+                like["flow_frame"] = c["flow_2d_backward"][:, :, :1]
+            like = {k: v.contiguous() for k, v in like.items()}
+        prev = comm.pass_tail(msg, like, has_prev, has_next)
+    rel = seam_phase_solve(st, prev, img_info)
+    if comm is not None:
+        rel_all = comm.gather_seams(rel, nwin, B)
+    else:
+        rel_all = (torch.stack([rel[w] for w in range(1, nwin)], dim=0) if nwin > 1 else
+                   torch.zeros(0, B, 18, dtype=torch.float32, device=net.device))
+    local = seam_phase_apply(st, rel_all)
+    return seam_outputs(net, local, T, rank, world, nwin, gather_outputs and on)
+
+
+def seam_outputs(net, local: dict, T: int, rank: int, world: int, nwin: int, gather: bool) -> dict:
+    """Output keys of L4P_VideoMAE.forward from a rank's frame blocks (optionally all-gathered into whole tensors)."""
+    names = {"depth": "depth", "camray": "camray", "flow_2d_backward": "flow_2d_backward", "dyn_mask": "dyn_mask"}
+    out = {}
+    f0, f1 = local["frame_range"]
+    for k, v in local.items():
+        if k == "frame_range":
+            continue
+        if gather:
+            chunks = window_chunks(nwin, world)
+            lens = []
+            strides = [int(s) for s in net.time_strides(T)]
+            for s, e in chunks:
+                lens.append(0 if e == s else (strides[e] if e < nwin else T) - strides[s])
+            fmax = max(lens)
+            xm = v.movedim(2, 0).contiguous()
+            block = torch.zeros((fmax,) + tuple(xm.shape[1:]), dtype=v.dtype, device=v.device)
+            block[: xm.shape[0]].copy_(xm)
+            parts = [torch.empty_like(block) for _ in range(world)]
+            dist.all_gather(parts, block)
+            v = torch.cat([parts[r][:n] for r, n in enumerate(lens)], dim=0).movedim(0, 2).contiguous()
+        if k == "camray_intrinsics_est":
+            cam = net.task_heads["camray"]
+            out[f"{cam.task_name}_intrinsics_est_{cam.task_suffix}"] = v
+        else:
+            head = net.task_heads[names[k]]
+            out[f"{head.task_name}_est_{head.task_suffix}"] = v
+    if not gather:
+        out["frame_range"] = (f0, f1)
     return out
 
 

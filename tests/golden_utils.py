@@ -26,6 +26,18 @@ def make_batch(T: int, nq: int, seed: int = 1234):
     }
 
 
+LONG_QUERY_TIMES = [0, 0, 3, 10, 19, 27, 36, 44, 53, 61, 70, 82, 95, 107, 118, 130]
+
+
+def long_batch(T: int = 136, seed: int = 4321):
+    """The long-recursion case (tools/gen_golden_long.py -> tests/golden/mini_T136_long.npz): 16 windows, 16 tracks whose queries
+    start anywhere in the video, so later windows see dead, newly started and re-seeded tracks side by side."""
+    b = make_batch(T, len(LONG_QUERY_TIMES), seed)
+    for i, t in enumerate(LONG_QUERY_TIMES):
+        b["track_2d_pointquerries_bn3"][0, i, 0] = min(t, T - 2) + 0.5
+    return b
+
+
 def sample_indices(numel: int, n: int = 4096) -> torch.Tensor:
     if numel <= n:
         return torch.arange(numel)

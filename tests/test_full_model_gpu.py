@@ -343,6 +343,52 @@ def test_benchmarked_configuration_itself(dev, full_sd):
         y = out4["traj3d_est_b16t"][i]
         assert (y - pose).abs().max() <= 1e-3 * pose.abs().max(), (i, float((y - pose).abs().max() / pose.abs().max()))
         assert (Kout[0].reshape(16, 16) - out4["traj3d_intrinsics_est_b16t"][i]).abs().max() <= 1e-3 * Kout.abs().max()
+    # ---- the estimator's CONSENSUS branch in this very configuration (batch 4, clip streams on, shipped use_intrinsics=false): with
+    #      random weights no clip's ray map has a consensus, so the comparison above never runs.  Clip 3's decoded ray map is
+    #      replaced AT THE HEAD'S OUTPUT (after the real decoder kernels have run, on their stream) by the rendering of a known
+    #      camera path with measurement noise (tests/test_wellposed_heads_gpu._scene, window 0), and the same forward runs again.
+    from tests.test_wellposed_heads_gpu import _scene
+
+    K_true, _, _, wins = _scene()
+    rays_wp = wins[0]["rays"]
+    cam = net.task_heads["camray"]
+    orig_decode = cam._decode
+    assert tuple(rays_wp.shape) == (1, 6, 16, 16, 16)
+
+    def decode_with_rendered_clip3(feats, img_info):
+        r = orig_decode(feats, img_info)
+        assert tuple(r.shape) == (4, 6, 16, 16, 16), r.shape
+        r[3].copy_(rays_wp[0].to(r.device, r.dtype))
+        return r
+
+    cam._decode = decode_with_rendered_clip3
+    try:
+        with torch.no_grad():
+            out_wp = m.forward({k: v.clone() for k, v in b4.items()}, ALL)
+        torch.cuda.synchronize()
+    finally:
+        del cam._decode
+    assert len(getattr(head, "_clip_streams", [])) >= 4
+    dirs = rays_wp[0, :3, 0].reshape(3, -1).T.numpy()
+    want, n_cons, iters = lo.engine_rays_to_intrinsics(dirs, 16, 16, 224, 224, thr=0.2, b=3)
+    assert n_cons >= 200, n_cons  # a real consensus: the gated comparison executes
+    K_pix = out_wp["traj3d_intrinsics_est_b16t"].float().cpu()[3].reshape(4, 4, 16)
+    got = K_pix[..., 0].double().numpy()
+    print(f"well-posed clip 3 at batch 4: consensus {n_cons}/256 after {iters} rounds, fx {got[0, 0]:.2f} fy {got[1, 1]:.2f} "
+          f"(true {float(K_true[0, 0]):.1f} {float(K_true[1, 1]):.1f})")
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max(), (got, want)           # kernel == its CPU restatement
+    assert np.abs(got[:3, :3] - K_true[:3, :3].double().numpy()).max() <= 2e-2 * float(K_true[0, 0]), got  # and the true camera
+    # the other clips' K do not depend on clip 3's ray map (per-clip estimate, hashed per clip)
+    for i in range(3):
+        assert torch.equal(out_wp["traj3d_intrinsics_est_b16t"].float().cpu()[i], out4["traj3d_intrinsics_est_b16t"][i]), i
+    # poses of clip 3: the reference flow downstream of the estimate, and the rendered camera path itself
+    K_ray = lo.denormalize_intrinsics(lo.normalize_intrinsics(K_pix[None], 224, 224), 16, 16)[0, :3, :3, 0]
+    E, _ = lo.rays_to_cameras_fixed_intrinsics(rays_wp, (224, 224), k_override=lambda b: K_ray)
+    pose = torch.linalg.inv(E.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).reshape(16, 16)
+    y = out_wp["traj3d_est_b16t"].float().cpu()[3]
+    assert (y - pose).abs().max() <= 1e-3 * pose.abs().max(), float((y - pose).abs().max() / pose.abs().max())
+    rel = wins[0]["rel"].reshape(16, 16).float()
+    assert (y - rel).abs().max() <= 5e-2, float((y - rel).abs().max())  # (measurement noise of the rendering; K to 2 %)
 
 
 @pytest.mark.parametrize("precision", ["32-true", "bf16", "16-mixed"])

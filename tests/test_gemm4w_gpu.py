@@ -16,7 +16,7 @@ from tests.test_kernels_gpu import as_mode, check, rnd
 
 
 @pytest.fixture(autouse=True)
-def _force_4w(monkeypatch, knob):
+def _force_4w(monkeypatch, probe_kernels, knob):
     knob("gemm_4w", 2)
     monkeypatch.setattr(t8, "FORM_TAG", " 4w ")
 

@@ -428,7 +428,7 @@ def test_conv3_halo_equals_implicit_gemm_form(dev, knob):
 
 
 @pytest.mark.parametrize("B,T,lo,hi", [(1, 16, (128, 128), (224, 224)), (2, 4, (60, 72), (112, 128))])
-def test_conv3_halo_fused_upsample_equals_upsample_then_conv(dev, B, T, lo, hi):
+def test_conv3_halo_fused_upsample_equals_upsample_then_conv(dev, probe_kernels, B, T, lo, hi):
     """l4p_gemm_desc.ups_hi / ups_wi: the bilinear (align_corners) up-sampling in front of a 3x3x3 conv formed inside the LDS-halo
     kernel's loader (dpt_head.py:79-84: interpolate -> head conv) - equal, bit for bit, to l4p_upsample_trilinear followed by the
     conv on the stored volume: the loader reproduces that kernel's arithmetic and rounding.  Full-size head shape and a small,

@@ -33,11 +33,13 @@ def _usage(src):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_hot_kernels_do_not_spill():
     gemm = _usage("gemm_bf16.hip")
-    # (the LDS-halo conv in its shipped form, "Lb0E": the fused up-sampling loader - off by default, measured slower - spills 44 bytes)
-    hot = [k for k in gemm if "gemm8p_kernel" in k or "gemm4w_kernel" in k or ("gemm_kernel" in k and "ELb1E" in k) or
+    # (the shipped build: the measured-and-not-adopted kernels - gemm4w.hpp, the up-sampling loader of conv3_halo.hpp - are compiled
+    #  only with PROBES=1 and must not be in this object)
+    assert not any("gemm4w_kernel" in k or ("conv3_halo_kernel" in k and "ELb1EEv" in k) for k in gemm), sorted(gemm)
+    hot = [k for k in gemm if "gemm8p_kernel" in k or ("gemm_kernel" in k and "ELb1E" in k) or
            ("conv3_halo_kernel" in k and k.endswith("ELb0EEv13l4p_gemm_desc"))]
     assert sum("conv3_halo_kernel" in k for k in hot) == 2, sorted(gemm)
-    assert len(hot) >= 5 and any("gemm4w_kernel" in k for k in hot), sorted(gemm)
+    assert len(hot) >= 5, sorted(gemm)
     for k in hot:
         assert gemm[k]["ScratchSize [bytes/lane]"] == 0, (k, gemm[k])
         assert gemm[k]["VGPRs"] <= 256
@@ -46,3 +48,10 @@ def test_hot_kernels_do_not_spill():
     assert hot
     for k in hot:
         assert attn[k]["ScratchSize [bytes/lane]"] == 0, (k, attn[k])
+    # the one-wave-per-SIMD attention: its state (S ping-pong, Q, P, O in the accumulator file) must stay in registers - the kernel
+    # whose closures once exceeded the optimiser's scalar-replacement limit and went to scratch wholesale (1344 bytes per lane)
+    a64 = _usage("attention64.hip")
+    assert len(a64) == 4, sorted(a64)
+    for k in a64:
+        assert a64[k]["ScratchSize [bytes/lane]"] == 0, (k, a64[k])
+        assert a64[k]["VGPRs"] <= 256

@@ -1,0 +1,91 @@
+"""A LONG recursion against the REAL reference (tools/gen_golden_long.py -> tests/golden/mini_T136_long.npz): mini geometry,
+136 frames = 16 windows = 15 seams, all five tasks, 16 tracks starting anywhere in the video.  The reference's own forward with
+its two random draws replaced by fixed stand-ins pins the oracle over 15 seams; here:
+
+  * integer / boolean tracker state of ALL 16 windows (labels, prompt labels, re-seeded query times, validity masks, argmax
+    re-seed index): f32 engine bit-exact against the reference's trace; bf16 engine bounded by the number of tracks the
+    reference's own bf16-autocast run moves on these inputs (sparse_heads.py:277-486);
+  * flow / motion mask / tracks: against the reference's outputs (f32: 1e-3 of the maximum; bf16: the reference's autocast drift);
+  * jointly aligned depth / poses / K over 15 seams: against the oracle's flow with the ENGINE's deterministic draws ("engine.*":
+    oracle output on reference-pinned per-window estimates), f32 engine 1e-3 (dense_heads.py:417-470);
+  * frames 0..7 (first window, never re-aligned): against the reference directly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from l4p_amd.weights import ModelCfg, seeded_state_dict
+from tests.golden_utils import assert_bf16_within_reference_drift, integer_state_mismatches, long_batch, reference_autocast_drift, sample_indices
+from tests.test_encoder_dpt_gpu import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALL = ["flow_2d_backward", "track_2d", "depth", "dyn_mask", "camray"]
+TRACK = ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t")
+T, NWIN = 136, 16
+
+
+def _samples(y, g):
+    y = y.float().cpu().reshape(-1)
+    s = y[sample_indices(y.numel())] if y.numel() > 4096 else y
+    return s, torch.from_numpy(np.asarray(g)).reshape(-1).float()
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16"])
+def test_sixteen_windows_all_tasks_vs_reference(dev, precision):
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "mini_T136_long.npz"))
+    cfg = ModelCfg.mini()
+    sd = seeded_state_dict(cfg)
+    m = build(cfg, sd, precision)
+    batch = long_batch(T)
+    head = m.l4p_model.task_heads["track_2d"]
+    head.trace = []
+    with torch.no_grad():
+        out = m.forward({k: v.clone() for k, v in batch.items()}, ALL)
+    torch.cuda.synchronize()
+    trace, head.trace = head.trace, None
+    exact = precision == "32-true"
+    # ---- integer / boolean state over 16 windows / 15 re-seedings ------------------------------------------------------------
+    bad = integer_state_mismatches(trace, gold, NWIN)
+    if exact:
+        assert not bool(bad.any()), bad
+    else:
+        ref_count = int(reference_autocast_drift("mini_T136_long", precision)["tracks_with_differing_integer_state"])
+        print(f"{precision}: {int(bad.sum())} of {bad.numel()} tracks differ from the f32 trace somewhere in 16 windows "
+              f"(the reference's own autocast run: {ref_count})")
+        assert int(bad.sum()) <= max(1, ref_count), (int(bad.sum()), ref_count)
+    # ---- outputs -----------------------------------------------------------------------------------------------------------------
+    report = {}
+    for k in ("flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw") + TRACK:
+        s, g = _samples(out[k], gold[k])
+        report[k] = (float((s - g).abs().max() / g.abs().max()), float((s - g).norm() / g.norm()))
+    joint_keys = ("depth_est_b1thw", "traj3d_est_b16t", "traj3d_intrinsics_est_b16t")
+    for k in joint_keys:
+        s, g = _samples(out[k], gold["engine." + k])
+        report["engine." + k] = (float((s - g).abs().max() / g.abs().max()), float((s - g).norm() / g.norm()))
+    print(precision, {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in report.items()})
+    if exact:
+        for k, (emax, _) in report.items():
+            assert emax <= 1e-3, (k, emax)
+    else:
+        # tracks whose state moved follow another trajectory from there on (as in the reference's own autocast run): the drift gate
+        # is taken over the tracks whose state is the f32 one; the dense outputs do not depend on the tracker
+        keep = ~bad
+        rep = {k: report[k][1] for k in ("flow_2d_backward_est_b2thw", "dyn_mask_est_b1thw")}
+        for k in TRACK:
+            y, g = out[k].float().cpu()[:, keep], torch.from_numpy(gold[k])[:, keep]
+            rep[k] = float((y - g).norm() / g.norm())
+        assert_bf16_within_reference_drift(rep, "mini_T136_long", what="16 windows", precision=precision,
+                                           small=[k for k in TRACK if out[k].numel() < 4096])
+    # ---- frames 0..7 are written by window 0 only: the reference's own values --------------------------------------------------------
+    for k in joint_keys:
+        y = out[k].float().cpu()
+        idx = sample_indices(y.numel()) if y.numel() > 4096 else torch.arange(y.numel())
+        t_of = (idx // (224 * 224)) % T if k == "depth_est_b1thw" else idx % T
+        sel = t_of < 8
+        s = y.reshape(-1)[idx][sel]
+        g = torch.from_numpy(np.asarray(gold[k])).reshape(-1).float()[sel]
+        e = float((s - g).abs().max() / g.abs().max())
+        assert e <= (1e-3 if exact else 6e-2), (k, e)

@@ -163,3 +163,50 @@ def test_single_rank_caller_inside_a_larger_group_stays_local():
         p.join(60)
         assert p.exitcode == 0
     assert all(r[1:] == (True, True, True, True) for r in res), res
+
+
+def _worker_seam(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from l4p_amd.parallel import _SeamComm, init_distributed, window_chunks
+
+    init_distributed("gloo")
+    nwin, B, T = 7, 2, 16  # chunks 3 + 2 + 2
+    comm = _SeamComm(rank, world, torch.device("cpu"))
+    k0 = comm.bcast_k0(torch.arange(B * 16 * T, dtype=torch.float32).reshape(B, 4, 4, T) if rank == 0 else None, B, T)
+    ok_k = bool(torch.equal(k0, torch.arange(B * 16 * T, dtype=torch.float32).reshape(B, 4, 4, T)))
+    s0, e0 = window_chunks(nwin, world)[rank]
+    msg = {"depth": torch.full((B, 1, 8, 3, 3), float(rank)), "camray": torch.full((B, 16, 8), 10.0 + rank),
+           "camray_intrinsics_est": torch.full((B, 16, 8), 20.0 + rank), "flow_frame": torch.full((B, 2, 1, 3, 3), 30.0 + rank)}
+    like = {k: torch.empty_like(v) for k, v in msg.items()}
+    got = comm.pass_tail(msg if rank + 1 < world else None, like if rank > 0 else None, rank > 0, rank + 1 < world)
+    ok_t = (got is None) if rank == 0 else all(float(got[k].mean()) == base + rank - 1 for k, base in
+                                                (("depth", 0.0), ("camray", 10.0), ("camray_intrinsics_est", 20.0), ("flow_frame", 30.0)))
+    rel = {w: torch.full((B, 18), float(w)) for w in range(max(s0, 1), e0)}
+    allr = comm.gather_seams(rel, nwin, B)
+    ok_r = tuple(allr.shape) == (nwin - 1, B, 18) and all(float(allr[w - 1].mean()) == float(w) for w in range(1, nwin))
+    q.put((rank, ok_k, bool(ok_t), bool(ok_r)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_seam_local_messages_world3():
+    """The three messages of the seam-local exchange (parallel._SeamComm: K broadcast, one tail to the next rank, all-gather of the
+    seam records over unequal chunks) through gloo with three ranks; and what a rank receives under the two schedules."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_seam, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(3))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] and r[3] for r in res), res
+    from l4p_amd.parallel import seam_exchange_bytes
+
+    b = seam_exchange_bytes(B=1, nwin=31, world=8)
+    # every decoded window a rank does not own (27 x 12.9 MB) against one tail + K + 30 seam records
+    assert 300e6 < b["gather_schedule"] < 400e6 and 1.5e6 < b["seam_local_schedule"] < 2.5e6, b

@@ -29,6 +29,9 @@ def mini():
     return cfg, seeded_state_dict(cfg)
 
 
+_ORACLE_TRACK = {}
+
+
 @pytest.mark.parametrize("precision", ["32-true", "bf16", "16-mixed"])
 @pytest.mark.parametrize("case,T,nq", [("mini_T16_all", 16, 8), ("mini_T32_stitch", 32, 12)])
 def test_tracker_vs_oracle_and_golden(dev, mini, precision, case, T, nq):
@@ -40,10 +43,12 @@ def test_tracker_vs_oracle_and_golden(dev, mini, precision, case, T, nq):
     head.trace = []
     batch = make_batch(T, nq)
     gold = np.load(os.path.join(GOLD, case + ".npz"))
-    otrace = []
     with torch.no_grad():
         out = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
-        oout = OracleModel(sd, cfg).forward(batch, ["track_2d"], trace=otrace)
+        if case not in _ORACLE_TRACK:  # (the CPU oracle's run is the same for every engine precision: once per case)
+            otr = []
+            _ORACLE_TRACK[case] = (OracleModel(sd, cfg).forward(batch, ["track_2d"], trace=otr), otr)
+        oout, otrace = _ORACLE_TRACK[case]
     torch.cuda.synchronize()
     exact = precision == "32-true"
     drift = {}
@@ -343,15 +348,15 @@ def test_trace_is_recorded_with_the_clip_streams_on(dev, mini, monkeypatch):
 
 def test_more_queries_than_max_queries_vs_oracle(dev, mini):
     """Row f4 (demo.py:38-40,57): N > max_queries over 3 windows against the ORACLE (not against the engine's own one-pass
-    result): 300 queries at mixed start frames in chunks of 128 (128 + 128 + 44), f32 engine, 1e-3; integer / boolean window
+    result): 112 queries at mixed start frames in chunks of 48 (48 + 48 + 16), f32 engine, 1e-3; integer / boolean window
     state bit-exact per chunk.  The oracle chunks the same way (OracleModel.track, sparse_heads.py:162-211)."""
     from oracle.l4p_oracle import OracleModel
 
     cfg, sd = mini
     model = build(cfg, sd, "32-true")
     head = model.l4p_model.task_heads["track_2d"]
-    head.max_queries = 128
-    nq = 300
+    head.max_queries = 48  # (the chunking logic does not depend on the chunk size; the CPU oracle's time is linear in the queries)
+    nq = 112
     batch = make_batch(32, nq)
     g = torch.Generator().manual_seed(5)
     batch["track_2d_pointquerries_bn3"][0, :, 1:] = torch.rand(nq, 2, generator=g) * 200 + 12  # off-grid positions
@@ -359,7 +364,7 @@ def test_more_queries_than_max_queries_vs_oracle(dev, mini):
     otrace = []
     with torch.no_grad():
         out = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
-        om = OracleModel(sd, cfg, max_queries=128)
+        om = OracleModel(sd, cfg, max_queries=48)
         ref = om.forward(batch, ["track_2d"], trace=otrace)
     torch.cuda.synchronize()
     for k in ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"):

@@ -14,6 +14,7 @@ int knob(int) { return 1; }
 #include "../../l4p_amd/csrc/attention64.hip"
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4, S = 2048, H = 16, Dh = 88;
+    const bool zeros = argc > 2 && atoi(argv[2]);  // all-zero operands: the same instruction stream at the clock an idle matrix pipe is granted
     const size_t n = (size_t)B * S * H * 96;
     std::vector<unsigned short> h(n);
     unsigned st = 12345u;
@@ -25,7 +26,7 @@ int main(int argc, char** argv) {
         }
         unsigned u;
         memcpy(&u, &acc, 4);
-        h[i] = (unsigned short)((u + 0x8000u) >> 16);
+        h[i] = zeros ? 0 : (unsigned short)((u + 0x8000u) >> 16);
     }
     void *q, *kt, *vt, *out;
     hipMalloc(&q, n * 2); hipMalloc(&kt, n * 2); hipMalloc(&vt, n * 2); hipMalloc(&out, n * 2);
@@ -39,7 +40,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < it; ++i) launch_attention64(L4P_BF16, q, kt, vt, out, B, S, H, Dh, 0.1066f, 0);
     hipEventRecord(b, 0); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    printf("B=%d: %.2f us per launch\n", B, ms / it * 1e3);
+    printf("B=%d%s: %.2f us per launch\n", B, zeros ? " zeros" : "", ms / it * 1e3);
 #ifdef ATTN64_TRACE
     std::vector<long long> t(4096);
     hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(attn64::g_trace), 4096 * 8);

@@ -10,6 +10,9 @@ build noldsread -DATTN64_DBG_NOLDSREAD
 build nobarrier -DATTN64_DBG_NOBARRIER
 build nosm_nolds -DATTN64_DBG_NOSOFTMAX -DATTN64_DBG_NOLDSREAD
 build nosm_nolds_noload -DATTN64_DBG_NOSOFTMAX -DATTN64_DBG_NOLDSREAD -DATTN64_DBG_NOLOAD
+build pre2 -DATTN64_PRE=2
+build pre6 -DATTN64_PRE=6
+build pre8 -DATTN64_PRE=8
 build mfma_only -DATTN64_DBG_NOSOFTMAX -DATTN64_DBG_NOLDSREAD -DATTN64_DBG_NOLOAD -DATTN64_DBG_NOBARRIER
 wait
 ls tools/probes/attn64_var_*
