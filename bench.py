@@ -353,6 +353,49 @@ def c5_phase_times(net, batch, tasks, rank, world, group):
             rank0_of_8()
             _, r8 = timed(rank0_of_8)
             res["emulated_rank0_of_8_ms"] = round(r8, 3)
+            # The same rank under the SEAM-LOCAL exchange (parallel.stitch_seam_local; L4P_C5_EXCHANGE=seam): its own
+            # windows' heads, its own seams against the raw predecessor, the prefix composition of all 30 seam records (taken from an
+            # untimed emulation of the 8 ranks), its own frames - instead of the replicated stitch of all 31 windows.
+            if par.seam_local_supported(net, dense):
+                img_info = tuple(data.get("img_info", net.window_size))
+                _, rel_all = par.stitch_seam_local_emulated(net, data, dense, windows, 8)
+                s0, e0 = par.window_chunks(nwin, 8)[0]
+
+                def seam_part():
+                    st8 = par.SeamLocalState(0, 8, {w: windows[w] for w in range(s0, e0)}, strides, net.window_size[0])
+                    k0 = par.seam_phase_k0(net, st8, data, img_info)
+                    par.seam_phase_heads(net, st8, data, dense, img_info, k0)
+                    par.seam_phase_solve(st8, None, img_info)
+                    return par.seam_phase_apply(st8, rel_all)
+
+                def rank0_of_8_seam():
+                    g8 = par.encode_local_windows(net, data, tasks, 0, 8, group)
+                    tr = net.task_heads["track_2d"]
+                    tr.defer_join = tr.own_stream = True
+                    tr.start_event = torch.cuda.Event()
+                    tr.start_event.record(torch.cuda.current_stream())
+                    try:
+                        par.decode_encoded_windows(net, data, tasks, g8)
+                        o = run_tracker(lasts, 0, 8)
+                        tr.join_streams()
+                        seam_part()
+                    finally:
+                        tr.join_streams()
+                        tr.defer_join = tr.own_stream = False
+                        tr.start_event = None
+                    return o
+
+                _, sp = timed(seam_part)
+                _, sp = timed(seam_part)
+                rank0_of_8_seam()
+                _, r8s = timed(rank0_of_8_seam)
+                res["phase3_dense_seam_local_rank0_of_8_ms"] = round(sp, 3)
+                res["emulated_rank0_of_8_seam_local_ms"] = round(r8s, 3)
+            xb = par.seam_exchange_bytes(B, nwin, 8, tasks=tuple(dense))
+            last_bytes = B * 2048 * net.cfg.dim * 4 * (nwin - (par.window_chunks(nwin, 8)[1][1] - par.window_chunks(nwin, 8)[1][0]))
+            res["exchange_bytes_per_rank_of_8"] = {"last_layer_features_all_gather": int(last_bytes),
+                                                   "dense_gather_schedule": xb["gather_schedule"],
+                                                   "dense_seam_local_schedule": xb["seam_local_schedule"]}
     if world == 1:
         serial = enc + dec + st + trk  # the pieces one after the other on one GPU
         res["serial_sum_ms"] = round(serial, 3)
@@ -528,6 +571,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=sorted(PRECISION), help="engine dtype: bf16 (BASELINE.json's configs; default), "
                     "16-mixed (IEEE half: the reference demo's own mode), 32-true (exact-f32 parity engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-quick", action="store_true",
+                    help="contract tests only: time 4 encoder blocks and 8 queries and scale (the default times the whole clip)")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--host-io", action="store_true", help="c2 / c3: after the timed steps, K more with the inputs coming from and every output going to "
                                                            "pinned host memory; reported as pcie_inclusive (never as value)")
@@ -668,6 +713,8 @@ def main():
             res["implied_8gpu_speedup_tracker_beside_decoders"] = round(t1 / phases["implied_8gpu_ms_tracker_beside_decoders"], 3)
             if "emulated_rank0_of_8_ms" in phases:
                 res["implied_8gpu_speedup_emulated_rank"] = round(t1 / phases["emulated_rank0_of_8_ms"], 3)
+            if "emulated_rank0_of_8_seam_local_ms" in phases:
+                res["implied_8gpu_speedup_emulated_rank_seam_local"] = round(t1 / phases["emulated_rank0_of_8_seam_local_ms"], 3)
     if not args.no_prof:
         prof = read_prof(lib)
         nwin_total = (args.frames - 16) // 8 + 1 if c5 else 1
@@ -743,7 +790,8 @@ def main():
         if c5:  # one 16-frame window of the long video (the CPU port is timed per clip of 16 frames)
             bc = {k: (v[..., :16, :, :] if k == "rgb_b3thw" else v[..., :16] if k == "intrinsics_b44t" else v) for k, v in bc.items()}
         with contextlib.redirect_stdout(sys.stderr):
-            res["cpu_baseline"] = cpu_baseline(sd, cfg, tasks, bc)
+            res["cpu_baseline"] = (cpu_baseline(sd, cfg, tasks, bc, sample_blocks=4, sample_queries=8) if args.cpu_baseline_quick else
+                                   cpu_baseline(sd, cfg, tasks, bc))
     print(json.dumps(res))
 
 

@@ -406,6 +406,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
                 constexpr int p = decltype(p_)::value;
                 pe[p] = pack2(xa[p], xb[p], T{});
+                // (pinned: the early pairs are only USED on the path that skips the next step's rare branch, and the optimiser sank
+                //  their 28 exponentials + 14 packs out of the PV gaps into that path's own block - 250 cycles beside no MFMA)
+                asm volatile("" : "+v"(pe[p]));
             };
             float mxn[QB] = {-INFINITY, -INFINITY};
             auto M = [&](auto u_) __attribute__((always_inline)) {  // two more scores into the running maximum of their query block: u = 0 .. 31, tile 0 first

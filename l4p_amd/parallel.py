@@ -628,6 +628,32 @@ def stitch_seam_local(net, data: dict, tasks: List[str], windows: dict, rank: in
     return seam_outputs(net, local, T, rank, world, nwin, gather_outputs and on)
 
 
+def stitch_seam_local_emulated(net, data: dict, tasks: List[str], windows: list, world: int):
+    """The phases of stitch_seam_local for EVERY rank of ``world`` in one process, the three messages handed over by hand (the
+    emulated-rank tests and bench.py's one-of-eight-ranks measurement).  ``windows``: DecodedWindow of all windows.
+    -> (frame blocks per rank, the seam records [n_windows - 1, B, 18])."""
+    T = data["rgb_b3thw"].shape[2]
+    B = data["rgb_b3thw"].shape[0]
+    img_info = tuple(data.get("img_info", net.window_size))
+    strides = net.time_strides(T)
+    nwin = len(strides)
+    states = []
+    for r in range(world):
+        s0, e0 = window_chunks(nwin, world)[r]
+        states.append(SeamLocalState(r, world, {w: windows[w] for w in range(s0, e0)}, strides, net.window_size[0]))
+    k0 = seam_phase_k0(net, states[0], data, img_info)                                  # broadcast
+    msgs = [seam_phase_heads(net, st, data, tasks, img_info, k0) for st in states]
+    rel: dict = {}
+    last_msg = None
+    for r, st in enumerate(states):                                                      # P2P: the previous rank's tail
+        rel.update(seam_phase_solve(st, last_msg, img_info))
+        if msgs[r] is not None:
+            last_msg = msgs[r]
+    rel_all = (torch.stack([rel[w] for w in range(1, nwin)], dim=0) if nwin > 1 else
+               torch.zeros(0, B, 18, dtype=torch.float32, device=net.device))            # all-gather of 18 floats per seam
+    return [seam_phase_apply(st, rel_all) for st in states], rel_all
+
+
 def seam_outputs(net, local: dict, T: int, rank: int, world: int, nwin: int, gather: bool) -> dict:
     """Output keys of L4P_VideoMAE.forward from a rank's frame blocks (optionally all-gathered into whole tensors)."""
     names = {"depth": "depth", "camray": "camray", "flow_2d_backward": "flow_2d_backward", "dyn_mask": "dyn_mask"}

@@ -34,7 +34,7 @@ def _check_common(r, steps, warmup):
 
 
 def test_default_workload_line(dev):
-    r = _run(["--steps", "1", "--warmup", "1"])
+    r = _run(["--steps", "1", "--warmup", "1", "--cpu-baseline-quick"])  # (the CPU leg on a scaled sample: the test is about the line)
     _check_common(r, 1, 1)
     assert r["unit"] == "frames/s" and r["dtype"] == "bf16" and r["scaling"] == "weak" and "all heads" in r["metric"]
     assert r["roofline"]["bound"] == "mfma" and r["roofline"]["peak"] == 2500.0 and "roofline_attention" in r
@@ -54,7 +54,7 @@ def test_c5_workload_line_at_full_length(dev):
     """configs[4] on one GPU at its own length: 256 frames = 31 windows, all heads, on-GPU alignment.  Property checks at full
     size: the line carries the pieces of the step (encoders, decoders, replicated dense stitch, tracker recursion in full and on
     an eighth of the queries) and what they imply for 8 GPUs with the tracker after / beside the decoders."""
-    r = _run(["--workload", "c5", "--steps", "1", "--warmup", "1"])
+    r = _run(["--workload", "c5", "--steps", "1", "--warmup", "1", "--cpu-baseline-quick"])
     _check_common(r, 1, 1)
     assert r["scaling"] == "strong" and "31 overlapping" in r["config"]["workload"]
     assert abs(r["value"] - 256 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-2

@@ -75,21 +75,9 @@ def test_similarity_prefix_is_the_product_of_the_records(dev):
     assert (p1 - p2).abs().max() <= 1e-5 * p1.abs().max() and (d1 - d2).abs().max() <= 1e-6 * d1.abs().max()
 
 
-def _emulate(net, data, tasks, windows, world, img_info):
-    """The phases of parallel.stitch_seam_local for every rank of one process, the three messages handed over by hand."""
-    strides = net.time_strides(T)
-    nwin = len(strides)
-    states = []
-    for r in range(world):
-        s0, e0 = parallel.window_chunks(nwin, world)[r]
-        states.append(parallel.SeamLocalState(r, world, {w: windows[w] for w in range(s0, e0)}, strides, WS))
-    k0 = parallel.seam_phase_k0(net, states[0], data, img_info)                      # broadcast
-    msgs = [parallel.seam_phase_heads(net, st, data, tasks, img_info, k0) for st in states]
-    rel = {}
-    for r, st in enumerate(states):                                                   # P2P: the previous rank's tail
-        rel.update(parallel.seam_phase_solve(st, msgs[r - 1] if r > 0 else None, img_info))
-    rel_all = torch.stack([rel[w] for w in range(1, nwin)], dim=0)                     # all-gather of 18 floats per seam
-    blocks = [parallel.seam_phase_apply(st, rel_all) for st in states]
+def _emulate(net, data, tasks, windows, world):
+    """parallel.stitch_seam_local_emulated + the frame blocks of the ranks put back together."""
+    blocks, rel_all = parallel.stitch_seam_local_emulated(net, data, tasks, windows, world)
     ranges = [b["frame_range"] for b in blocks]
     assert ranges[0][0] == 0 and ranges[-1][1] == T and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), ranges
     out = {k: torch.cat([b[k] for b in blocks], dim=2) for k in blocks[0] if k != "frame_range"}
@@ -117,7 +105,7 @@ def test_seam_local_schedule_equals_the_sequential_stitch_on_rendered_windows(de
             "intrinsics_b44t": K[None, :, :, None].repeat(1, 1, 1, T).cuda()}
     with torch.no_grad():
         seq = net.stitch_windows(windows, data, tasks, strides)
-        loc, rel_all = _emulate(net, data, tasks, windows, world, (WS, H, W))
+        loc, rel_all = _emulate(net, data, tasks, windows, world)
     torch.cuda.synchronize()
     pairs = {"depth": "depth_est_b1thw", "camray": "traj3d_est_b16t", "camray_intrinsics_est": "traj3d_intrinsics_est_b16t"}
     for k, key in pairs.items():

@@ -197,7 +197,7 @@ def test_quantile_and_rank_select_on_signed_values(dev):
 
 
 def test_depth_stitch_with_linear_aligner(dev):
-    """VideoMAEDepthDPTHead(align_type="linear") (dense_heads.py:146-170): the 3-window depth stitch with the scale-only
+    """VideoMAEDepthDPTHead(align_type="linear") (dense_heads.py:146-170): a 2-window depth stitch with the scale-only
     LinearAligner(method="mean") against the oracle's restatement of aligner.py:91-118, and it must differ from the affine one."""
     from l4p_amd.models.aligner import LinearAligner
     from oracle.l4p_oracle import OracleModel
@@ -205,7 +205,7 @@ def test_depth_stitch_with_linear_aligner(dev):
     cfg = ModelCfg.mini()
     sd = seeded_state_dict(cfg)
     model = build(cfg, sd, "32-true")
-    batch = make_batch(32, 2)
+    batch = make_batch(24, 2)
     with torch.no_grad():
         affine = model.forward({k: v.clone() for k, v in batch.items()}, ["depth"])["depth_est_b1thw"].float().cpu()
         model.l4p_model.task_heads["depth"].overlap_aligner_type = LinearAligner

@@ -348,15 +348,15 @@ def test_trace_is_recorded_with_the_clip_streams_on(dev, mini, monkeypatch):
 
 def test_more_queries_than_max_queries_vs_oracle(dev, mini):
     """Row f4 (demo.py:38-40,57): N > max_queries over 3 windows against the ORACLE (not against the engine's own one-pass
-    result): 112 queries at mixed start frames in chunks of 48 (48 + 48 + 16), f32 engine, 1e-3; integer / boolean window
+    result): 80 queries at mixed start frames in chunks of 32 (32 + 32 + 16), f32 engine, 1e-3; integer / boolean window
     state bit-exact per chunk.  The oracle chunks the same way (OracleModel.track, sparse_heads.py:162-211)."""
     from oracle.l4p_oracle import OracleModel
 
     cfg, sd = mini
     model = build(cfg, sd, "32-true")
     head = model.l4p_model.task_heads["track_2d"]
-    head.max_queries = 48  # (the chunking logic does not depend on the chunk size; the CPU oracle's time is linear in the queries)
-    nq = 112
+    head.max_queries = 32  # (the chunking logic does not depend on the chunk size; the CPU oracle's time is linear in the queries)
+    nq = 80
     batch = make_batch(32, nq)
     g = torch.Generator().manual_seed(5)
     batch["track_2d_pointquerries_bn3"][0, :, 1:] = torch.rand(nq, 2, generator=g) * 200 + 12  # off-grid positions
@@ -364,7 +364,7 @@ def test_more_queries_than_max_queries_vs_oracle(dev, mini):
     otrace = []
     with torch.no_grad():
         out = model.forward({k: v.clone() for k, v in batch.items()}, ["track_2d"])
-        om = OracleModel(sd, cfg, max_queries=48)
+        om = OracleModel(sd, cfg, max_queries=32)
         ref = om.forward(batch, ["track_2d"], trace=otrace)
     torch.cuda.synchronize()
     for k in ("track_2d_traj_est_bn2t", "track_2d_vis_est_bn1t", "track_2d_depth_est_bn1t"):
