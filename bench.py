@@ -546,7 +546,7 @@ def bench_demo(args, rank, world, device, lib, selftest):
                                f"{'+'.join(DEMO_TASKS)}, {nq} grid queries in chunks of {net.task_heads['track_2d'].max_queries}, windows batched {net.window_batch} at a time",
                    "queries": nq, "windows": nwin, "tasks": DEMO_TASKS},
         "roofline": {"kernel": {"gemm": "gemm8p_kernel<0> / gemm_kernel<bf16,MODE0>", "conv3d": "gemm8p_kernel<1> / gemm_kernel<bf16,MODE1>",
-                                "attention": "attn_kernel<bf16,96,64>"}[dom], "bound": "mfma", "achieved": classes[dom]["tflops"],
+                                "attention": "attn64_kernel<bf16,88> (encoder attention, one wave per SIMD, 64 query rows per wave; attn_kernel<bf16,96,64> below 256 tiles)"}[dom], "bound": "mfma", "achieved": classes[dom]["tflops"],
                      "peak": PRECISION[ENGINE_PRECISION][2] / 1e12, "unit": "TFLOP/s", "frac": round(classes[dom]["tflops"] / (PRECISION[ENGINE_PRECISION][2] / 1e12), 4),
                      "traffic": None, "method": "algorithmic FLOPs / HIP-event-bracketed kernel time, second pass of the same K steps",
                      "algorithmic_flops_per_step": fl[dom] * nwin},
@@ -746,7 +746,7 @@ def main():
         dom = max(mfma, key=lambda k: classes[k]["ms_per_step"])
         kern = {"gemm": "gemm8p_kernel<0> / gemm_kernel<bf16,MODE0> (linear / 1x1x1 conv / ConvTranspose GEMM; >= 1024 rows, one weight matrix)",
                 "conv3d": "conv3_halo_kernel (LDS-halo 3x3x3 conv) / gemm_kernel<bf16,MODE1> (implicit-GEMM 3x3x3 conv, low-resolution levels)",
-                "attention": "attn_kernel<bf16,96,64>"}
+                "attention": "attn64_kernel<bf16,88> (encoder attention, one wave per SIMD, 64 query rows per wave; attn_kernel<bf16,96,64> below 256 tiles)"}
 
         # HBM bytes per launch of the class from the committed PMC passes (profiles/r01_c3_hbm_traffic.*: rocprofv3
         # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate passes); PMC cannot be collected from inside this

@@ -30,9 +30,19 @@ __device__ long long g_trace[4096];
     do {                                                                                   \
         if (blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 4096) g_trace[slot] = __builtin_readcyclecounter(); \
     } while (0)
+// inside a KV step the stamps stay in scalar registers (s_memtime returns through lgkmcnt like an LDS read: waiting for each one
+// would drain the fragment reads in flight and time a different kernel) and are stored behind the step's closing barrier - only in
+// steps that store them: an s_memtime whose destination the compiler considers dead lands in registers it has handed to something else
+#define A64_STEP_STAMP(i)                                                    \
+    do {                                                                     \
+        if constexpr (HAS_NEXT) asm volatile("s_memtime %0" : "=s"(ts_[i])); \
+    } while (0)
 #else
 #define A64_STAMP(slot) \
     do {                \
+    } while (0)
+#define A64_STEP_STAMP(i) \
+    do {                  \
     } while (0)
 #endif
 
@@ -290,7 +300,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                        frag_t (&qf)[QB][NKS], unsigned (&pw)[NP], unsigned (&ka)[NST], unsigned (&va)[NST * 2]) __attribute__((always_inline)) {
             constexpr bool HAS_NEXT = decltype(has_next)::value;
             constexpr int CUR = decltype(cur_)::value;
-            A64_STAMP(8 + it * 8 + 0);
+#ifdef ATTN64_TRACE
+            unsigned long long ts_[6] = {};
+#endif
+            A64_STEP_STAMP(0);
             // the tiles the requests of this step fetch: K block it + 2 and V^T block it + 1 - of the next tile past this one's end (and,
             // on the last tile, of this one again: a request nobody reads, cheaper than a branch in the MFMA stream)
             const bool k_in = it + 2 < nit, v_in = it + 1 < nit;
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef ATTN64_DBG_NOLOAD
             if (has_next_tile && it == nit - 4) issue_q(qrow0n, bhn);
 #endif
-            A64_STAMP(8 + it * 8 + 1);
+            A64_STEP_STAMP(1);
 
             // rare side path (always at the first block): move the reference, rescale O, rewrite -m in Q's padding dims, shift this
             // block's scores in place and redo the early pairs
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %0\n\tv_max_f32 %0, %0, %1" : "+v"(m), "=&v"(t));
                 mx[b] = m;
             };
-            A64_STAMP(8 + it * 8 + 2);
+            A64_STEP_STAMP(2);
             static_for<0, PRE>(rd);
             if constexpr (!HAS_NEXT) {  // the last block of a tile: no scores to build, its late pairs up front
                 static_for<E_, NP>([&](auto p_) __attribute__((always_inline)) { X(p_, s_cur); });
@@ -440,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     constexpr int issued = (PRE + m < NR) ? PRE + m : NR;
                     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(issued - m - 2) : "memory");
                 }
-                if constexpr (r == 12 && b == 0 && HAS_NEXT) A64_STAMP(8 + it * 8 + 3);
+                if constexpr (r == 12 && b == 0 && HAS_NEXT) A64_STEP_STAMP(3);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (r < 12) {
                     s_nxt[b][r % NST] = mma32(__builtin_bit_cast(frag_t, fr[r]), qf[b][r / NST], r < NST ? zero16 : s_nxt[b][r % NST]);
@@ -493,11 +506,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (HAS_NEXT) {
 #pragma unroll
                 for (int p = 0; p < E_; ++p) pw[p] = pe[p];
-                A64_STAMP(8 + it * 8 + 4);
+                A64_STEP_STAMP(4);
 #ifndef ATTN64_DBG_NOBARRIER
                 __syncthreads();
 #endif
-                A64_STAMP(8 + it * 8 + 5);
+                A64_STEP_STAMP(5);
+#ifdef ATTN64_TRACE
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (blockIdx.x == 0 && threadIdx.x == 0 && 8 + it * 8 + 5 < 4096)
+                    for (int i = 0; i < 6; ++i) g_trace[8 + it * 8 + i] = (long long)ts_[i];
+#endif
             }
         };
         {

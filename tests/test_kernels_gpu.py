@@ -230,6 +230,41 @@ def test_attention_peaked_softmax(dev, mode, prescaled, S, B, H):
     check_attn(out, ref, mode, prescaled)
 
 
+@pytest.mark.parametrize("mode", [m for m in MODES if m != L4P_F32])
+@pytest.mark.parametrize("B,S,H,Dh", [(2, 2048, 16, 88),   # 256 tiles: one per workgroup, no tile seam
+                                      (3, 2048, 16, 88),   # 384 tiles: workgroups with one and with two tiles
+                                      (11, 1024, 6, 88),   # 264 tiles of 16 KV blocks, batch * heads = 66 not a multiple of 8 (plain tile order)
+                                      (4, 2048, 16, 64)])  # head dim 64: the constant pieces sit elsewhere in the tile
+def test_attention64_forms_and_the_8_wave_kernel(dev, knob, mode, B, S, H, Dh):
+    """csrc/attention64.hip (one wave per SIMD, 64 query rows per wave; launches of >= 256 tiles of 256 rows) against fp32 softmax
+    on the same rounded operands, in its tile-walk variants, and against the 8-wave kernel on the same inputs (knob attn64 = 0):
+    the two agree to the rounding of P - they move the deferred maximum per 64 / per 32 rows."""
+    g = torch.Generator().manual_seed(B * 1000 + S + Dh)
+    q4 = torch.randn(B, S, H, ops.DP, generator=g) * (Dh ** -0.5 * LOG2E)
+    k4 = torch.randn(B, S, H, ops.DP, generator=g)
+    v4 = torch.randn(B, S, H, ops.DP, generator=g)
+    for t in (q4, k4, v4):
+        t[..., Dh:] = 0
+    k4[1, 700:708] *= 5.0  # a few dominant keys in one batch item: the rescale path runs in some waves and not in others
+    q, kt, vt, qf, kf, vf = _attn_inputs(q4, k4, v4, mode)
+    out = {}
+    for v in (1, 0):
+        knob("attn64", v)
+        out[v] = ops.attention(q, kt, vt, Dh, scale=0.0)
+        torch.cuda.synchronize()
+    td = ops.torch_dtype(mode)
+    ref = torch.empty(B, S, H, Dh)
+    for b in range(B):  # (per batch item: the fp32 score matrix of one item is 16 x 2048 x 2048 floats)
+        qh, kh, vh = (t[b].permute(1, 0, 2).double() for t in (qf, kf, vf))
+        attn = torch.softmax((qh * math.log(2.0)) @ kh.transpose(-2, -1), dim=-1)
+        ref[b] = (attn @ vh)[..., :Dh].permute(1, 0, 2).float()
+    ref = ref.reshape(B * S, H * Dh)
+    for v in (1, 0):
+        check_attn(out[v], ref, mode, True)
+    d = (out[1].float() - out[0].float()).abs().max().item()
+    assert d <= ref.abs().max().item() * 2 ** (-6 if td == torch.bfloat16 else -9), d
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_attention_very_negative_and_huge_scores(dev, mode):
     """All scores of a row far below zero (the first block must SET the reference, not clamp it at 0) and a row whose

@@ -49,4 +49,10 @@ python tools/pmc_fetch_calibration.py $O/pmc_${TAG}_calib_f $O/pmc_${TAG}_calib_
 python tools/pmc_mfma_util.py $O/pmc_${TAG}_sq $O/pmc_${TAG}_grbm $O/${TAG}_power_probe.txt > $O/${TAG}_c3_mfma_util.md 2> $O/${TAG}_mfma_util.err
 python tools/rocprof_summary.py $(find $O/prof_${TAG}_c3 -name "*.db" | head -1) "L4P_TRACK_STREAMS=0 L4P_HEAD_STREAMS=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof (c3: 7 steps, every kernel serialised on one stream)" > $O/${TAG}_c3_kernel_stats.md
 python tools/rocprof_summary.py $(find $O/prof_${TAG}_c2 -name "*.db" | head -1) "python bench.py --workload c2 --steps 10 --warmup 3 --no-cpu-baseline --no-prof (c2: 13 steps)" > $O/${TAG}_c2_kernel_stats.md
-ls -la $O | grep ${TAG}_ | head -30
+# round 6: the two encoder attention kernels side by side (knob attn64), random and all-zero operands; what fits behind an MFMA when
+# one wave owns the SIMD (tools/probes/gap_probe.hip); the 16-bit drift gates' ratios with the non-bit-identical kernels off one by one
+( for v in 0 1; do echo "== attn64=$v, random operands"; L4P_ATTN64=$v python tools/attn_time.py 2>/dev/null | tail -3; echo "== attn64=$v, all-zero operands"; L4P_ATTN64=$v python tools/attn_time.py --zeros 2>/dev/null | tail -3; done ) > $O/${TAG}_attention64_ab.txt 2>&1
+[ -x tools/probes/gap_probe ] && timeout 300 tools/probes/gap_probe > $O/${TAG}_mfma_gap_probe.txt 2>&1
+[ -x tools/probes/attn64_var_trace ] && ( timeout 60 tools/probes/attn64_var_trace 4; timeout 60 tools/probes/attn64_var_trace 4 1 ) > $O/${TAG}_attention64_step_trace.txt 2>&1
+bash tools/drift_report.sh > $O/${TAG}_bf16_drift_ratios.txt 2>&1
+ls -la $O | grep ${TAG}_ | head -40

@@ -37,7 +37,7 @@ def klass(name):
         return "gemm_small"
     if "gemm" in name or "splitk" in name:
         return "gemm"
-    if "attn_kernel" in name and "t2i" not in name and "i2t" not in name and "self" not in name:
+    if ("attn_kernel" in name or "attn64_kernel" in name) and "t2i" not in name and "i2t" not in name and "self" not in name:
         return "attention"
     if "layernorm" in name:
         return "layernorm"

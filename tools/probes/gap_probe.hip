@@ -46,8 +46,10 @@ __global__ __launch_bounds__(256) void gap_kernel(float* out, long long* cyc, in
             else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a), "v"(b));
             fillers<KIND, K>(x, p, fr, lds);
         }
-        if constexpr (KIND == 3) asm volatile("s_waitcnt lgkmcnt(0)");
     }
+    // (LDS reads return in order and nothing consumes them here: no wait inside the loop, so the figure is the issue / return-path
+    //  cost of a read, not its latency)
+    asm volatile("s_waitcnt lgkmcnt(0)");
     const long long t1 = __builtin_readcyclecounter();
     asm volatile("s_nop 15\n s_nop 15");
     float s = 0;
