@@ -24,11 +24,11 @@ def test_video_dataset_to_model_forward(dev):
     model = build(cfg, sd, "32-true")
     frames = synthetic_video(31, 20, 96, 128)  # 20 frames -> mirror-padded, cropped to 24 = 2 windows
     ds = VideoDataset(video_paths=["videos/clip.mp4"], crop_size=(24, 224, 224), estimation_directions=[1],
-                      track_2d_querry_sampling_spacing=0.34, frames={"videos/clip.mp4": frames}, device=dev)
+                      track_2d_querry_sampling_spacing=0.5, frames={"videos/clip.mp4": frames}, device=dev)
     loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
     batch = next(iter(loader))
     assert batch["rgb_b3thw"].shape == (1, 3, 24, 224, 224) and batch["rgb_b3thw"].is_cuda
-    assert batch["track_2d_pointquerries_bn3"].shape == (1, 9, 3) and batch["seq_name"] == ["clip.mp4"]
+    assert batch["track_2d_pointquerries_bn3"].shape == (1, 4, 3) and batch["seq_name"] == ["clip.mp4"]
     with torch.no_grad():
         out = model.forward(batch, TASKS)
         cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -36,7 +36,7 @@ def test_video_dataset_to_model_forward(dev):
     torch.cuda.synchronize()
     for key, shape in [("depth_est_b1thw", (1, 1, 24, 224, 224)), ("flow_2d_backward_est_b2thw", (1, 2, 24, 224, 224)),
                        ("dyn_mask_est_b1thw", (1, 1, 24, 224, 224)),
-                       ("track_2d_traj_est_bn2t", (1, 9, 2, 24)), ("track_2d_vis_est_bn1t", (1, 9, 1, 24))]:
+                       ("track_2d_traj_est_bn2t", (1, 4, 2, 24)), ("track_2d_vis_est_bn1t", (1, 4, 1, 24))]:
         y, r = out[key].float().cpu(), ref[key]
         assert tuple(y.shape) == shape == tuple(r.shape), key
         assert bool(torch.isfinite(y).all()), key
