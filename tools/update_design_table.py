@@ -38,7 +38,7 @@ for name, d in rows:
     t += (f"| {name} | **{d['value']:.0f}** | {d['ms_per_step']:.1f} | {kc(d, 'gemm')} | {kc(d, 'conv3d')} | {kc(d, 'attention')} | {kc(d, 'gemm_small')} | "
           f"{kc(d, 'layernorm', False)} | {kc(d, 'elementwise', False)} | {kc(d, 'track', False)} |\n")
 t += f"| prep: 50 decoded 480×854 frames → [3,64,224,224] | **{pr['value'] / 1000:.0f} k** | {pr['ms_per_step']:.2f} | | | | | | | |\n"
-attn = [l for l in open(os.path.join(P, f"{tag}_c3_kernel_stats.md")) if "attn_kernel" in l][0].split("|")
+attn = [l for l in open(os.path.join(P, f"{tag}_c3_kernel_stats.md")) if "attn64_kernel" in l or "_Z11attn_kernel" in l][0].split("|")
 avg = float(attn[4])
 rd = c3["roofline"]
 ra = c3.get("roofline_attention", rd)
@@ -55,8 +55,13 @@ g = c5.get
 t += (f"c5 pieces on one GPU: encoders {g('phase1a_encoder_ms'):.0f} ms, decoders {g('phase1b_decoders_ms'):.0f} ms, dense stitch {g('phase3_dense_ms'):.1f} ms, "
       f"tracker {g('phase3_track_ms'):.0f} ms ({g('phase3_track_ms_on_an_eighth_of_the_queries'):.0f} ms on an eighth of the queries), exchanges on one rank "
       f"{g('exchange_last_ms'):.1f} + {g('exchange_decoded_ms'):.1f} ms.  **One of eight ranks, emulated and measured: {g('emulated_rank0_of_8_ms'):.0f} ms "
-      f"= {g('implied_8gpu_speedup_emulated_rank'):.1f}x** implied on 8 GPUs (models: tracker after the decoders "
-      f"{g('implied_8gpu_speedup_tracker_after_decoders'):.1f}x, ideally beside them {g('implied_8gpu_speedup_tracker_beside_decoders'):.1f}x).\n<!--R4TABLE-END-->\n")
+      f"= {g('implied_8gpu_speedup_emulated_rank'):.1f}x** implied on 8 GPUs with the gather schedule"
+      + (f", **{g('emulated_rank0_of_8_seam_local_ms'):.0f} ms = {g('implied_8gpu_speedup_emulated_rank_seam_local'):.1f}x with the seam-local exchange** "
+         f"(the rank's dense path {g('phase3_dense_seam_local_rank0_of_8_ms'):.1f} ms instead of {g('phase3_dense_ms'):.1f}; bytes received per rank for the dense path "
+         f"{g('exchange_bytes_per_rank_of_8')['dense_seam_local_schedule'] / 1e6:.1f} MB instead of {g('exchange_bytes_per_rank_of_8')['dense_gather_schedule'] / 1e6:.0f} MB, "
+         f"+ {g('exchange_bytes_per_rank_of_8')['last_layer_features_all_gather'] / 1e6:.0f} MB of last-layer features for the tracker in both)"
+         if g('emulated_rank0_of_8_seam_local_ms') else "")
+      + f" (models: tracker after the decoders {g('implied_8gpu_speedup_tracker_after_decoders'):.1f}x, ideally beside them {g('implied_8gpu_speedup_tracker_beside_decoders'):.1f}x).\n<!--R4TABLE-END-->\n")
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
 i, j = s.index("<!--R4TABLE-BEGIN-->"), s.index("<!--R4TABLE-END-->") + len("<!--R4TABLE-END-->\n")
