@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
     const int li = lane & 15, kg = lane >> 4;
 
     // ---- workgroup -> output block: XCD x (workgroup b runs on XCD b % 8) owns a contiguous range of blocks in the order
-    //      (batch, h block, t block, w block fastest): the ~32 blocks an XCD runs at a time are a compact slab whose halos
+    //      (batch, h block, w block, t block fastest - below): the ~32 blocks an XCD runs at a time are a compact slab whose halos
     //      overlap in its L2 ----
     const int nbw = p.Wo / TW, nbh = p.Ho / TH, nbt = p.To / TT;
     const int ntiles = (p.M / BM);
@@ -82,21 +82,24 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const GemmParams p) {
         const int bid = (int)blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = ntiles >> 3, r = ntiles & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // order of the blocks: w fastest, then T, then h (round 3; was w, h, t): the ~32 blocks an XCD runs at a time then hold, for a
-    // strip of h, several CONSECUTIVE t blocks - the two halo planes a block shares with its t neighbours (half of its halo)
-    // are read by blocks that are resident at the same time instead of a whole (h x w) plane of blocks later
+    // order of the blocks: T fastest, then w, then h (round 6; round 3 had w, t, h).  The ~32 blocks an XCD runs at a time are then ALL
+    // t blocks of a few neighbouring w positions: the two halo planes a block shares with each t neighbour (half of its halo) and
+    // the halo columns it shares with its w neighbours are fetched into the XCD's L2 once.  Expected fetch per output plane:
+    // 18/16 (t) x ~1.03 (w) x 18/16 (h) = 1.30 against 1.6 for the w-fastest order, whose 32 resident blocks are 14 w positions
+    // x 2.3 t blocks (PMC, round 5: 1216 MB fetched per head-conv launch against 680 MB of operands).  -DCONV_HALO_ORDER_WTH: round 3's.
     int rem = tile;
+#ifdef CONV_HALO_ORDER_WTH
     const int bw = rem % nbw;
     rem /= nbw;
-#ifdef CONV_HALO_ORDER_WHT
-    const int bh = rem % nbh;
-    rem /= nbh;
-    const int bt = rem % nbt, bb = rem / nbt;
+    const int bt = rem % nbt;
+    rem /= nbt;
 #else
     const int bt = rem % nbt;
     rem /= nbt;
-    const int bh = rem % nbh, bb = rem / nbh;
+    const int bw = rem % nbw;
+    rem /= nbw;
 #endif
+    const int bh = rem % nbh, bb = rem / nbh;
     const int t0 = bt * TT, h0 = bh * TH, w0 = bw * TW;
 
     // ---- W staging: LDS slot s = pass * 512 + tid  ->  (LDS row s >> 2 = colblock * 64 + j * 16 + a, physical chunk s & 3) ----

@@ -26,6 +26,24 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, bool align, 
     lam = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
     i1 = i0 + (i0 < in - 1 ? 1 : 0);
 }
+// The same with the scale formed by the caller (ONCE, on the host: an IEEE single division there and here round alike) - the
+// per-thread division sequence was a sixth of the up-sampling kernel's vector instructions.
+__host__ __device__ __forceinline__ float src_scale(int in, int out, bool align) {
+    return align ? (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f) : (float)in / (float)out;
+}
+__device__ __forceinline__ void src_index_s(int dst, int in, float scale, bool align, int& i0, int& i1, float& lam) {
+    float src;
+    if (align) {
+        src = scale * (float)dst;
+    } else {
+        src = scale * ((float)dst + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+    }
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    lam = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+}
 
 // One workgroup row = one output (b, to, ho) line (blockIdx.y): its t / h source indices and weights are wave-uniform
 // scalars, and a thread only splits its x index into (wo, channel group) - the flat-index form spent five integer
@@ -36,18 +54,25 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, bool align, 
 // (the per-tap `if (weight == 0) continue` of the previous form kept every load behind a branch: one round trip each).
 template <typename T, bool NT_STORE, int NT, int NH>
 __device__ __forceinline__ void upsample_line(const T* __restrict__ xb, T* __restrict__ yl, int Hi, int Wi, int Wo, int C, int align,
-                                              int t0, int t1, float lt, int h0, int h1, float lh) {
+                                              int t0, int t1, float lt, int h0, int h1, float lh, float sw, int cv_shift) {
     constexpr int V = 8;  // channels per thread
     const int cv = C / V;
     const float wt[2] = {NT == 2 ? 1.f - lt : 1.f, lt}, wh[2] = {NH == 2 ? 1.f - lh : 1.f, lh};
     const int ti[2] = {t0, t1}, hi[2] = {h0, h1};
+    // the (t, h) source rows of the line: wave-uniform bases; a lane adds one 32-bit offset per w tap (a clip's input volume is far
+    // below 2 GB) - the 64-bit per-tap address arithmetic was another fifth of the kernel's vector instructions
+    const T* rowp[NT][NH];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int bb = 0; bb < NH; ++bb) rowp[a][bb] = xb + ((long long)ti[a] * Hi + hi[bb]) * Wi * C;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < Wo * cv; i += gridDim.x * 256) {
-        const int wo = i / cv, c = (i - wo * cv) * V;
+        const int wo = cv_shift >= 0 ? i >> cv_shift : i / cv, c = (i - wo * cv) * V;
         int w0, w1;
         float lw;
-        src_index(wo, Wi, Wo, align, w0, w1, lw);
+        src_index_s(wo, Wi, sw, align, w0, w1, lw);
         const float ww[2] = {1.f - lw, lw};
-        const int wi[2] = {w0, w1};
+        const unsigned wofs[2] = {(unsigned)(w0 * C + c), (unsigned)(w1 * C + c)};
         float v[NT][NH][2][V];
 #pragma unroll
         for (int a = 0; a < NT; ++a)
@@ -55,7 +80,7 @@ __device__ __forceinline__ void upsample_line(const T* __restrict__ xb, T* __res
             for (int bb = 0; bb < NH; ++bb)
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    const T* p = xb + (((long long)ti[a] * Hi + hi[bb]) * Wi + wi[cc]) * C + c;
+                    const T* p = rowp[a][bb] + wofs[cc];
                     if (sizeof(T) == 2) {
                         const vec8h<T> t = *(const vec8h<T>*)p;
 #pragma unroll
@@ -82,7 +107,7 @@ __device__ __forceinline__ void upsample_line(const T* __restrict__ xb, T* __res
 #pragma unroll
                     for (int k = 0; k < V; ++k) acc[k] += wgt * v[a][bb][cc][k];
                 }
-        T* yp = yl + (long long)wo * C + c;
+        T* yp = yl + (unsigned)(i * V);  // (wo * C + c == i * V)
         if (sizeof(T) == 2) {
             vec8h<T> o;
 #pragma unroll
@@ -100,27 +125,30 @@ __device__ __forceinline__ void upsample_line(const T* __restrict__ xb, T* __res
 
 template <typename T, bool NT = false>
 __global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Ti, int Hi, int Wi,
-                                                       int To, int Ho, int Wo, int C, int align) {
+                                                       int To, int Ho, int Wo, int C, int align, float st, float sh, float sw, int cv_shift) {
     const int line = blockIdx.y + blockIdx.z * 65535;  // (b * To + to) * Ho + ho
     if (line >= B * To * Ho) return;
     const int ho = line % Ho, to = (line / Ho) % To, b = line / (Ho * To);
     int t0, t1, h0, h1;
     float lt, lh;
-    src_index(to, Ti, To, align, t0, t1, lt);
-    src_index(ho, Hi, Ho, align, h0, h1, lh);
+    src_index_s(to, Ti, st, align, t0, t1, lt);
+    src_index_s(ho, Hi, sh, align, h0, h1, lh);
+    // (the same for every lane of the line, but formed by vector float instructions: made scalar so that the row bases below are)
+    t0 = __builtin_amdgcn_readfirstlane(t0), t1 = __builtin_amdgcn_readfirstlane(t1);
+    h0 = __builtin_amdgcn_readfirstlane(h0), h1 = __builtin_amdgcn_readfirstlane(h1);
     const T* xb = x + (long long)b * Ti * Hi * Wi * C;
     T* yl = y + (long long)line * Wo * C;
     // (a zero weight removes the tap exactly as the skipped term did: 0 * finite contributes nothing to the sum)
     if (lt == 0.f) {
         if (lh == 0.f)
-            upsample_line<T, NT, 1, 1>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh);
+            upsample_line<T, NT, 1, 1>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh, sw, cv_shift);
         else
-            upsample_line<T, NT, 1, 2>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh);
+            upsample_line<T, NT, 1, 2>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh, sw, cv_shift);
     } else {
         if (lh == 0.f)
-            upsample_line<T, NT, 2, 1>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh);
+            upsample_line<T, NT, 2, 1>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh, sw, cv_shift);
         else
-            upsample_line<T, NT, 2, 2>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh);
+            upsample_line<T, NT, 2, 2>(xb, yl, Hi, Wi, Wo, C, align, t0, t1, lt, h0, h1, lh, sw, cv_shift);
     }
 }
 
@@ -138,14 +166,24 @@ int launch_upsample(int dtype, const void* x, void* y, int B, int Ti, int Hi, in
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
     const dim3 grid(gx, lines < 65535 ? lines : 65535, (lines + 65534) / 65535);
     ProfScope prof(PROF_ELEMENTWISE, stream, "upsample");
+    if ((long long)Ti * Hi * Wi * C * esize_of(dtype) >= (1ll << 31) || (long long)Wo * C >= (1ll << 28)) {
+        l4p_set_error("upsample: a clip's input volume must stay below 2 GB (32-bit tap offsets)");
+        return L4P_E_INVALID;
+    }
+    const float st = src_scale(Ti, To, align != 0), sh = src_scale(Hi, Ho, align != 0), sw = src_scale(Wi, Wo, align != 0);
+    const int cvn = C / 8;
+    int cv_shift = -1;
+    if ((cvn & (cvn - 1)) == 0)
+        for (cv_shift = 0; (1 << cv_shift) < cvn; ++cv_shift) {
+        }
     static const int nt = getenv("L4P_UPS_NT") ? atoi(getenv("L4P_UPS_NT")) : 1;
     if (is16(dtype) && nt) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL((upsample_kernel<T16, true>), grid, dim3(256), 0, stream, (const T16*)x, (T16*)y, B, Ti,
-                           Hi, Wi, To, Ho, Wo, C, align));
+                           Hi, Wi, To, Ho, Wo, C, align, st, sh, sw, cv_shift));
     else if (is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(upsample_kernel<T16>, grid, dim3(256), 0, stream, (const T16*)x, (T16*)y, B, Ti,
-                           Hi, Wi, To, Ho, Wo, C, align));
+                           Hi, Wi, To, Ho, Wo, C, align, st, sh, sw, cv_shift));
     else
         hipLaunchKernelGGL(upsample_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)y, B, Ti, Hi,
-                           Wi, To, Ho, Wo, C, align);
+                           Wi, To, Ho, Wo, C, align, st, sh, sw, cv_shift);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -234,7 +234,8 @@ def test_attention_peaked_softmax(dev, mode, prescaled, S, B, H):
 @pytest.mark.parametrize("B,S,H,Dh", [(2, 2048, 16, 88),   # 256 tiles: one per workgroup, no tile seam
                                       (3, 2048, 16, 88),   # 384 tiles: workgroups with one and with two tiles
                                       (11, 1024, 6, 88),   # 264 tiles of 16 KV blocks, batch * heads = 66 not a multiple of 8 (plain tile order)
-                                      (4, 2048, 16, 64)])  # head dim 64: the constant pieces sit elsewhere in the tile
+                                      (4, 2048, 16, 64),   # head dim 64: the constant pieces sit elsewhere in the tile
+                                      (16, 256, 16, 88)])  # the shortest sequence the kernel takes: 4 KV blocks, every step is a first / last one
 def test_attention64_forms_and_the_8_wave_kernel(dev, knob, mode, B, S, H, Dh):
     """csrc/attention64.hip (one wave per SIMD, 64 query rows per wave; launches of >= 256 tiles of 256 rows) against fp32 softmax
     on the same rounded operands, in its tile-walk variants, and against the 8-wave kernel on the same inputs (knob attn64 = 0):
@@ -245,7 +246,7 @@ def test_attention64_forms_and_the_8_wave_kernel(dev, knob, mode, B, S, H, Dh):
     v4 = torch.randn(B, S, H, ops.DP, generator=g)
     for t in (q4, k4, v4):
         t[..., Dh:] = 0
-    k4[1, 700:708] *= 5.0  # a few dominant keys in one batch item: the rescale path runs in some waves and not in others
+    k4[1, S - 120:S - 112] *= 5.0  # a few dominant keys in one batch item: the rescale path runs in some waves and not in others
     q, kt, vt, qf, kf, vf = _attn_inputs(q4, k4, v4, mode)
     out = {}
     for v in (1, 0):
