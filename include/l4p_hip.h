@@ -74,6 +74,13 @@ int l4p_stream_destroy(l4p_stream stream);
  *                S % 256 == 0): one wave per SIMD with 64 query rows (csrc/attention64.hip: every K / V^T fragment read feeds two
  *                MFMAs); 0 = the 8-wave form with 32 rows per wave.  Equal to the rounding of P, not bit for bit (the rare rescale of
  *                the deferred maximum is decided per wave).
+ *   "gemm_skinny" (L4P_GEMM_SKINNY, default 1): l4p_gemm / l4p_gemm_group of the 16-bit engines on dense problems with M <= 64 rows and
+ *                K % 64 == 0 (the tracker's token-side projections of a rank's query shard) run one wave per 16 x 32 output block with
+ *                the operands streamed from global memory into MFMA fragment registers (csrc/gemm_skinny.hpp); bit-identical to the
+ *                LDS-staged kernels (0)
+ *   "readout_wide" (L4P_READOUT_WIDE, default 1): l4p_track_readout with at most 512 (track, frame) pairs runs 1024 threads per pair
+ *                (the samples of 32 rows formed by all threads, then summed per column in the order of the 256-thread kernel:
+ *                bit-identical; 58 -> ~20 us per launch on a rank's 8-track shard); 0 = the 256-thread kernel
  *   "probe_kernels" (read-only): 1 when the library was built with PROBES=1 and contains the measured-and-not-adopted kernels the knobs
  *                "gemm_4w" and "conv_ups" select; in the shipped build (0) those two knobs stay 0 and setting them is an error.
  * l4p_set_knob returns L4P_E_INVALID for an unknown name; l4p_get_knob returns the current value (or -1). */

@@ -7,4 +7,5 @@
 #include "gemm4w.hpp"
 #endif
 #include "conv3_halo.hpp"
+#include "gemm_skinny.hpp"
 #include "gemm_launch.inc"

@@ -25,6 +25,9 @@ const KnobDef kKnobs[KNOB_NUM] = {{"conv_halo", "L4P_CONV_HALO", 1}, {"gemm_4w",
                                    {"ln_tracks", "L4P_LN_TRACKS", 1},
                                    {"ln_rows16", "L4P_LN_ROWS16", 1},
                                    {"attn64", "L4P_ATTN64", 1},
+                                   {"gemm_skinny", "L4P_GEMM_SKINNY", 1},
+                                   {"readout_wide", "L4P_READOUT_WIDE", 1},
+                                   {"track_deep", "L4P_TRACK_DEEP", 1},
                                    {"probe_kernels", "", 0}};
 std::atomic<int> g_knob[KNOB_NUM];
 std::once_flag g_knob_once;

@@ -21,7 +21,7 @@ enum ProfClass {
 };
 
 // Dispatch knobs (l4p_set_knob / l4p_get_knob, include/l4p_hip.h): environment default read once, run-time setter for the tests.
-enum Knob { KNOB_CONV_HALO = 0, KNOB_GEMM_4W, KNOB_MASKDOT_MFMA, KNOB_CONV_UPS, KNOB_LN_TRACKS, KNOB_LN_ROWS16, KNOB_ATTN64, KNOB_PROBE_KERNELS, KNOB_NUM };
+enum Knob { KNOB_CONV_HALO = 0, KNOB_GEMM_4W, KNOB_MASKDOT_MFMA, KNOB_CONV_UPS, KNOB_LN_TRACKS, KNOB_LN_ROWS16, KNOB_ATTN64, KNOB_GEMM_SKINNY, KNOB_READOUT_WIDE, KNOB_TRACK_DEEP, KNOB_PROBE_KERNELS, KNOB_NUM };
 int knob(int id);
 
 void prof_begin(int cls, hipStream_t stream, const char* tag = nullptr);

@@ -177,6 +177,57 @@ __global__ __launch_bounds__(64) void self_attn6_kernel(const T* __restrict__ q,
     const int n = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     const long long base = (long long)n * 6 * D + (long long)h * hd;
     float s[6][6];
+    if (hd <= 192) {
+        // Head dims of up to three 64-lane chunks (the tracker: 176): all 54 operand elements of a lane are requested before the first
+        // product - the rolled form below re-read q / k per (i, j) pair, 36 x 2 dependent round trips per launch (27 us for 0.1 MFLOP).
+        // Same products, same order, same sums.
+        float qv[6][3], kv[6][3], vv[6][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int d = lane + 64 * c;
+            const bool ok = d < hd;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                qv[i][c] = ok ? (float)q[base + (long long)i * D + d] : 0.f;
+                kv[i][c] = ok ? (float)k[base + (long long)i * D + d] : 0.f;
+                vv[i][c] = ok ? (float)v[base + (long long)i * D + d] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (lane + 64 * c < hd) acc += qv[i][c] * kv[j][c];
+                s[i][j] = wave_sum(acc) * scale;
+            }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float m = s[i][0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) m = fmaxf(m, s[i][j]);
+            float z = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                s[i][j] = expf(s[i][j] - m);
+                z += s[i][j];
+            }
+            const float iz = 1.f / z;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int d = lane + 64 * c;
+                if (d < hd) {
+                    float o = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) o += s[i][j] * iz * vv[j][c];
+                    out[base + (long long)i * D + d] = from_f32<T>(o);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -666,6 +717,130 @@ __global__ __launch_bounds__(256) void track_readout_kernel(const float* __restr
     }
 }
 
+// The same read-out on a 1024-thread workgroup (W <= 256; knob "readout_wide").  In the kernel above a thread owns an output column and
+// walks its H rows: H x (bilinear sample + expf) serially per thread on 224 of 256 threads - 58 us per launch whatever the number of
+// tracks, one launch per window.  Here the samples exp(logit - max) of RB rows at a time are formed by ALL threads into LDS, and the
+// column threads then add them up in the SAME order (row after row: z, sum e x, sum e y per column, then the wave / workgroup sums of
+// the kernel above): the same values in the same sums, bit for bit.
+constexpr int READOUT_RB = 32;
+__global__ __launch_bounds__(1024) void track_readout_wide_kernel(const float* __restrict__ masks, float* __restrict__ traj,
+                                                                  float* __restrict__ vis, float* __restrict__ depth, int T,
+                                                                  int h, int w, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lo = (float*)smem;  // [3][h*w]
+    __shared__ float red[4][8];
+    const int n = blockIdx.x / T, t = blockIdx.x % T, tid = threadIdx.x;
+    const int hw = h * w;
+    float* wxs = lo + 3 * hw;        // [w]
+    float* wys = wxs + w;            // [h]
+    float* tlx = wys + h;            // [W] x interpolation weight
+    float* tly = tlx + W;            // [H]
+    int* tx0 = (int*)(tly + H);      // [W] x0 | x1 << 16
+    int* ty0 = tx0 + W;              // [H] y0 * w | (y1 * w) << 16
+    float* eb = (float*)(ty0 + H);   // [RB][W]
+    for (int i = tid; i < 3 * hw; i += 1024) {
+        const int m = i / hw, r = i % hw;
+        lo[i] = masks[(((long long)n * 3 + m) * T + t) * hw + r];
+    }
+    for (int i = tid; i < W + H; i += 1024) {
+        const bool isx = i < W;
+        const int d = isx ? i : i - W;
+        int i0, i1;
+        float lam;
+        src_idx_nc(d, isx ? w : h, isx ? W : H, i0, i1, lam);
+        if (isx) {
+            tlx[d] = lam;
+            tx0[d] = i0 | (i1 << 16);
+        } else {
+            tly[d] = lam;
+            ty0[d] = (i0 * w) | ((i1 * w) << 16);
+        }
+    }
+    __syncthreads();
+    auto lerp2 = [&](const float* b, int r0, int r1, int x0, int x1, float lx, float ly) -> float {
+        const float top = (1.f - lx) * b[r0 + x0] + lx * b[r0 + x1];
+        const float bot = (1.f - lx) * b[r1 + x0] + lx * b[r1 + x1];
+        return (1.f - ly) * top + ly * bot;
+    };
+    for (int i = tid; i < w + h; i += 1024) {
+        const bool isx = i < w;
+        const int idx = isx ? i : i - w, in = isx ? w : h, out = isx ? W : H;
+        float acc = 0.f;
+        for (int d = 0; d < out; ++d) {
+            int i0, i1;
+            float lam;
+            src_idx_nc(d, in, out, i0, i1, lam);
+            if (i0 == idx) acc += 1.f - lam;
+            if (i1 == idx) acc += lam;
+        }
+        (isx ? wxs : wys)[idx] = acc;
+    }
+    __syncthreads();
+    float mx = -INFINITY, s1 = 0.f, s2 = 0.f;
+    if (tid < 256) {  // (the partial sums of the 256-thread kernel: thread tid takes r = tid, tid + 256, ...)
+        for (int r = tid; r < hw; r += 256) {
+            const float wgt = wys[r / w] * wxs[r % w];
+            mx = fmaxf(mx, lo[r]);
+            s1 += lo[hw + r] * wgt;
+            s2 += lo[2 * hw + r] * wgt;
+        }
+        mx = wave_max(mx);
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if ((tid & 63) == 0) {
+            red[tid >> 6][0] = mx;
+            red[tid >> 6][1] = s1;
+            red[tid >> 6][2] = s2;
+        }
+    }
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    s1 = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    s2 = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    __syncthreads();
+    // pass 2: soft-argmax
+    float z = 0.f, sx = 0.f, sy = 0.f;
+    const float xc = (float)tid + 0.5f;
+    for (int yb = 0; yb < H; yb += READOUT_RB) {
+        const int rows = H - yb < READOUT_RB ? H - yb : READOUT_RB;
+        for (int i = tid; i < rows * W; i += 1024) {
+            const int yy = i / W, x = i - yy * W;
+            const int px = tx0[x], py = ty0[yb + yy];
+            eb[i] = expf(lerp2(lo, py & 0xFFFF, py >> 16, px & 0xFFFF, px >> 16, tlx[x], tly[yb + yy]) - mx);
+        }
+        __syncthreads();
+        if (tid < W) {
+            for (int yy = 0; yy < rows; ++yy) {
+                const float e = eb[yy * W + tid];
+                z += e;
+                sx += e * xc;
+                sy += e * ((float)(yb + yy) + 0.5f);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 256) {
+        z = wave_sum(z);
+        sx = wave_sum(sx);
+        sy = wave_sum(sy);
+        if ((tid & 63) == 0) {
+            red[tid >> 6][0] = z;
+            red[tid >> 6][1] = sx;
+            red[tid >> 6][2] = sy;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        z = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        sx = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        sy = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+        traj[((long long)n * 2 + 0) * T + t] = sx / z;
+        traj[((long long)n * 2 + 1) * T + t] = sy / z;
+        vis[(long long)n * T + t] = s1 / (float)(H * W);
+        depth[(long long)n * T + t] = expf(s2 / (float)(H * W));
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Sliding-window bookkeeping (forward_windowed_core, sparse_heads.py:303-335, :366-393, :455-486).
 // All integer / boolean decisions are made here, bit-for-bit as the reference's float comparisons.
@@ -983,12 +1158,15 @@ __device__ __forceinline__ vec8<T> tr_frag(const char* lo, int hi_off) {
     const s16x8_t r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return __builtin_bit_cast(vec8<T>, r);
 }
-template <typename T, int HT, int CW>
+// ST = 8 (six stages in flight): the launch of a rank's 8-track shard - 88 workgroups, each walking its 64 key steps alone on its CU -
+// is bound by the round trip of a stage, not by bandwidth (57 us at ST = 4, 0.9 us per step).  Same sums in the same order.
+template <typename T, int HT, int CW, int ST = 4>
 __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__ probs, const T* __restrict__ keys,
                                                            T* __restrict__ ctx, const float* __restrict__ stats, int P, int C, int heads,
                                                            int tokens, long long Rg) {
     static_assert(HT == 48, "t2i_scales");
-    constexpr int KT = 32, ST = 4, MT = HT / 16, NTW = CW / 64;  // NTW: 16-column tiles per wave
+    static_assert(ST == 4 || ST == 8, "ring depth");
+    constexpr int KT = 32, MT = HT / 16, NTW = CW / 64;  // NTW: 16-column tiles per wave
     constexpr int SPK = T2I_SPLIT / KT;                          // key steps per softmax split
     constexpr int KB = KT * CW * 2, PB = KT * HT * 2, SB = KB + PB;
     constexpr int KP = KB / 4096;  // 1 KB pieces of the key stage per wave
@@ -1024,23 +1202,32 @@ __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[m][j] = tot[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    issue(0);
-    issue(1);
-    issue(2);
+    constexpr int AH = ST - 2;  // stages in flight behind the one being read
+#pragma unroll
+    for (int s = 0; s <= AH; ++s)
+        if (s < ns) issue(s);
     t2i_scales(stats, n, (P + T2I_SPLIT - 1) / T2I_SPLIT, scale);
     for (int s = 0; s < ns; ++s) {
-        const int ahead = ns - 1 - s < 2 ? ns - 1 - s : 2;
-        if (ahead == 2)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (KP + 1)) : "memory");
-        else if (ahead == 1)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KP + 1) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ahead = ns - 1 - s < AH ? ns - 1 - s : AH;
+        switch (ahead) {  // (AH == 2: cases 3 .. 6 are never taken)
+            case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (KP + 1)) : "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (KP + 1)) : "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (KP + 1)) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (KP + 1)) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (KP + 1)) : "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KP + 1) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(defined(CTX_ABL) && CTX_ABL == 3)  // (CTX_ABL: timing ablations of tools/probes/ctx_ablate.sh, wrong results)
         __builtin_amdgcn_s_barrier();
-        if (s + 3 < ns) issue(s + 3);
+#endif
+#if !(defined(CTX_ABL) && CTX_ABL == 2)
+        if (s + AH + 1 < ns) issue(s + AH + 1);
+#endif
         const char* base = smem + (s & (ST - 1)) * SB;
         vec8<T> fa[MT], fb[NTW];
+#if !(defined(CTX_ABL) && CTX_ABL == 1)
 #pragma unroll
         for (int m = 0; m < MT; ++m) fa[m] = tr_frag<T>(base + a_off + m * 32, 4 * HT * 2);
 #pragma unroll
@@ -1049,6 +1236,7 @@ __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) acc[m][j] = mma16(fa[m], fb[j], acc[m][j]);
+#endif
         if ((s % SPK) == SPK - 1 || s == ns - 1) {  // end of a softmax split: its sum joins the total with the split's weight
             const float* sc = scale + (s / SPK) * HT + 4 * g;
 #pragma unroll
@@ -1219,7 +1407,14 @@ int launch_t2i_context(int dtype, const void* probs, const float* stats, const v
     // (a batched GEMM: N x [HT x P] x [P x C]; profiled with the small / streaming products: the FLOP model's executed-shapes check sees it)
     ProfScope prof(PROF_GEMM_SMALL, stream, "M%d N%d K%d epi0 act0 ctx t48x%d", N * heads * tokens, C, P, C % 128 ? 64 : 128);
     if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
-        if (C % 128 == 0) {
+        if (C % 128 == 0 && (C / 128) * N <= 256 && knob(KNOB_TRACK_DEEP)) {  // at most one workgroup per CU: the deep ring
+            constexpr int lds = 8 * (32 * 128 * 2 + 32 * 48 * 2);
+            auto kern = t2i_ctx_mfma_kernel<T16, 48, 128, 8>;
+            static lds_attr_state attr_deep;
+            HIP_TRY(lds_attr_once(attr_deep, kern, lds));
+            hipLaunchKernelGGL(kern, dim3(C / 128, N), dim3(256), lds, stream, (const T16*)probs, (const T16*)keys, (T16*)ctx, stats, P, C,
+                               heads, tokens, Rg);
+        } else if (C % 128 == 0) {
             constexpr int lds = 4 * (32 * 128 * 2 + 32 * 48 * 2);
             hipLaunchKernelGGL((t2i_ctx_mfma_kernel<T16, 48, 128>), dim3(C / 128, N), dim3(256), lds, stream, (const T16*)probs,
                                (const T16*)keys, (T16*)ctx, stats, P, C, heads, tokens, Rg);
@@ -1476,6 +1671,17 @@ int launch_mask_gather(const float* partial, float* masks, int N, int T, int h, 
 
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
                          int W, hipStream_t stream) {
+    // the 1024-thread form: few (track, frame) workgroups - a rank's query shard of the sharded long video - leave most of the chip idle
+    // and the launch is one workgroup's serial walk; with many tracks the 256-thread form fills the chip just as well
+    const size_t lds_wide = ((size_t)3 * h * w + w + h + 2 * (W + H) + (size_t)READOUT_RB * W) * 4;
+    if (knob(KNOB_READOUT_WIDE) && W <= 256 && h * w < 65536 && N * T <= 512 && lds_wide <= 160 * 1024) {
+        static lds_attr_state attr_wide;
+        HIP_TRY(lds_attr_once(attr_wide, track_readout_wide_kernel, (int)lds_wide));
+        ProfScope prof(PROF_TRACK, stream, "track_readout wide");
+        hipLaunchKernelGGL(track_readout_wide_kernel, dim3(N * T), dim3(1024), lds_wide, stream, masks, traj, vis, depth, T, h, w, H, W);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const size_t lds = ((size_t)3 * h * w + w + h) * 4;
     static lds_attr_state attr_done;
     HIP_TRY(lds_attr_once(attr_done, track_readout_kernel, (int)lds));

@@ -43,6 +43,13 @@ def test_hot_kernels_do_not_spill():
     for k in hot:
         assert gemm[k]["ScratchSize [bytes/lane]"] == 0, (k, gemm[k])
         assert gemm[k]["VGPRs"] <= 256
+    # the one-wave kernel of the tracker's token-side projections: an 18-step ring of fragments (216 registers) that must not spill, and
+    # whose descriptor patches (row-grouped weights, the grouped launch's run-time descriptor choice) must stay in scalar registers
+    sk = [k for k in gemm if "gemm_skinny" in k]
+    assert len(sk) == 3, sorted(gemm)
+    for k in sk:
+        assert gemm[k]["ScratchSize [bytes/lane]"] == 0, (k, gemm[k])
+        assert gemm[k]["VGPRs"] <= 256
     attn = _usage("attention.hip")
     hot = [k for k in attn if "DF16b" in k]
     assert hot

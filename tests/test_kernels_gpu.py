@@ -474,6 +474,193 @@ def test_gemm_group_equals_separate_launches(dev):
     assert bool(torch.isfinite(ob.float()).all()) and float(ob.float().abs().max()) > 0
 
 
+@pytest.mark.parametrize("mode", [L4P_BF16, L4P_F16])
+def test_gemm_skinny_equals_the_staged_kernels_bitwise(dev, knob, mode):
+    """gemm_skinny.hpp (M <= 64 rows: one wave per 16 x 32 output block, operands streamed into fragment registers with hand-counted
+    waits) against the LDS-staged kernels it replaces for the tracker's token-side projections: bit for bit - same MFMA, same k
+    order, same epilogue - over the three unrolled contraction lengths and the generic loop, ragged M and N, bias / ReLU / GELU /
+    float residual / both outputs, a strided A (the hyper-network's token rows), and a grouped launch; and against fp32."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+    from l4p_amd._lib import EPI_DENSE, GemmDesc
+    from tests.test_gemm8p_gpu import prof_tags
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    dt = ops.torch_dtype(mode)
+
+    def run(M, N, K, act, res, both, seed, lda=None, skinny=1, want_skinny=True):
+        knob("gemm_skinny", skinny)
+        lda = lda or K
+        a = as_mode(rnd((M, lda), seed), mode)[0]
+        w = ops.pad_rows(as_mode(rnd((N, K), seed + 1, K ** -0.5), mode)[0], 128)
+        bias = rnd((N,), seed + 2).cuda()
+        r = rnd((M, N), seed + 3).cuda() if res else None
+        oT = torch.zeros(M, N, dtype=dt, device="cuda")
+        of = torch.zeros(M, N, dtype=torch.float32, device="cuda") if (both or res) else None
+        d = GemmDesc()
+        d.A, d.lda, d.W, d.ldw = a.data_ptr(), lda, w.data_ptr(), K
+        d.M, d.N, d.K = M, N, K
+        d.bias, d.act, d.epi = bias.data_ptr(), act, EPI_DENSE
+        if res:
+            d.res1, d.res_f32, d.ldr = r.data_ptr(), 1, N
+        d.out_T, d.ldc = oT.data_ptr(), N
+        if of is not None:
+            d.out_f32 = of.data_ptr()
+        with prof_tags() as p:
+            _lib.check(lib.l4p_gemm(st, mode, C.byref(d)), "l4p_gemm")
+        tags = [ln[1] for ln in p.lines if ln[0] in ("gemm", "gemm_small")]
+        assert len(tags) == 1 and tags[0].endswith("skinny") == bool(skinny and want_skinny), (tags, skinny)
+        ref = a.float().cpu()[:, :K] @ w[:N].float().cpu().t() + bias.cpu()
+        if act == ACT_RELU:
+            ref = ref.clamp_min(0)
+        elif act == ACT_GELU:
+            ref = F.gelu(ref)
+        if res:
+            ref = ref + r.cpu()
+        return oT, of, ref
+
+    cases = [(48, 1408, 1408, ACT_NONE, True, False), (48, 704, 1408, ACT_NONE, False, False), (48, 2048, 1408, ACT_RELU, False, False),
+             (48, 1408, 2048, ACT_NONE, True, True), (48, 1408, 704, ACT_NONE, True, False), (48, 4096, 704, ACT_NONE, False, False),
+             (8, 1408, 1408, ACT_RELU, False, False), (8, 176, 1408, ACT_NONE, False, True), (48, 8, 704, ACT_NONE, False, True),
+             (5, 40, 128, ACT_GELU, False, True), (64, 1408, 1344, ACT_NONE, True, False), (33, 200, 2816, ACT_RELU, False, False),
+             (17, 96, 64, ACT_NONE, False, True)]
+    for i, (M, N, K, act, res, both) in enumerate(cases):
+        yT, yf, ref = run(M, N, K, act, res, both, 700 + 10 * i, skinny=1)
+        zT, zf, _ = run(M, N, K, act, res, both, 700 + 10 * i, skinny=0)
+        assert torch.equal(yT, zT), (M, N, K, act, res)
+        if yf is not None:
+            assert torch.equal(yf, zf), (M, N, K, act, res)
+            check(yf, ref, mode, False)
+        check(yT, ref, mode, True)
+    # more than 512 output blocks (the folded key products, N = 11264): the staged kernel - every row block would stream the weights again
+    run(48, 11264, 704, ACT_NONE, False, False, 880, skinny=1, want_skinny=False)
+    # strided A: token 2 of a [8, 6, K] block (the hyper-network MLP's input rows)
+    yT, _, ref = run(8, 1408, 1408, ACT_RELU, False, False, 900, lda=6 * 1408, skinny=1)
+    zT, _, _ = run(8, 1408, 1408, ACT_RELU, False, False, 900, lda=6 * 1408, skinny=0)
+    assert torch.equal(yT, zT)
+    check(yT, ref, mode, True)
+    # grouped launch of three skinny problems (self-attention q / k / v of 8 tracks) == three staged launches
+    K = 1408
+    xs = [as_mode(rnd((48, K), 950 + i), mode)[0] for i in range(2)]
+    ws = [ops.pad_rows(as_mode(rnd((n, K), 960 + i, K ** -0.5), mode)[0], 128) for i, n in enumerate((1408, 1408, 704))]
+    bs = [rnd((n,), 970 + i).cuda() for i, n in enumerate((1408, 1408, 704))]
+
+    def group(skinny, grouped):
+        knob("gemm_skinny", skinny)
+        outs = [torch.zeros(48, n, dtype=dt, device="cuda") for n in (1408, 1408, 704)]
+        ds = (GemmDesc * 3)()
+        for i, (a, n) in enumerate(((xs[0], 1408), (xs[0], 1408), (xs[1], 704))):
+            d = ds[i]
+            d.A, d.lda, d.W, d.ldw = a.data_ptr(), K, ws[i].data_ptr(), K
+            d.M, d.N, d.K = 48, n, K
+            d.bias, d.act, d.epi = bs[i].data_ptr(), ACT_NONE, EPI_DENSE
+            d.out_T, d.ldc = outs[i].data_ptr(), n
+        with prof_tags() as p:
+            if grouped:
+                _lib.check(lib.l4p_gemm_group(st, mode, ds, 3), "l4p_gemm_group")
+            else:
+                for i in range(3):
+                    _lib.check(lib.l4p_gemm(st, mode, C.byref(ds[i])), "l4p_gemm")
+        tags = [ln[1] for ln in p.lines if ln[0] in ("gemm", "gemm_small")]
+        return outs, tags
+
+    a, ta = group(1, True)
+    b, tb = group(0, False)
+    assert len(ta) == 1 and ta[0].startswith("group of 3") and ta[0].endswith("skinny"), ta
+    assert len(tb) == 2 and not any(t.endswith("skinny") for t in tb), tb  # (the table is keyed by tag: two of the three share one)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("N,D,heads", [(8, 1408, 8), (3, 128, 2), (2, 2048, 8)])
+def test_small_attn_kind0_vs_torch(dev, mode, N, D, heads):
+    """l4p_small_attn kind 0 (sam/transformer.py:223-245 on the 6 prompt tokens of each track) against torch in fp32: the form with
+    all of a lane's operands requested up front (head dims up to 192: the tracker's 176) and the rolled form (256)."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+
+    q, qr = as_mode(rnd((N, 6, D), 1200), mode)
+    k, kr = as_mode(rnd((N, 6, D), 1201), mode)
+    v, vr = as_mode(rnd((N, 6, D), 1202), mode)
+    out = torch.empty_like(q)
+    _lib.check(_lib.load().l4p_small_attn(torch.cuda.current_stream().cuda_stream, mode, 0, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                          out.data_ptr(), N, 6, D, heads), "l4p_small_attn")
+    torch.cuda.synchronize()
+    hd = D // heads
+    sp = lambda t: t.reshape(N, 6, heads, hd).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(qr), sp(kr), sp(vr)).transpose(1, 2).reshape(N, 6, D)
+    check(out, ref, mode, True)
+
+
+def test_track_readout_wide_equals_the_column_kernel_bitwise(dev, knob):
+    """l4p_track_readout (sparse_heads.py:572-589,645-647): the 1024-thread form (knob readout_wide: samples of 32 rows formed by all
+    threads, summed per column in the original order) == the 256-thread column kernel bit for bit, and both against torch
+    (trilinear resize, soft-argmax over pixel centres, spatial means)."""
+    from l4p_amd import _lib
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    N, T, h, w, H, W = 8, 16, 56, 56, 224, 224
+    masks = (rnd((N, 3, T, h, w), 1300) * 3).cuda()
+    outs = {}
+    for wide in (1, 0):
+        knob("readout_wide", wide)
+        traj = torch.zeros(N, 2, T, device="cuda")
+        vis = torch.zeros(N, T, device="cuda")
+        dep = torch.zeros(N, T, device="cuda")
+        _lib.check(lib.l4p_track_readout(st, masks.data_ptr(), traj.data_ptr(), vis.data_ptr(), dep.data_ptr(), N, T, h, w, H, W),
+                   "l4p_track_readout")
+        torch.cuda.synchronize()
+        outs[wide] = (traj, vis, dep)
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.equal(a, b)
+    up = F.interpolate(masks.cpu().double(), size=(T, H, W), mode="trilinear", align_corners=False)
+    p = torch.softmax(up[:, 0].reshape(N, T, H * W), dim=-1).reshape(N, T, H, W)
+    xs = torch.arange(W, dtype=torch.float64) + 0.5
+    ys = torch.arange(H, dtype=torch.float64) + 0.5
+    ref_traj = torch.stack([(p.sum(2) * xs).sum(-1), (p.sum(3) * ys).sum(-1)], dim=1)
+    traj, vis, dep = (t.double().cpu() for t in outs[1])
+    assert (traj - ref_traj).abs().max() <= 1e-3
+    assert (vis - up[:, 1].mean((-1, -2))).abs().max() <= 1e-5
+    assert ((dep - up[:, 2].mean((-1, -2)).exp()).abs() / dep.abs()).max() <= 1e-5
+
+
+@pytest.mark.parametrize("mode", [L4P_BF16, L4P_F16])
+def test_row_grouped_scores_deep_ring_equals_two_stages_bitwise(dev, knob, mode):
+    """The folded score product of a few tracks (rows [g P, (g + 1) P) of the keys against track g's 48 folded rows: l4p_gemm_desc.w_gr;
+    sam/transformer.py:223-245 with the projections folded, packing.py) leaves CUs idle: the four-stage form of the row-grouped
+    kernel (knob track_deep) == the two-stage one bit for bit, and both against fp32."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+    from l4p_amd._lib import EPI_DENSE, GemmDesc
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    G, P, HT, K = 3, 2048, 48, 1408
+    a, ar = as_mode(rnd((G * P, K), 1400), mode)
+    w, wr = as_mode(rnd((G * HT + 128, K), 1401, K ** -0.5), mode)
+    outs = []
+    for deep in (1, 0):
+        knob("track_deep", deep)
+        o = torch.zeros(G * P, HT, device="cuda")
+        d = GemmDesc()
+        d.A, d.lda, d.W, d.ldw = a.data_ptr(), K, w.data_ptr(), K
+        d.M, d.N, d.K = G * P, HT, K
+        d.out_f32, d.ldc, d.epi = o.data_ptr(), HT, EPI_DENSE
+        d.w_gr, d.w_gs, d.b_gs = P, HT * K, 0
+        _lib.check(lib.l4p_gemm(st, mode, C.byref(d)), "l4p_gemm(w_gr)")
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.cat([ar[g * P:(g + 1) * P] @ wr[g * HT:(g + 1) * HT].t() for g in range(G)])
+    check(outs[0], ref, mode, False)
+
+
 def test_cu_masked_stream_runs_kernels(dev):
     """l4p_stream_create_cu_mask (plumbing of the sharded long-video path, parallel.cu_masked_stream): a stream confined to 32 CUs
     runs the engine's kernels with the same result as the default stream, and can be released."""

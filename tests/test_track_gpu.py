@@ -626,7 +626,7 @@ def test_i2t_delta_kernel_equals_grouped_gemm(dev, P, Cc):
 
 @pytest.mark.parametrize("precision", ["32-true", "bf16", "16-mixed"])
 @pytest.mark.parametrize("Cc", [1408, 704, 256])
-def test_folded_t2i_value_kernels(dev, precision, Cc):
+def test_folded_t2i_value_kernels(dev, precision, Cc, knob):
     """The token -> image attention with the VALUE projection folded away (l4p_t2i_probs, l4p_t2i_context, the per-head projection as a
     row-grouped-weights GEMM whose groups write their own column blocks: l4p_gemm_desc.o_gs) against plain torch on the same rounded
     operands: softmax over the keys, P.V of the PROJECTED values (sam/transformer.py:223-245).  1408 and 256 columns take the 128-wide MFMA
@@ -699,6 +699,20 @@ def test_folded_t2i_value_kernels(dev, precision, Cc):
     torch.cuda.synchronize()
     err = float((ta[:N * tokens].float().cpu() - oref).abs().max()) / float(oref.abs().max())
     assert err <= (2e-2 if precision != "32-true" else 1e-5), err
+    if precision == "32-true":
+        return
+    # the forms for launches that leave CUs idle (a rank's query shard: the context kernel's eight-stage ring, knob track_deep; the head
+    # groups' projection on one wave per 16 x 32 block, knob gemm_skinny) == the chip-filling forms, bit for bit
+    knob("track_deep", 0)
+    knob("gemm_skinny", 0)
+    cx2 = torch.full((heads * Rg, Cc), float("nan"), dtype=td, device="cuda")
+    _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(st), _p(keys), _p(cx2), N, P, Cc, heads, tokens, Rg), "l4p_t2i_context")
+    ta2 = torch.empty(Rg, Dh, dtype=td, device="cuda")
+    d.out_T = _p(ta2)
+    _lib.check(lib.l4p_gemm(_stream(), dt, C.byref(d)), "l4p_gemm(head groups, o_gs)")
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(cx2, nan=0.0), cx)
+    assert torch.equal(ta2[:N * tokens], ta[:N * tokens])
 
 
 def test_folded_i2t_equals_projected_form(dev, mini, monkeypatch):
