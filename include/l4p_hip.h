@@ -433,7 +433,9 @@ int l4p_transpose_pad(l4p_stream stream, int dtype, const void* in_T, void* out_
  * l4p_t2i_context: ctx T [(h * Rg + n * tokens + t)][C] = sum_p softmax_p[n][p][t * heads + h] * keys[n][p][C] (keys T [N][P][C] WITHOUT
  *   the positional term; rows grouped by head with Rg >= N * tokens rows per group, a multiple of 128, rows past N * tokens untouched):
  *   the A operand of the row-grouped-weights GEMM against the head blocks of W_v (w_gr = Rg, w_gs = hd * C, b_gs = o_gs = hd, c_gr = Rg).
- *   heads * tokens == 48, C % 64 == 0, P % 32 == 0, 96 <= P <= 4096.  bf16: MFMA kernel bound by one read of the keys. */
+ *   heads * tokens == 48, C % 64 == 0, P % 32 == 0, 96 <= P <= 4096.  bf16: MFMA kernel bound by one read of the keys.
+ *   shared_from (a multiple of 32; >= P: none): key rows p >= shared_from of EVERY track are read from track 0's block - later windows of
+ *   the recursion, layer 0: the second temporal half of every track's keys is still the same (l4p_track_keys_init(shared_from)). */
 /* delta = P x V' + b of the folded image -> token attention as a streaming kernel (bf16, K == 64, C % 128 == 0, P % 16 == 0): probs T
  * [N][P][64] (l4p_i2t_probs), vt T [N][C][64] (l4p_transpose_pad), bias float [C] or NULL -> delta T [N][P][C].  Bit-identical to
  * l4p_gemm with w_gr = P, w_gs = C * 64 on the same operands, which serves every other shape / dtype. */
@@ -441,7 +443,7 @@ int l4p_i2t_delta(l4p_stream stream, int dtype, const void* probs_T, const void*
                   int K);
 int l4p_t2i_probs(l4p_stream stream, int dtype, const float* scores, long long ld_scores, void* probs_T, float* stats, int N, int P, int HT);
 int l4p_t2i_context(l4p_stream stream, int dtype, const void* probs_T, const float* stats, const void* keys_T, void* ctx_T, int N, int P,
-                    int C, int heads, int tokens, long long Rg);
+                    int C, int heads, int tokens, long long Rg, int shared_from);
 
 /* Fused read-out (sparse_heads.py:572-589,645-647): trilinear (align_corners=False) resize of masks
  * [N][3][T][h][w] to H x W, soft-argmax of channel 0 (traj [N][2][T]), spatial mean of channel 1
@@ -519,7 +521,12 @@ int l4p_dpt_forward(l4p_engine* e, l4p_stream stream, const char* task, const l4
  * first window / the plain single-window forward), only its first P rows are read; hist_uniform == 2: rows [P/2, P) of every
  * track's history are identical (the state need_history leaves behind: the learned mask token), so the layer-0 projections
  * of those rows are computed once and copied (l4p_broadcast_block) — same values, half the key-side projection work of
- * layer 0; q_off float [N][3] (t, x, y) relative
+ * layer 0; hist_uniform == 2 or 4 name a LATER window of a recursion (4: without the half-sharing of 2, every track on its own rows -
+ * the equality check of that shortcut): layer 0's token -> image attention then takes the folded form of the later layers
+ * (packing.py fold_t2i: scores against the folded prompt tokens, softmax x keys on the matrix pipe, the head blocks of W_v on the 48
+ * context rows) instead of projecting N x P key rows twice and attending per (track, head) - L4P_TRACK_FOLD_L0=0: the projected
+ * form; hist_uniform == 0 (a window evaluated out of context) keeps the projected form, bit-identical to the first window's shortcut;
+ * q_off float [N][3] (t, x, y) relative
  * to the window; labels, plabel float [N]; pfeat float [N][C].  Outputs: traj float [N][2][T], vis, depth float [N][T],
  * new_pfeat float [N][C].  Weights "trk.*" must have been bound with l4p_bind_weight. */
 typedef struct l4p_track_cfg {

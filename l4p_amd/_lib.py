@@ -135,7 +135,7 @@ SIGNATURES = {
     "l4p_transpose_pad": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I]),
     "l4p_i2t_delta": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I]),
     "l4p_t2i_probs": (_I, [_VP, _I, _VP, _LL, _VP, _VP, _I, _I, _I]),
-    "l4p_t2i_context": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _LL]),
+    "l4p_t2i_context": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _LL, _I]),
     "l4p_layernorm_t": (_I, [_VP, _I, _VP, _VP, _VP, C.c_float, _VP, _I, _I, _I]),
     "l4p_pil_coeffs": (_I, [_I, _I, _VP, _VP, _I, C.POINTER(_I)]),
     "l4p_pil_resample_u8": (_I, [_VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _VP, _VP, _I]),

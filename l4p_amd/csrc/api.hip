@@ -29,7 +29,7 @@ int launch_layernorm_res(int dtype, const float* x, int x_mod, const void* delta
 extern "C" {
 
 const char* l4p_last_error(void) { return g_err; }
-int l4p_abi_version(void) { return 9; }
+int l4p_abi_version(void) { return 10; }
 
 // A HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (hipExtStreamCreateWithCUMask): the sharded long-video path
 // gives the tracker's latency-bound kernel chain a slice of the chip of its own, beside the chip-filling decoders on the rest.

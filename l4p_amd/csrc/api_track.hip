@@ -35,7 +35,7 @@ int launch_i2t_delta(int dtype, const void* probs, const void* vt, const float* 
                      hipStream_t stream);
 int launch_t2i_probs(int dtype, const float* scores, long long ld_scores, void* probs, float* stats, int N, int P, int HT, hipStream_t stream);
 int launch_t2i_context(int dtype, const void* probs, const float* stats, const void* keys, void* ctx, int N, int P, int C, int heads,
-                       int tokens, long long Rg, hipStream_t stream);
+                       int tokens, long long Rg, int shared_from, hipStream_t stream);
 int launch_mask_product(int dtype, const void* up, const float* hyper, float* masks, int N, long long vox, int Cc,
                         hipStream_t stream);
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
@@ -116,8 +116,8 @@ int l4p_t2i_probs(l4p_stream s, int dtype, const float* scores, long long ld_sco
     return launch_t2i_probs(dtype, scores, ld_scores, probs_T, stats, N, P, HT, (hipStream_t)s);
 }
 int l4p_t2i_context(l4p_stream s, int dtype, const void* probs_T, const float* stats, const void* keys_T, void* ctx_T, int N, int P, int C,
-                    int heads, int tokens, long long Rg) {
-    return launch_t2i_context(dtype, probs_T, stats, keys_T, ctx_T, N, P, C, heads, tokens, Rg, (hipStream_t)s);
+                    int heads, int tokens, long long Rg, int shared_from) {
+    return launch_t2i_context(dtype, probs_T, stats, keys_T, ctx_T, N, P, C, heads, tokens, Rg, shared_from, (hipStream_t)s);
 }
 int l4p_mask_gather(l4p_stream s, const float* partial, float* masks, int N, int T, int h, int w, int chunks_per_tap) {
     return launch_mask_gather(partial, masks, N, T, h, w, chunks_per_tap, (hipStream_t)s);

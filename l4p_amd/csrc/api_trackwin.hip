@@ -48,7 +48,7 @@ int launch_i2t_delta(int dtype, const void* probs, const void* vt, const float* 
                      hipStream_t stream);
 int launch_t2i_probs(int dtype, const float* scores, long long ld_scores, void* probs, float* stats, int N, int P, int HT, hipStream_t stream);
 int launch_t2i_context(int dtype, const void* probs, const float* stats, const void* keys, void* ctx, int N, int P, int C, int heads,
-                       int tokens, long long Rg, hipStream_t stream);
+                       int tokens, long long Rg, int shared_from, hipStream_t stream);
 int launch_track_readout(const float* masks, float* traj, float* vis, float* depth, int N, int T, int h, int w, int H,
                          int W, hipStream_t stream);
 
@@ -169,7 +169,13 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
     const long long NP = (long long)N * P;
     // hist_uniform == 2: rows [P/2, P) of every track's keys are the same until the first image -> token update
     const bool half_shared = hist_uniform == 2 && N > 1 && P % 2 == 0;
-    if (hist_uniform == 2) hist_uniform = 0;
+    // hist_uniform == 2 / 4: a later window of a recursion - layer 0's token -> image attention in the folded form of the later layers
+    // (the per-(track, head) attention kernel on projected keys / values is 120 us per window whatever the number of tracks, and the two
+    // projections of N x P key rows go with it: 8 tracks 240 -> 110 us).  A window evaluated out of context (0) keeps the projected
+    // form, which the first window's shared-key shortcut equals bit for bit.  L4P_TRACK_FOLD_L0=0: A/B aid.
+    static const bool fold_l0_env = !(getenv("L4P_TRACK_FOLD_L0") && atoi(getenv("L4P_TRACK_FOLD_L0")) == 0);
+    const bool fold_l0 = fold_l0_env && (hist_uniform == 2 || hist_uniform == 4);
+    if (hist_uniform == 2 || hist_uniform == 4) hist_uniform = 0;
     // projection of per-track keys x [N*P][Cc] whose second temporal half is common to all tracks: the first halves of all
     // tracks (row-mapped GEMM over N * P/2 rows), track 0's second half, and a copy of that block to the other tracks
     auto proj_half_shared = [&](const void* x, const std::string& wk, int n) -> void* {
@@ -244,7 +250,9 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
     static const bool fold_v_env = !(getenv("L4P_TRACK_FOLD_T2I_V") && atoi(getenv("L4P_TRACK_FOLD_T2I_V")) == 0);
     const bool fold_v = fold_t2i_ok && fold_v_env && HTk == 48 && Cc % 128 == 0 && (Dh / g.sam_heads) % 8 == 0 && P % 32 == 0 && P >= 96 && P <= 4096;
     const long long RgT = (6ll * N + 127) / 128 * 128;  // rows of a head group of the context (and of `ta`, whose rows past 6 N are scratch)
-    auto t2i_folded = [&](const void* tq, const std::string& prefix, const void* keysP, const void* keysT, void* ta) {
+    // hs: rows [P/2, P) of keysP / keysT exist for track 0 only (a later window's layer 0): the scores of the two halves are two
+    // row-mapped launches, the context product reads those rows from track 0, the projected values (fold_v off) are formed once and copied
+    auto t2i_folded = [&](const void* tq, const std::string& prefix, const void* keysP, const void* keysT, void* ta, bool hs) {
         const long long KW = (long long)g.sam_heads * Cc;
         void* qf = c.T((long long)N * HTk + 128, Cc);  // Q' [N][HT][C] (+ slack rows under the last tile)
         c.gemm(tq, 6ll * N, Dh, Dh, prefix + ".kfold", (int)KW, false, ACT_NONE, nullptr, 0, nullptr, qf, KW);
@@ -255,7 +263,16 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
             p.A = keysP, p.lda = Cc, p.W = qf, p.ldw = Cc, p.M = (int)NP, p.N = HTk, p.K = Cc;
             p.out_f32 = sc, p.ldc = HTk, p.epi = EPI_DENSE;
             p.w_gr = P, p.w_gs = (long long)HTk * Cc, p.b_gs = 0;
-            c.rc = launch_gemm(c.dt, 0, p, c.st);
+            if (hs) {
+                const int half = P / 2;
+                p.M = N * half, p.w_gr = half;
+                p.a_gr = half, p.a_gs = P, p.a_go = 0, p.c_gr = half, p.c_gs = P, p.c_go = 0;  // first halves: every track's own
+                c.rc = launch_gemm(c.dt, 0, p, c.st);
+                p.a_gs = 0, p.a_go = half, p.c_go = half;                                      // second halves: track 0's rows
+                if (!c.rc) c.rc = launch_gemm(c.dt, 0, p, c.st);
+            } else {
+                c.rc = launch_gemm(c.dt, 0, p, c.st);
+            }
         }
         if (fold_v) {
             const int hd = Dh / g.sam_heads;
@@ -265,7 +282,7 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
             void* cx = c.T((long long)g.sam_heads * RgT, Cc);
             float* stt = c.f32((long long)N * ((P + 255) / 256), 2 * HTk);  // per 256-key split: column maxima, sums
             if (!c.rc && !c.dry) c.rc = launch_t2i_probs(c.dt, sc, HTk, pr, stt, N, P, HTk, c.st);
-            if (!c.rc && !c.dry) c.rc = launch_t2i_context(c.dt, pr, stt, keysT, cx, N, P, Cc, g.sam_heads, 6, RgT, c.st);
+            if (!c.rc && !c.dry) c.rc = launch_t2i_context(c.dt, pr, stt, keysT, cx, N, P, Cc, g.sam_heads, 6, RgT, hs ? P / 2 : P, c.st);
             if (!c.rc && !c.dry) {
                 GemmParams p = c.desc(cx, (long long)g.sam_heads * RgT, Cc, Cc, prefix + ".v", hd, true, ACT_NONE, nullptr, 0, nullptr, ta, Dh);
                 p.w_gr = (int)RgT, p.w_gs = (long long)hd * Cc, p.b_gs = hd, p.o_gs = hd;
@@ -273,7 +290,7 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
                 if (!c.rc) c.rc = launch_gemm(c.dt, 0, p, c.st);
             }
         } else {
-            void* tv = c.proj(keysT, NP, Cc, prefix + ".v", Dh);
+            void* tv = hs ? proj_half_shared(keysT, prefix + ".v", Dh) : c.proj(keysT, NP, Cc, prefix + ".v", Dh);
             if (!c.rc && !c.dry) c.rc = launch_t2i_attn_scores(c.dt, sc, HTk, tv, ta, N, P, Dh, g.sam_heads, c.st);
         }
     };
@@ -309,14 +326,14 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         {
             void* tq = c.proj(qP, 6ll * N, Cc, lo + "t2i.q", Dh);
             const bool hs = half_shared && l == 0;
-            const bool folded = fold_t2i_ok && l >= 1 && !shared && !hs;
+            const bool folded = fold_t2i_ok && (l >= 1 || fold_l0) && !shared && (!hs || P % 256 == 0);
             void* tv = folded ? nullptr : hs ? proj_half_shared(curT, lo + "t2i.v", Dh) : c.proj(curT, (long long)Nk * P, Cc, lo + "t2i.v", Dh);
             void* ta = c.T(RgT, Dh);
-            // (layer 0 keeps the projected form whatever the keys look like: where its keys are still common to all tracks, or
-            //  half common, the projection of the common rows is one small GEMM - and the per-track evaluation of the same window
-            //  (the equality tests of those shortcuts) stays bit-identical to it)
+            // (layer 0 of a FIRST window - keys still common to all tracks - and of a window evaluated out of context keeps the
+            //  projected form: the projection of the common rows is one small GEMM, and the per-track evaluation of the same window
+            //  (the equality test of that shortcut) stays bit-identical to it; layer 0 of a later window: see fold_l0 above)
             if (folded) {
-                t2i_folded(tq, lo + "t2i", curP, curT, ta);
+                t2i_folded(tq, lo + "t2i", curP, curT, ta, hs);
             } else {
                 void* tk = hs ? proj_half_shared(curP, lo + "t2i.k", Dh) : c.proj(curP, (long long)Nk * P, Cc, lo + "t2i.k", Dh);
                 c.attn(shared ? 3 : 1, tq, tk, tv, ta, N, P, Dh, g.sam_heads);
@@ -455,7 +472,7 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
         void* fq = c.proj(qP, 6ll * N, Cc, "final.q", Dh);
         void* fa = c.T(RgT, Dh);
         if (fold_t2i_ok && Nk == N) {
-            t2i_folded(fq, "final", curP, curT, fa);
+            t2i_folded(fq, "final", curP, curT, fa, false);
         } else {
             void* fv = c.proj(curT, (long long)Nk * P, Cc, "final.v", Dh);
             void* fk = c.proj(curP, (long long)Nk * P, Cc, "final.k", Dh);

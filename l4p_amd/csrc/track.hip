@@ -1158,12 +1158,15 @@ __device__ __forceinline__ vec8<T> tr_frag(const char* lo, int hi_off) {
     const s16x8_t r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return __builtin_bit_cast(vec8<T>, r);
 }
-// ST = 8 (six stages in flight): the launch of a rank's 8-track shard - 88 workgroups, each walking its 64 key steps alone on its CU -
-// is bound by the round trip of a stage, not by bandwidth (57 us at ST = 4, 0.9 us per step).  Same sums in the same order.
+// (ST = 8, six stages in flight, was measured on a rank's 8-track shard - 88 workgroups, each alone on its CU: no faster, 49.7 vs 51.9 us;
+//  tools/probes/ctx_ablate.sh: a step's 0.7 us is the stage wait + barrier (0.22 us) and the fragment reads -> MFMAs (0.27 us) one
+//  after the other, not the memory round trip)
+// shared_from < P: the rows p >= shared_from of EVERY track are read from track 0's block (later windows of the recursion, layer 0: the
+// second temporal half of every track's keys is still track 0's; a multiple of 32).
 template <typename T, int HT, int CW, int ST = 4>
 __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__ probs, const T* __restrict__ keys,
                                                            T* __restrict__ ctx, const float* __restrict__ stats, int P, int C, int heads,
-                                                           int tokens, long long Rg) {
+                                                           int tokens, long long Rg, int shared_from) {
     static_assert(HT == 48, "t2i_scales");
     static_assert(ST == 4 || ST == 8, "ring depth");
     constexpr int KT = 32, MT = HT / 16, NTW = CW / 64;  // NTW: 16-column tiles per wave
@@ -1179,12 +1182,14 @@ __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__
     __shared__ float scale[16 * HT];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c0 = blockIdx.x * CW, n = blockIdx.y;
-    const char* kb = (const char*)(keys + (long long)n * P * C + c0);
+    const char* kb_own = (const char*)(keys + (long long)n * P * C + c0);
+    const char* kb_shared = (const char*)(keys + c0);
     const char* pb = (const char*)(probs + (long long)n * P * HT);
     const int ns = P / KT;
     auto issue = [&](int s) {
         char* dst = smem + (s & (ST - 1)) * SB;
         const long long p0 = (long long)s * KT;
+        const char* kb = p0 >= shared_from ? kb_shared : kb_own;
 #pragma unroll
         for (int i = 0; i < KP; ++i) {
             const int q = wave * 64 + i * 256 + lane;  // 16-byte chunk of the [32][CW] tile: row q / CPR, part q % CPR
@@ -1266,7 +1271,8 @@ __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__
 // any dtype (the f32 engine): one thread per column, the HT running sums in registers, probs rows read as wave-uniform values
 template <typename T, int HT>
 __global__ __launch_bounds__(256) void t2i_ctx_kernel(const T* __restrict__ probs, const T* __restrict__ keys, T* __restrict__ ctx,
-                                                      const float* __restrict__ stats, int P, int C, int heads, int tokens, long long Rg) {
+                                                      const float* __restrict__ stats, int P, int C, int heads, int tokens, long long Rg,
+                                                      int shared_from) {
     __shared__ float scale[16 * HT];
     const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     t2i_scales(stats, n, (P + T2I_SPLIT - 1) / T2I_SPLIT, scale);
@@ -1274,10 +1280,11 @@ __global__ __launch_bounds__(256) void t2i_ctx_kernel(const T* __restrict__ prob
     float acc[HT], tot[HT];
 #pragma unroll
     for (int t = 0; t < HT; ++t) acc[t] = tot[t] = 0.f;
-    const T* kp = keys + (long long)n * P * C + c;
+    const T* kp_own = keys + (long long)n * P * C + c;
+    const T* kp_shared = keys + c;
     const T* pp = probs + (long long)n * P * HT;
     for (int p = 0; p < P; ++p) {
-        const float kv = to_f32<T>(kp[(long long)p * C]);
+        const float kv = to_f32<T>((p >= shared_from ? kp_shared : kp_own)[(long long)p * C]);
 #pragma unroll
         for (int t = 0; t < HT; ++t) acc[t] += to_f32<T>(pp[(long long)p * HT + t]) * kv;
         if ((p % T2I_SPLIT) == T2I_SPLIT - 1 || p == P - 1) {
@@ -1399,33 +1406,28 @@ int launch_t2i_probs(int dtype, const float* scores, long long ld_scores, void* 
     return 0;
 }
 int launch_t2i_context(int dtype, const void* probs, const float* stats, const void* keys, void* ctx, int N, int P, int C, int heads,
-                       int tokens, long long Rg, hipStream_t stream) {
-    if (N < 1 || heads * tokens != 48 || C % 64 || P % 32 || P < 96 || P > 16 * T2I_SPLIT || Rg < (long long)N * tokens) {
-        l4p_set_error("t2i_context: heads * tokens == 48, C %% 64 == 0, P %% 32 == 0, 96 <= P <= 4096, Rg >= N * tokens");
+                       int tokens, long long Rg, int shared_from, hipStream_t stream) {
+    if (N < 1 || heads * tokens != 48 || C % 64 || P % 32 || P < 96 || P > 16 * T2I_SPLIT || Rg < (long long)N * tokens || shared_from < 0 ||
+        shared_from % 32) {
+        l4p_set_error("t2i_context: heads * tokens == 48, C %% 64 == 0, P %% 32 == 0, 96 <= P <= 4096, Rg >= N * tokens, shared_from %% 32 == 0");
         return L4P_E_INVALID;
     }
+    if (shared_from > P) shared_from = P;
     // (a batched GEMM: N x [HT x P] x [P x C]; profiled with the small / streaming products: the FLOP model's executed-shapes check sees it)
     ProfScope prof(PROF_GEMM_SMALL, stream, "M%d N%d K%d epi0 act0 ctx t48x%d", N * heads * tokens, C, P, C % 128 ? 64 : 128);
     if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
-        if (C % 128 == 0 && (C / 128) * N <= 256 && knob(KNOB_TRACK_DEEP)) {  // at most one workgroup per CU: the deep ring
-            constexpr int lds = 8 * (32 * 128 * 2 + 32 * 48 * 2);
-            auto kern = t2i_ctx_mfma_kernel<T16, 48, 128, 8>;
-            static lds_attr_state attr_deep;
-            HIP_TRY(lds_attr_once(attr_deep, kern, lds));
-            hipLaunchKernelGGL(kern, dim3(C / 128, N), dim3(256), lds, stream, (const T16*)probs, (const T16*)keys, (T16*)ctx, stats, P, C,
-                               heads, tokens, Rg);
-        } else if (C % 128 == 0) {
+        if (C % 128 == 0) {
             constexpr int lds = 4 * (32 * 128 * 2 + 32 * 48 * 2);
             hipLaunchKernelGGL((t2i_ctx_mfma_kernel<T16, 48, 128>), dim3(C / 128, N), dim3(256), lds, stream, (const T16*)probs,
-                               (const T16*)keys, (T16*)ctx, stats, P, C, heads, tokens, Rg);
+                               (const T16*)keys, (T16*)ctx, stats, P, C, heads, tokens, Rg, shared_from);
         } else {
             constexpr int lds = 4 * (32 * 64 * 2 + 32 * 48 * 2);
             hipLaunchKernelGGL((t2i_ctx_mfma_kernel<T16, 48, 64>), dim3(C / 64, N), dim3(256), lds, stream, (const T16*)probs,
-                               (const T16*)keys, (T16*)ctx, stats, P, C, heads, tokens, Rg);
+                               (const T16*)keys, (T16*)ctx, stats, P, C, heads, tokens, Rg, shared_from);
         }
     }); else {
         hipLaunchKernelGGL((t2i_ctx_kernel<float, 48>), dim3((C + 255) / 256, N), dim3(256), 0, stream, (const float*)probs,
-                           (const float*)keys, (float*)ctx, stats, P, C, heads, tokens, Rg);
+                           (const float*)keys, (float*)ctx, stats, P, C, heads, tokens, Rg, shared_from);
     }
     HIP_TRY(hipGetLastError());
     return 0;

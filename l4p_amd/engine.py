@@ -124,19 +124,19 @@ class Engine:
         clips whose trackers run concurrently on different HIP streams must not share one."""
         N, Cc = q_off.shape[0], self.cfg.dim
         T = tcfg.T
-        hu = int(hist_uniform)  # 0 per-track history, 1 uniform (first window), 2 second temporal half uniform (later windows)
+        hu = int(hist_uniform)  # 0 per-track history, 1 uniform (first window), 2 second temporal half uniform (later windows), 4 later window, per-track
         # ONE workspace per slot, sized for the largest of the three history forms at the largest N seen (a clip's first
         # window runs hu = 1, its later ones hu = 2, a last chunk has fewer queries: keyed by shape, every forward freed and
         # re-allocated several hundred MB per clip); it only ever grows
         need = self._trk_need.get((N, hu))
         if need is None:
-            for h in (0, 1, 2):
+            for h in (0, 1, 2, 4):
                 nb = int(self.lib.l4p_track_window_workspace_bytes(self.handle, C.byref(tcfg), N, h))
                 if nb == 0:
                     raise _lib.L4PHipError("l4p_track_window_workspace_bytes: " + self.lib.l4p_last_error().decode())
                 self._trk_need[(N, h)] = nb
-            need = max(self._trk_need[(N, h)] for h in (0, 1, 2))
-            for h in (0, 1, 2):
+            need = max(self._trk_need[(N, h)] for h in (0, 1, 2, 4))
+            for h in (0, 1, 2, 4):
                 self._trk_need[(N, h)] = need
         ws = self._trk_ws.get(slot)
         if ws is None or ws.numel() < need:

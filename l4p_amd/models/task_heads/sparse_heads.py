@@ -161,7 +161,9 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         pos = self._w("dense_pe")
         # hist_uniform == 2: rows [P/2, P) of every track's keys coincide until the first image -> token update
         half_shared = hist_uniform == 2 and N > 1 and P % 2 == 0
-        if hist_uniform == 2:
+        # hist_uniform 2 / 4: a later window of a recursion - layer 0's token -> image attention in the folded form (csrc/api_trackwin.hip)
+        fold_l0 = hist_uniform in (2, 4) and os.environ.get("L4P_TRACK_FOLD_L0", "1") != "0"
+        if hist_uniform in (2, 4):
             hist_uniform = 0
 
         def proj_half_shared(x: torch.Tensor, key: str, n: int) -> torch.Tensor:
@@ -197,12 +199,19 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                   and 96 <= P <= 4096)
         RgT = (6 * N + 127) // 128 * 128
 
-        def t2i_folded(tq: torch.Tensor, prefix: str, keysP: torch.Tensor, keysT: torch.Tensor) -> torch.Tensor:
+        def t2i_folded(tq: torch.Tensor, prefix: str, keysP: torch.Tensor, keysT: torch.Tensor, hs: bool = False) -> torch.Tensor:
             KW = cfg.sam_heads * Cc
             qf = torch.empty((N * HTk + 128, Cc), dtype=td, device=dev)  # Q' [N][HT][C] (+ slack rows under the last tile)
             _gemm(tq, 6 * N, Dh, Dh, self._w(prefix + ".kfold.w"), KW, out_T=qf, ldc=KW)
             sc = torch.empty((N * P, HTk), **f32)
-            _gemm(keysP, N * P, Cc, Cc, qf, HTk, out_f32=sc, ldc=HTk, wgroup=(P, HTk * Cc, 0), ldw=Cc)
+            if hs:  # rows [P/2, P) exist for track 0 only: two row-mapped launches over the half blocks
+                half = P // 2
+                _gemm(keysP, N * half, Cc, Cc, qf, HTk, out_f32=sc, ldc=HTk, wgroup=(half, HTk * Cc, 0), ldw=Cc,
+                      a_map=(half, P, 0), c_map=(half, P, 0))
+                _gemm(keysP, N * half, Cc, Cc, qf, HTk, out_f32=sc, ldc=HTk, wgroup=(half, HTk * Cc, 0), ldw=Cc,
+                      a_map=(half, 0, half), c_map=(half, P, half))
+            else:
+                _gemm(keysP, N * P, Cc, Cc, qf, HTk, out_f32=sc, ldc=HTk, wgroup=(P, HTk * Cc, 0), ldw=Cc)
             ta = torch.empty((RgT, Dh), dtype=td, device=dev)  # (rows past 6 N: scratch of the head groups' padding rows)
             if fold_v:
                 hd = Dh // cfg.sam_heads
@@ -210,12 +219,12 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 cx = torch.empty((cfg.sam_heads * RgT, Cc), dtype=td, device=dev)
                 stt = torch.empty((N * ((P + 255) // 256), 2 * HTk), **f32)  # per 256-key split: column maxima, sums
                 _lib.check(lib.l4p_t2i_probs(_stream(), dt, _p(sc), HTk, _p(pr), _p(stt), N, P, HTk), "l4p_t2i_probs")
-                _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(stt), _p(keysT), _p(cx), N, P, Cc, cfg.sam_heads, 6, RgT),
-                           "l4p_t2i_context")
+                _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(stt), _p(keysT), _p(cx), N, P, Cc, cfg.sam_heads, 6, RgT,
+                                               P // 2 if hs else P), "l4p_t2i_context")
                 _gemm(cx, cfg.sam_heads * RgT, Cc, Cc, self._w(prefix + ".v.w"), hd, bias=self._w(prefix + ".v.b"), out_T=ta, ldc=Dh,
                       wgroup=(RgT, hd * Cc, hd), c_map=(RgT, 0, 0), ogroup=hd)
             else:
-                tv = self._proj(keysT, prefix + ".v", Dh)
+                tv = proj_half_shared(keysT, prefix + ".v", Dh) if hs else self._proj(keysT, prefix + ".v", Dh)
                 _lib.check(lib.l4p_t2i_attn_scores(_stream(), dt, _p(sc), HTk, _p(tv), _p(ta), N, P, Dh, cfg.sam_heads),
                            "l4p_t2i_attn_scores")
             return ta
@@ -240,8 +249,8 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
             # --- tokens -> image (transformer.py:168-173) ---
             tq = self._proj(qP, lo + "t2i.q", Dh)
             hs = half_shared and l == 0
-            if fold_t2i_ok and l >= 1 and not shared and not hs:  # (layer 0 keeps the projected form: see csrc/api_trackwin.hip)
-                ta = t2i_folded(tq, lo + "t2i", kP, kT)
+            if fold_t2i_ok and (l >= 1 or fold_l0) and not shared and (not hs or P % 256 == 0):  # (see csrc/api_trackwin.hip)
+                ta = t2i_folded(tq, lo + "t2i", kP, kT, hs)
             else:
                 tv = proj_half_shared(kT, lo + "t2i.v", Dh) if hs else self._proj(kT, lo + "t2i.v", Dh)
                 tk = proj_half_shared(kP, lo + "t2i.k", Dh) if hs else self._proj(kP, lo + "t2i.k", Dh)
@@ -519,7 +528,7 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                 # later windows: the second temporal half of every track's history is the mask token again (written by the
                 # previous window's memory update) -> what layer 0 derives from those rows is computed once (L4P_TRACK_HALF_SHARE=0:
                 # every track on its own, the A/B and equality check)
-                hu = 1 if wi == 0 else (2 if os.environ.get("L4P_TRACK_HALF_SHARE", "1") != "0" else 0)
+                hu = 1 if wi == 0 else (2 if os.environ.get("L4P_TRACK_HALF_SHARE", "1") != "0" else 4)  # (4: a later window, every track on its own rows)
                 # (need_history = 2: hist was filled with the mask token above and only this loop writes it - the memory update
                 #  of a window rewrites rows [0, P/2) of each track, nothing touches rows [P/2, P) - so the re-fill is skipped)
                 w_traj, w_vis, w_dep, new_pfeat = self._window(enc_last, hist, q_off, labels, pfeat, plabel, 0 if last else 2,

@@ -677,7 +677,7 @@ def test_folded_t2i_value_kernels(dev, precision, Cc, knob):
     assert float((pnorm - pref).abs().max()) <= (4e-3 if precision != "32-true" else 5e-6) * float(pref.max())
     Rg = (tokens * N + 127) // 128 * 128
     cx = torch.full((heads * Rg, Cc), float("nan"), dtype=td, device="cuda")
-    _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(st), _p(keys), _p(cx), N, P, Cc, heads, tokens, Rg), "l4p_t2i_context")
+    _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(st), _p(keys), _p(cx), N, P, Cc, heads, tokens, Rg, P), "l4p_t2i_context")
     torch.cuda.synchronize()
     cref = torch.einsum("npth,npc->htnc", pnorm.view(N, P, tokens, heads), keys.float().cpu().view(N, P, Cc))  # [h][t][n][c]
     cxc = cx.float().cpu().view(heads, Rg, Cc)
@@ -685,6 +685,16 @@ def test_folded_t2i_value_kernels(dev, precision, Cc, knob):
     tol = 6e-3 if precision != "32-true" else 1e-4    # (one bf16 rounding of the f32 sum; f32: summation order, relative to >= 1 % of the maximum)
     assert float(((got - cref).abs() / cref.abs().clamp_min(1e-2 * float(cref.abs().max()))).max()) <= tol
     assert bool(torch.isnan(cxc[:, N * tokens:]).all())                                     # rows past N * tokens untouched
+    # shared_from: key rows p >= 320 of every track read from track 0's block == the same call on keys with those rows copied
+    sf = 320
+    kcp = keys.view(N, P, Cc).clone()
+    kcp[:, sf:] = kcp[0:1, sf:]
+    cxa = torch.zeros(heads * Rg, Cc, dtype=td, device="cuda")
+    cxb = torch.zeros(heads * Rg, Cc, dtype=td, device="cuda")
+    _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(st), _p(keys), _p(cxa), N, P, Cc, heads, tokens, Rg, sf), "l4p_t2i_context")
+    _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(st), _p(kcp), _p(cxb), N, P, Cc, heads, tokens, Rg, P), "l4p_t2i_context")
+    torch.cuda.synchronize()
+    assert torch.equal(cxa, cxb) and not torch.equal(cxa, torch.nan_to_num(cx, nan=0.0))
     if hd % 8:
         return  # (the grouped projection writes 8-column vectors: head dims of whole vectors only)
     cx = torch.nan_to_num(cx, nan=0.0)
@@ -706,7 +716,7 @@ def test_folded_t2i_value_kernels(dev, precision, Cc, knob):
     knob("track_deep", 0)
     knob("gemm_skinny", 0)
     cx2 = torch.full((heads * Rg, Cc), float("nan"), dtype=td, device="cuda")
-    _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(st), _p(keys), _p(cx2), N, P, Cc, heads, tokens, Rg), "l4p_t2i_context")
+    _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(st), _p(keys), _p(cx2), N, P, Cc, heads, tokens, Rg, P), "l4p_t2i_context")
     ta2 = torch.empty(Rg, Dh, dtype=td, device="cuda")
     d.out_T = _p(ta2)
     _lib.check(lib.l4p_gemm(_stream(), dt, C.byref(d)), "l4p_gemm(head groups, o_gs)")

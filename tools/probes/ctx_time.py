@@ -23,12 +23,12 @@ for N, P in ((1, 2048), (8, 2048), (64, 2048)):
     for deep in (0, 1):
         _lib.set_knob("track_deep", deep)
         for _ in range(5):
-            lib.l4p_t2i_context(_stream(), L4P_BF16, _p(pr), _p(st), _p(keys), _p(cx), N, P, Cc, heads, tokens, Rg)
+            lib.l4p_t2i_context(_stream(), L4P_BF16, _p(pr), _p(st), _p(keys), _p(cx), N, P, Cc, heads, tokens, Rg, P)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(100):
-            lib.l4p_t2i_context(_stream(), L4P_BF16, _p(pr), _p(st), _p(keys), _p(cx), N, P, Cc, heads, tokens, Rg)
+            lib.l4p_t2i_context(_stream(), L4P_BF16, _p(pr), _p(st), _p(keys), _p(cx), N, P, Cc, heads, tokens, Rg, P)
         e.record()
         torch.cuda.synchronize()
         line += f"  track_deep={deep}: {s.elapsed_time(e) * 10:.1f} us"
