@@ -16,7 +16,7 @@ int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dp
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
-                        int W, hipStream_t stream);
+                        int W, hipStream_t stream, int dtype = 0, void* tokens_T = nullptr);
 int launch_track_keys_init(int dtype, const float* enc, const float* hist, const float* pos, float* k32, void* kT,
                            void* kP, int N, int P, int C, int shared_from, float* k32_shared, hipStream_t stream);
 int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,

@@ -29,7 +29,7 @@ int launch_layernorm_chain(int dtype, const float* xs, int x_mod, const void* dp
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
-                        int W, hipStream_t stream);
+                        int W, hipStream_t stream, int dtype = 0, void* tokens_T = nullptr);
 int launch_track_keys_init(int dtype, const float* enc, const float* hist, const float* pos, float* k32, void* kT,
                            void* kP, int N, int P, int C, int shared_from, float* k32_shared, hipStream_t stream);
 int launch_fill_rows(float* out, const float* v, long long rows, int C, long long group_rows, long long group_stride,
@@ -194,8 +194,7 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
     if (!c.rc && !c.dry) {
         c.rc = launch_track_tokens(q_off, labels, pfeat, plabel, c.Wf("gauss"), c.Wf("mask_tokens"), c.Wf("point_emb0"),
                                    c.Wf("point_emb1"), c.Wf("not_a_point"), c.Wf("feat_emb0"), c.Wf("feat_emb1"), tok32, N, Cc, T, H, W,
-                                   c.st);
-        if (!c.rc) c.rc = launch_cast(c.dt, tok32, tokT, 6ll * N * Cc, c.st);
+                                   c.st, c.dt, tokT);  // (both forms of the tokens from one launch: the values l4p_cast gives)
     }
     // ---- keys = enc_features[-1] + history (sparse_heads.py:341-346); one shared [P][C] set while every track still has
     //      the same history rows (first window), the per-track set from the first image -> token update on ----

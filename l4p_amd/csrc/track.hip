@@ -88,13 +88,16 @@ template <> struct Vec4<float> {
 // tokens[n] = [mask_tok0, mask_tok1, mask_tok2, point PE + label emb, not-a-point, feature + feature emb]
 // queries [N][3] = (t, x, y) in window time / pixels; labels [N] float {0,1,2}; pfeat [N][C]; plabel [N].
 // -------------------------------------------------------------------------------------------------
+// TT: the engine type of the optional second output (tokens_T: the same values rounded once - what l4p_cast makes of `tokens`; the
+// window call takes both from one launch)
+template <typename TT>
 __global__ void track_tokens_kernel(const float* __restrict__ queries, const float* __restrict__ labels,
                                     const float* __restrict__ pfeat, const float* __restrict__ plabel,
                                     const float* __restrict__ gauss, const float* __restrict__ mask_tokens,
                                     const float* __restrict__ point_emb0, const float* __restrict__ point_emb1,
                                     const float* __restrict__ not_a_point, const float* __restrict__ feat_emb0,
                                     const float* __restrict__ feat_emb1, float* __restrict__ tokens, int N, int C, float T,
-                                    float H, float W) {
+                                    float H, float W, TT* __restrict__ tokens_T) {
     const int n = blockIdx.x;
     const int half = C / 2;
     const float ct = 2.f * (queries[n * 3 + 0] / T) - 1.f;
@@ -120,6 +123,15 @@ __global__ void track_tokens_kernel(const float* __restrict__ queries, const flo
         if (pl == 0.f) fe = pfeat[(long long)n * C + c] + feat_emb0[c];
         if (pl == 1.f) fe = pfeat[(long long)n * C + c] + feat_emb1[c];
         out[5 * C + c] = fe;
+        if (tokens_T) {
+            TT* ot = tokens_T + (long long)n * 6 * C;
+            ot[0 * C + c] = from_f32<TT>(mask_tokens[0 * C + c]);
+            ot[1 * C + c] = from_f32<TT>(mask_tokens[1 * C + c]);
+            ot[2 * C + c] = from_f32<TT>(mask_tokens[2 * C + c]);
+            ot[3 * C + c] = from_f32<TT>(pe);
+            ot[4 * C + c] = from_f32<TT>(not_a_point[c]);
+            ot[5 * C + c] = from_f32<TT>(fe);
+        }
     }
 }
 
@@ -1163,12 +1175,12 @@ __device__ __forceinline__ vec8<T> tr_frag(const char* lo, int hi_off) {
 //  after the other, not the memory round trip)
 // shared_from < P: the rows p >= shared_from of EVERY track are read from track 0's block (later windows of the recursion, layer 0: the
 // second temporal half of every track's keys is still track 0's; a multiple of 32).
-template <typename T, int HT, int CW, int ST = 4>
+template <typename T, int HT, int CW, int ST = 4, int UNR = 1>
 __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__ probs, const T* __restrict__ keys,
                                                            T* __restrict__ ctx, const float* __restrict__ stats, int P, int C, int heads,
                                                            int tokens, long long Rg, int shared_from) {
     static_assert(HT == 48, "t2i_scales");
-    static_assert(ST == 4 || ST == 8, "ring depth");
+    static_assert(ST == 4 || ST == 8 || ST == 12, "ring depth");
     constexpr int KT = 32, MT = HT / 16, NTW = CW / 64;  // NTW: 16-column tiles per wave
     constexpr int SPK = T2I_SPLIT / KT;                          // key steps per softmax split
     constexpr int KB = KT * CW * 2, PB = KT * HT * 2, SB = KB + PB;
@@ -1187,7 +1199,7 @@ __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__
     const char* pb = (const char*)(probs + (long long)n * P * HT);
     const int ns = P / KT;
     auto issue = [&](int s) {
-        char* dst = smem + (s & (ST - 1)) * SB;
+        char* dst = smem + (s % ST) * SB;
         const long long p0 = (long long)s * KT;
         const char* kb = p0 >= shared_from ? kb_shared : kb_own;
 #pragma unroll
@@ -1207,20 +1219,30 @@ __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[m][j] = tot[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int AH = ST - 2;  // stages in flight behind the one being read
+    // UNR stages are consumed per barrier (a "group"); AHG groups stay in flight behind the one being read, one more is requested into
+    // the slots of the group read before (UNR = 1, ST = 4: the chip-filling form; UNR = 2, ST = 8: a launch of at most one workgroup
+    // per CU, where a step is the stage wait + barrier and then the fragment reads -> MFMAs, one after the other: half the barriers, and
+    // the LDS latency of two stages' fragments overlaps).  MFMAs run in stage order: the same sums in the same order.
+    constexpr int NGS = ST / UNR, AHG = NGS - 2;
+    static_assert(ST % UNR == 0 && AHG >= 1 && AHG <= 6, "ring of whole groups");
+    const int ngr = ns / UNR;  // (the launcher guarantees ns % UNR == 0)
 #pragma unroll
-    for (int s = 0; s <= AH; ++s)
-        if (s < ns) issue(s);
+    for (int gq = 0; gq <= AHG; ++gq)
+        if (gq < ngr) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) issue(gq * UNR + u);
+        }
     t2i_scales(stats, n, (P + T2I_SPLIT - 1) / T2I_SPLIT, scale);
-    for (int s = 0; s < ns; ++s) {
-        const int ahead = ns - 1 - s < AH ? ns - 1 - s : AH;
-        switch (ahead) {  // (AH == 2: cases 3 .. 6 are never taken)
-            case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (KP + 1)) : "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (KP + 1)) : "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (KP + 1)) : "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (KP + 1)) : "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (KP + 1)) : "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KP + 1) : "memory"); break;
+    for (int gi = 0; gi < ngr; ++gi) {
+        const int ahead = ngr - 1 - gi < AHG ? ngr - 1 - gi : AHG;
+        constexpr int LPG = UNR * (KP + 1);  // loads of a wave per group
+        switch (ahead) {
+            case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * LPG > 63 ? 63 : 6 * LPG) : "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * LPG > 63 ? 63 : 5 * LPG) : "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPG > 63 ? 63 : 4 * LPG) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPG > 63 ? 63 : 3 * LPG) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPG) : "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPG) : "memory"); break;
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1228,30 +1250,42 @@ __global__ __launch_bounds__(256) void t2i_ctx_mfma_kernel(const T* __restrict__
         __builtin_amdgcn_s_barrier();
 #endif
 #if !(defined(CTX_ABL) && CTX_ABL == 2)
-        if (s + AH + 1 < ns) issue(s + AH + 1);
+        if (gi + AHG + 1 < ngr) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) issue((gi + AHG + 1) * UNR + u);
+        }
 #endif
-        const char* base = smem + (s & (ST - 1)) * SB;
-        vec8<T> fa[MT], fb[NTW];
+        vec8<T> fa[UNR][MT], fb[UNR][NTW];
 #if !(defined(CTX_ABL) && CTX_ABL == 1)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) fa[m] = tr_frag<T>(base + a_off + m * 32, 4 * HT * 2);
+        for (int u = 0; u < UNR; ++u) {
+            const char* base = smem + ((gi * UNR + u) % ST) * SB;
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) fb[j] = tr_frag<T>(base + b_off + j * 32, 4 * CW * 2);
+            for (int m = 0; m < MT; ++m) fa[u][m] = tr_frag<T>(base + a_off + m * 32, 4 * HT * 2);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[m][j] = mma16(fa[m], fb[j], acc[m][j]);
+            for (int j = 0; j < NTW; ++j) fb[u][j] = tr_frag<T>(base + b_off + j * 32, 4 * CW * 2);
+        }
 #endif
-        if ((s % SPK) == SPK - 1 || s == ns - 1) {  // end of a softmax split: its sum joins the total with the split's weight
-            const float* sc = scale + (s / SPK) * HT + 4 * g;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const f32x4 w = *(const f32x4*)(sc + m * 16);
+        for (int u = 0; u < UNR; ++u) {
+            const int s = gi * UNR + u;
+#if !(defined(CTX_ABL) && CTX_ABL == 1)
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) tot[m][j][e] += w[e] * acc[m][j][e];
-                    acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < NTW; ++j) acc[m][j] = mma16(fa[u][m], fb[u][j], acc[m][j]);
+#endif
+            if ((s % SPK) == SPK - 1 || s == ns - 1) {  // end of a softmax split: its sum joins the total with the split's weight
+                const float* sc = scale + (s / SPK) * HT + 4 * g;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const f32x4 w = *(const f32x4*)(sc + m * 16);
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tot[m][j][e] += w[e] * acc[m][j][e];
+                        acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
                 }
             }
         }
@@ -1416,7 +1450,23 @@ int launch_t2i_context(int dtype, const void* probs, const float* stats, const v
     // (a batched GEMM: N x [HT x P] x [P x C]; profiled with the small / streaming products: the FLOP model's executed-shapes check sees it)
     ProfScope prof(PROF_GEMM_SMALL, stream, "M%d N%d K%d epi0 act0 ctx t48x%d", N * heads * tokens, C, P, C % 128 ? 64 : 128);
     if (is16(dtype)) L4P_WITH_T16(dtype, T16, {
-        if (C % 128 == 0) {
+        // at most one workgroup per CU (a rank's query shard): four 32-key stages per barrier on a twelve-stage ring (8 tracks: 53.8 -> 34.2 us;
+        // two per barrier: 39.0), else - P not a multiple of 128 - two
+        if (C % 128 == 0 && (C / 128) * N <= 256 && P % 128 == 0 && knob(KNOB_TRACK_DEEP)) {
+            constexpr int lds = 12 * (32 * 128 * 2 + 32 * 48 * 2);
+            auto kern = t2i_ctx_mfma_kernel<T16, 48, 128, 12, 4>;
+            static lds_attr_state attr_quads;
+            HIP_TRY(lds_attr_once(attr_quads, kern, lds));
+            hipLaunchKernelGGL(kern, dim3(C / 128, N), dim3(256), lds, stream, (const T16*)probs, (const T16*)keys, (T16*)ctx, stats, P, C,
+                               heads, tokens, Rg, shared_from);
+        } else if (C % 128 == 0 && (C / 128) * N <= 256 && P % 64 == 0 && knob(KNOB_TRACK_DEEP)) {
+            constexpr int lds = 8 * (32 * 128 * 2 + 32 * 48 * 2);
+            auto kern = t2i_ctx_mfma_kernel<T16, 48, 128, 8, 2>;
+            static lds_attr_state attr_pairs;
+            HIP_TRY(lds_attr_once(attr_pairs, kern, lds));
+            hipLaunchKernelGGL(kern, dim3(C / 128, N), dim3(256), lds, stream, (const T16*)probs, (const T16*)keys, (T16*)ctx, stats, P, C,
+                               heads, tokens, Rg, shared_from);
+        } else if (C % 128 == 0) {
             constexpr int lds = 4 * (32 * 128 * 2 + 32 * 48 * 2);
             hipLaunchKernelGGL((t2i_ctx_mfma_kernel<T16, 48, 128>), dim3(C / 128, N), dim3(256), lds, stream, (const T16*)probs,
                                (const T16*)keys, (T16*)ctx, stats, P, C, heads, tokens, Rg, shared_from);
@@ -1435,10 +1485,12 @@ int launch_t2i_context(int dtype, const void* probs, const float* stats, const v
 int launch_track_tokens(const float* queries, const float* labels, const float* pfeat, const float* plabel,
                         const float* gauss, const float* mask_tokens, const float* pe0, const float* pe1,
                         const float* nap, const float* fe0, const float* fe1, float* tokens, int N, int C, int T, int H,
-                        int W, hipStream_t stream) {
+                        int W, hipStream_t stream, int dtype, void* tokens_T) {
     ProfScope prof(PROF_TRACK, stream, "track_tokens");
-    hipLaunchKernelGGL(track_tokens_kernel, dim3(N), dim3(256), 0, stream, queries, labels, pfeat, plabel, gauss,
-                       mask_tokens, pe0, pe1, nap, fe0, fe1, tokens, N, C, (float)T, (float)H, (float)W);
+    if (tokens_T && is16(dtype)) L4P_WITH_T16(dtype, T16, hipLaunchKernelGGL(track_tokens_kernel<T16>, dim3(N), dim3(256), 0, stream, queries, labels, pfeat, plabel, gauss, mask_tokens, pe0, pe1, nap, fe0, fe1, tokens, N, C, (float)T, (float)H, (float)W, (T16*)tokens_T));
+    else
+        hipLaunchKernelGGL(track_tokens_kernel<float>, dim3(N), dim3(256), 0, stream, queries, labels, pfeat, plabel, gauss, mask_tokens,
+                           pe0, pe1, nap, fe0, fe1, tokens, N, C, (float)T, (float)H, (float)W, (float*)tokens_T);
     HIP_TRY(hipGetLastError());
     return 0;
 }

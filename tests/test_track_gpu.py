@@ -725,6 +725,47 @@ def test_folded_t2i_value_kernels(dev, precision, Cc, knob):
     assert torch.equal(ta2[:N * tokens], ta[:N * tokens])
 
 
+@pytest.mark.parametrize("precision", ["bf16", "16-mixed"])
+def test_t2i_context_two_stages_per_barrier_equals_the_chip_filling_form(dev, precision, knob):
+    """l4p_t2i_context on a launch of at most one workgroup per CU (a rank's query shard; knob track_deep): four (two) 32-key stages per
+    barrier on a twelve- (eight-) stage ring == the one-stage form bit for bit (MFMAs in stage order), with and without the shared second half."""
+    from l4p_amd import _lib
+    from l4p_amd._lib import L4P_BF16, L4P_F16
+    from l4p_amd.ops import _p, _stream
+
+    lib = _lib.load()
+    dt = L4P_BF16 if precision == "bf16" else L4P_F16
+    td = torch.bfloat16 if precision == "bf16" else torch.float16
+    Cc, heads, tokens = 1408, 8, 6
+    HT = heads * tokens
+    for N, P in ((3, 2048), (2, 1984)):  # (four stages per barrier; P % 128 != 0: two)
+        _ctx_forms_equal(lib, dt, td, N, P, Cc, heads, tokens, knob)
+
+
+def _ctx_forms_equal(lib, dt, td, N, P, Cc, heads, tokens, knob):
+    from l4p_amd import _lib
+    from l4p_amd.ops import _p, _stream
+
+    HT = heads * tokens
+    g = torch.Generator().manual_seed(5)
+    sc = (3.0 * torch.randn(N * P, HT, generator=g)).cuda()
+    keys = torch.randn(N * P, Cc, generator=g).to(td).cuda()
+    nsp = (P + 255) // 256
+    pr = torch.empty(N * P, HT, dtype=td, device="cuda")
+    st = torch.empty(N * nsp, 2 * HT, device="cuda")
+    _lib.check(lib.l4p_t2i_probs(_stream(), dt, _p(sc), HT, _p(pr), _p(st), N, P, HT), "l4p_t2i_probs")
+    Rg = (tokens * N + 127) // 128 * 128
+    for sf in (P, P // 2 // 32 * 32):
+        outs = []
+        for deep in (1, 0):
+            knob("track_deep", deep)
+            cx = torch.zeros(heads * Rg, Cc, dtype=td, device="cuda")
+            _lib.check(lib.l4p_t2i_context(_stream(), dt, _p(pr), _p(st), _p(keys), _p(cx), N, P, Cc, heads, tokens, Rg, sf), "l4p_t2i_context")
+            torch.cuda.synchronize()
+            outs.append(cx)
+        assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().max()) > 0
+
+
 def test_folded_i2t_equals_projected_form(dev, mini, monkeypatch):
     """The tracker with the image-side projections of its cross attentions folded into the token side (default: i2t.q / i2t.out of
     the image -> token attention, t2i.k / final.k of the token -> image attentions) against the form that projects every image

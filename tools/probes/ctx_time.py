@@ -10,7 +10,7 @@ from l4p_amd.ops import _p, _stream
 lib = _lib.load()
 Cc, heads, tokens = 1408, 8, 6
 HT = heads * tokens
-for N, P in ((1, 2048), (8, 2048), (64, 2048)):
+for N, P in ((1, 2048), (8, 2048), (16, 2048), (23, 2048), (64, 2048)):
     sc = (3.0 * torch.randn(N * P, HT)).cuda()
     keys = torch.randn(N * P, Cc).bfloat16().cuda()
     nsp = (P + 255) // 256
