@@ -330,6 +330,8 @@ def c5_phase_times(net, batch, tasks, rank, world, group):
             # eighth of the queries over all windows (last-layer features as x1 would deliver them) on its own stream beside
             # the decoders of rank 0's chunk, the join, the replicated stitch of all windows (decoded as x2 would deliver them).
             # Everything a rank does except the three collectives.
+            nq8 = par.shard_track_inputs(data, 0, 8)[1]  # (the shard size selects the decoders' stream: parallel.decoder_stream)
+
             def rank0_of_8():
                 g8 = par.encode_local_windows(net, data, tasks, 0, 8, group)
                 tr = net.task_heads["track_2d"]
@@ -339,7 +341,7 @@ def c5_phase_times(net, batch, tasks, rank, world, group):
                 ts = par.cu_masked_stream(net.device, os.environ.get("L4P_C5_TRK_CUS"))
                 tr.clip_stream_override = [ts] if ts is not None else None
                 try:
-                    par.decode_encoded_windows_on(par.cu_masked_stream(net.device, os.environ.get("L4P_C5_DEC_CUS")), net, data, tasks, g8)
+                    par.decode_encoded_windows_on(par.decoder_stream(net.device, nq8), net, data, tasks, g8)
                     o = run_tracker(lasts, 0, 8)
                     tr.join_streams()
                     net.stitch_windows(windows, data, dense, strides)
@@ -375,7 +377,7 @@ def c5_phase_times(net, batch, tasks, rank, world, group):
                     tr.start_event = torch.cuda.Event()
                     tr.start_event.record(torch.cuda.current_stream())
                     try:
-                        par.decode_encoded_windows(net, data, tasks, g8)
+                        par.decode_encoded_windows_on(par.decoder_stream(net.device, nq8), net, data, tasks, g8)
                         o = run_tracker(lasts, 0, 8)
                         tr.join_streams()
                         seam_part()
@@ -393,6 +395,8 @@ def c5_phase_times(net, batch, tasks, rank, world, group):
                 res["emulated_rank0_of_8_seam_local_ms"] = round(r8s, 3)
             xb = par.seam_exchange_bytes(B, nwin, 8, tasks=tuple(dense))
             last_bytes = B * 2048 * net.cfg.dim * 4 * (nwin - (par.window_chunks(nwin, 8)[1][1] - par.window_chunks(nwin, 8)[1][0]))
+            ds = os.environ.get("L4P_C5_DEC_CUS")
+            res["emulated_rank_decoder_cus"] = (ds if ds is not None else ("0,160" if 0 < nq8 <= 16 else "")) or "all"
             res["exchange_bytes_per_rank_of_8"] = {"last_layer_features_all_gather": int(last_bytes),
                                                    "dense_gather_schedule": xb["gather_schedule"],
                                                    "dense_seam_local_schedule": xb["seam_local_schedule"]}

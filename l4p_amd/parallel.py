@@ -214,6 +214,22 @@ def cu_masked_stream(device: torch.device, spec: Optional[str]):
     return _MASKED_STREAMS[key]
 
 
+def decoder_stream(device: torch.device, nq_local: int):
+    """The stream the DPT decoders of a rank's windows are queued on while the tracker of its query shard runs beside them.
+    L4P_C5_DEC_CUS="first,count" confines them to those CUs ("" / "0": the whole chip, the main stream).  Default: 160 of the 256 CUs when
+    the shard is small (<= 16 queries).  Measured on one of eight ranks of configs[4] (tools/probes/c5_rank_timeline.py, c5_rank_masks.sh):
+    beside chip-filling conv kernels every small tracker kernel waits for a round of conv workgroups to end (~90 us each: 4 windows of the
+    recursion advance in the 28 ms the decoders take, the pieces simply add up: 89.4 ms); with 96 CUs kept free the tracker's chain runs
+    on unhindered while the decoders take 1.4x as long underneath it: 81 ms (160 - 176 CUs alike; 224: 87.6, 128: 83.4).  With 64
+    queries on one GPU the tracker's own kernels fill the chip and the mask only costs: off."""
+    spec = os.environ.get("L4P_C5_DEC_CUS")
+    if spec is None:
+        spec = "0,160" if 0 < nq_local <= 16 else ""
+    if spec in ("", "0"):
+        return None
+    return cu_masked_stream(device, spec)
+
+
 def decode_encoded_windows_on(stream, net, data: dict, tasks: List[str], groups: list) -> dict:
     """decode_encoded_windows queued on ``stream`` (after everything queued on the current stream so far); the current stream waits
     for it again before it returns (its host work is done then, its kernels are not), and the results are marked as used there."""
@@ -344,7 +360,7 @@ def forward_windows_sharded(net, data: dict, tasks: List[str], rank: Optional[in
         # while the host is still feeding the tracker's stream.  The tracker's streams wait for `ready` (the gathered features),
         # not for the decoders queued behind it.
         # (L4P_C5_DEC_CUS / L4P_C5_TRK_CUS = "first,count": CU-masked streams for the decoders / the tracker, see cu_masked_stream)
-        dec_stream = cu_masked_stream(net.device, os.environ.get("L4P_C5_DEC_CUS")) if track and dense else None
+        dec_stream = decoder_stream(net.device, nq_local) if track and dense else None
         local = decode_encoded_windows_on(dec_stream, net, data, tasks, groups) if dense else None
         del groups
         if track:

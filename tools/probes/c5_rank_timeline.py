@@ -60,7 +60,11 @@ def main():
             tr.start_event.record(torch.cuda.current_stream())
             try:
                 if order == "dec_first":
-                    par.decode_encoded_windows(net, data, tasks, g8)
+                    # C5_TL_DEC_CUS="first,count": the decoders on a stream confined to those CUs (l4p_stream_create_cu_mask)
+                    # (default: parallel.decoder_stream's choice for an 8-query shard)
+                    spec = os.environ.get("C5_TL_DEC_CUS")
+                    ds = par.decoder_stream(dev, 8) if spec is None else par.cu_masked_stream(dev, spec)
+                    par.decode_encoded_windows_on(ds, net, data, tasks, g8)
                     h2 = time.perf_counter()
                     o = run_tracker(lasts, 0, 8)
                     h3 = time.perf_counter()
