@@ -15,3 +15,4 @@ run "defaults (ln_rows16 = 1, maskdot_mfma = 1, attn64 = 1)" "L4P_NOP=1"
 run "ln_rows16 = 0 (one wave per LayerNorm3d row: the round-4 summation order)" "L4P_LN_ROWS16=0"
 run "maskdot_mfma = 0 (all-VALU mask product: float row, float dot products)" "L4P_MASKDOT_MFMA=0"
 run "attn64 = 0 (8-wave attention, rescale decided per 32 rows)" "L4P_ATTN64=0"
+run "L4P_TRACK_FOLD_L0 = 0 (later windows: layer 0's token -> image attention on projected keys / values, the form up to round 6)" "L4P_TRACK_FOLD_L0=0"
