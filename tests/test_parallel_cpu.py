@@ -210,3 +210,26 @@ def test_seam_local_messages_world3():
     b = seam_exchange_bytes(B=1, nwin=31, world=8)
     # every decoded window a rank does not own (27 x 12.9 MB) against one tail + K + 30 seam records
     assert 300e6 < b["gather_schedule"] < 400e6 and 1.5e6 < b["seam_local_schedule"] < 2.5e6, b
+
+
+def test_decoder_stream_choice(monkeypatch):
+    """parallel.decoder_stream: where the decoders of a rank's windows are queued while its query shard is tracked beside them -
+    160 CUs for a small shard (<= 16 queries), the whole chip otherwise; L4P_C5_DEC_CUS overrides ("" / "0": the whole chip)."""
+    import torch
+
+    from l4p_amd import parallel as par
+
+    seen = []
+    monkeypatch.setattr(par, "cu_masked_stream", lambda dev, spec: seen.append(spec) or ("stream", spec))
+    dev = torch.device("cpu")
+    monkeypatch.delenv("L4P_C5_DEC_CUS", raising=False)
+    assert par.decoder_stream(dev, 8) == ("stream", "0,160")
+    assert par.decoder_stream(dev, 16) == ("stream", "0,160")
+    assert par.decoder_stream(dev, 64) is None and par.decoder_stream(dev, 0) is None
+    monkeypatch.setenv("L4P_C5_DEC_CUS", "")
+    assert par.decoder_stream(dev, 8) is None
+    monkeypatch.setenv("L4P_C5_DEC_CUS", "0")
+    assert par.decoder_stream(dev, 8) is None
+    monkeypatch.setenv("L4P_C5_DEC_CUS", "32,128")
+    assert par.decoder_stream(dev, 64) == ("stream", "32,128")
+    assert seen == ["0,160", "0,160", "32,128"]
