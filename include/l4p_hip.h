@@ -197,6 +197,11 @@ typedef struct l4p_gemm_desc {
      * not resized - rounded to T exactly as l4p_upsample_trilinear would have stored it, without that tensor ever existing
      * (dpt_head.py:79-84: interpolate -> head conv).  l4p_conv3d_k3 returns L4P_E_INVALID for shapes the fused loader does not take. */
     int ups_hi, ups_wi;
+    /* Block-structured weights (dense GEMM, kw_cols > 0): output columns [g * kw_cols, (g + 1) * kw_cols) only meet the kw_len elements
+     * [g * kw_len, (g + 1) * kw_len) of the contraction - W is zero everywhere else (the tracker's folded projections, packing.py
+     * fold_i2t / fold_t2i: head h's 1408 columns meet head h's 88 inputs) - so a tile walks only the k-tiles that cover its group's
+     * window: the same sums bit for bit (the skipped tiles add zeros), 1/4 of the weight bytes.  kw_cols a multiple of 128. */
+    int kw_cols, kw_len;
 } l4p_gemm_desc;
 
 int l4p_gemm(l4p_stream stream, int dtype, const l4p_gemm_desc* d);

@@ -48,6 +48,7 @@ class GemmDesc(C.Structure):
         ("q_scale", C.c_float), ("tuning", C.c_int),
         ("w_gr", C.c_int), ("w_gs", C.c_longlong), ("b_gs", C.c_int), ("o_gs", C.c_longlong),
         ("ups_hi", C.c_int), ("ups_wi", C.c_int),
+        ("kw_cols", C.c_int), ("kw_len", C.c_int),
     ]
 
 

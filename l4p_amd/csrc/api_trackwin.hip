@@ -249,12 +249,20 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
     static const bool fold_v_env = !(getenv("L4P_TRACK_FOLD_T2I_V") && atoi(getenv("L4P_TRACK_FOLD_T2I_V")) == 0);
     const bool fold_v = fold_t2i_ok && fold_v_env && HTk == 48 && Cc % 128 == 0 && (Dh / g.sam_heads) % 8 == 0 && P % 32 == 0 && P >= 96 && P <= 4096;
     const long long RgT = (6ll * N + 127) / 128 * 128;  // rows of a head group of the context (and of `ta`, whose rows past 6 N are scratch)
+    // the folded weights are block-structured (packing.py fold_i2t / fold_t2i: head h's C columns meet head h's C/2/heads inputs only):
+    // their products walk only the k-tiles of a tile's head (l4p_gemm_desc.kw_cols: bit-identical, a quarter of the weight bytes)
+    static const bool kwin_env = !(getenv("L4P_TRACK_KWIN") && atoi(getenv("L4P_TRACK_KWIN")) == 0);
+    const int kw_cols = kwin_env && Cc % 128 == 0 ? Cc : 0, kw_len = Dh / g.sam_heads;
     // hs: rows [P/2, P) of keysP / keysT exist for track 0 only (a later window's layer 0): the scores of the two halves are two
     // row-mapped launches, the context product reads those rows from track 0, the projected values (fold_v off) are formed once and copied
     auto t2i_folded = [&](const void* tq, const std::string& prefix, const void* keysP, const void* keysT, void* ta, bool hs) {
         const long long KW = (long long)g.sam_heads * Cc;
         void* qf = c.T((long long)N * HTk + 128, Cc);  // Q' [N][HT][C] (+ slack rows under the last tile)
-        c.gemm(tq, 6ll * N, Dh, Dh, prefix + ".kfold", (int)KW, false, ACT_NONE, nullptr, 0, nullptr, qf, KW);
+        if (!c.rc && !c.dry) {
+            GemmParams pq = c.desc(tq, 6ll * N, Dh, Dh, prefix + ".kfold", (int)KW, false, ACT_NONE, nullptr, 0, nullptr, qf, KW);
+            pq.kw_cols = kw_cols, pq.kw_len = kw_len;
+            if (!c.rc) c.rc = launch_gemm(c.dt, 0, pq, c.st);
+        }
         float* sc = c.f32(NP, HTk);
         if (!c.rc && !c.dry) {
             GemmParams p;
@@ -392,10 +400,12 @@ int run(TW& c, const l4p_track_cfg& g, const float* enc_last, float* hist, const
                 void* vf = c.T(6ll * N * g.sam_heads, Cc);
                 float* cf = c.f32(6ll * N, g.sam_heads);
                 void* vt = c.T((long long)N * Cc + 128, HTp);    // V'^T [N][C][HTp] (+ slack rows)
-                const GemmParams tk[3] = {
+                GemmParams tk[3] = {
                     c.desc(ik, 6ll * N, Dh, Dh, lo + "i2t.qfold", (int)KW, false, ACT_NONE, nullptr, 0, pair ? kf32 : nullptr, pair ? nullptr : kf, KW),
                     c.desc(iv, 6ll * N, Dh, Dh, lo + "i2t.ofold", (int)KW, false, ACT_NONE, nullptr, 0, nullptr, vf, KW),
                     c.desc(ik, 6ll * N, Dh, Dh, lo + "i2t.cfold", g.sam_heads, false, ACT_NONE, nullptr, 0, cf, nullptr, g.sam_heads)};
+                tk[0].kw_cols = tk[1].kw_cols = kw_cols;
+                tk[0].kw_len = tk[1].kw_len = kw_len;
                 c.group(tk, 3);
                 if (pair && !c.rc && !c.dry) c.rc = launch_split_hilo(c.dt, kf32, kf, N, HT, Cc, c.st);
                 if (!c.rc && !c.dry) c.rc = launch_transpose_pad(c.dt, vf, vt, N, HT, Cc, HTp, c.st);

@@ -1091,7 +1091,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p_in, const int wg_i
 
     // split-K: this workgroup contracts k-tiles [kt0, kt1) only and leaves a float partial (see below)
     const int nsplit = p.splitk > 1 ? p.splitk : 1;
-    const int kt0 = (int)((long long)nk * ksplit / nsplit), kt1 = (int)((long long)nk * (ksplit + 1) / nsplit);
+    int kt0 = (int)((long long)nk * ksplit / nsplit), kt1 = (int)((long long)nk * (ksplit + 1) / nsplit);
+    if (MODE == 0 && p.kw_cols > 0) {  // block-structured weights (l4p_gemm_desc.kw_cols): only the k-tiles of this tile's column group
+        const int grp = n0 / p.kw_cols;
+        kt0 = (grp * p.kw_len) / BK;
+        kt1 = ((grp + 1) * p.kw_len + BK - 1) / BK;
+        kt1 = kt1 < nk ? kt1 : nk;
+    }
     if (STAGES >= 3) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)

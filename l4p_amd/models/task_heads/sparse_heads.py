@@ -24,7 +24,7 @@ from ...ops import _p, _stream
 def _gemm(a: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, n: int, *, bias=None, act=ACT_NONE, res1=None,
           out_f32: Optional[torch.Tensor] = None, out_T: Optional[torch.Tensor] = None, ldc: Optional[int] = None,
           a_map=None, c_map=None, a_off: int = 0, f32_off: int = 0, res_mod: int = 0, wgroup=None,
-          ldw: Optional[int] = None, ogroup: int = 0) -> None:
+          ldw: Optional[int] = None, ogroup: int = 0, kwin=None) -> None:
     """Raw l4p_gemm call with explicit strides / row maps (see include/l4p_hip.h)."""
     d = GemmDesc()
     es = a.element_size()
@@ -45,6 +45,8 @@ def _gemm(a: torch.Tensor, M: int, K: int, lda: int, w: torch.Tensor, n: int, *,
         d.w_gr, d.w_gs, d.b_gs = wgroup
         d.ldw = K if ldw is None else ldw
         d.o_gs = ogroup  # output elements between groups
+    if kwin is not None:    # block-structured weights: (output columns per group, contraction elements per group)
+        d.kw_cols, d.kw_len = kwin
     _lib.check(_lib.load().l4p_gemm(_stream(), ops.code_of(a.dtype), C.byref(d)), "l4p_gemm")
 
 
@@ -198,11 +200,13 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
         fold_v = (fold_t2i_ok and os.environ.get("L4P_TRACK_FOLD_T2I_V", "1") != "0" and HTk == 48 and Cc % 128 == 0 and (Dh // cfg.sam_heads) % 8 == 0 and P % 32 == 0
                   and 96 <= P <= 4096)
         RgT = (6 * N + 127) // 128 * 128
+        # the folded weights are block-structured (packing.py: head h's C columns meet head h's inputs only): l4p_gemm_desc.kw_cols
+        kwin = (Cc, Dh // cfg.sam_heads) if Cc % 128 == 0 and os.environ.get("L4P_TRACK_KWIN", "1") != "0" else None
 
         def t2i_folded(tq: torch.Tensor, prefix: str, keysP: torch.Tensor, keysT: torch.Tensor, hs: bool = False) -> torch.Tensor:
             KW = cfg.sam_heads * Cc
             qf = torch.empty((N * HTk + 128, Cc), dtype=td, device=dev)  # Q' [N][HT][C] (+ slack rows under the last tile)
-            _gemm(tq, 6 * N, Dh, Dh, self._w(prefix + ".kfold.w"), KW, out_T=qf, ldc=KW)
+            _gemm(tq, 6 * N, Dh, Dh, self._w(prefix + ".kfold.w"), KW, out_T=qf, ldc=KW, kwin=kwin)
             sc = torch.empty((N * P, HTk), **f32)
             if hs:  # rows [P/2, P) exist for track 0 only: two row-mapped launches over the half blocks
                 half = P // 2
@@ -289,8 +293,8 @@ class VideoMAETrack2DSamHead(torch.nn.Module):
                     kf32 = torch.empty((6 * N, KW), **f32)
                     _gemm(ik, 6 * N, Dh, Dh, self._w(lo + "i2t.qfold.w"), KW, out_f32=kf32, ldc=KW)
                 else:
-                    _gemm(ik, 6 * N, Dh, Dh, self._w(lo + "i2t.qfold.w"), KW, out_T=kf, ldc=KW)
-                _gemm(iv, 6 * N, Dh, Dh, self._w(lo + "i2t.ofold.w"), KW, out_T=vf, ldc=KW)
+                    _gemm(ik, 6 * N, Dh, Dh, self._w(lo + "i2t.qfold.w"), KW, out_T=kf, ldc=KW, kwin=kwin)
+                _gemm(iv, 6 * N, Dh, Dh, self._w(lo + "i2t.ofold.w"), KW, out_T=vf, ldc=KW, kwin=kwin)
                 _gemm(ik, 6 * N, Dh, Dh, self._w(lo + "i2t.cfold.w"), heads, out_f32=cf, ldc=heads)
                 if pair:
                     _lib.check(lib.l4p_split_hilo(_stream(), dt, _p(kf32), _p(kf), N, HT, Cc), "l4p_split_hilo")

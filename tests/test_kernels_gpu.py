@@ -661,6 +661,67 @@ def test_row_grouped_scores_deep_ring_equals_two_stages_bitwise(dev, knob, mode)
     check(outs[0], ref, mode, False)
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("M", [48, 384])
+def test_gemm_block_structured_weights_k_window_bitwise(dev, mode, M):
+    """l4p_gemm_desc.kw_cols / kw_len: the tracker's folded projections (packing.py fold_i2t / fold_t2i: head h's C output columns meet head
+    h's 88 inputs only, the weight is zero elsewhere) walk only the k-tiles of a tile's head - the same result bit for bit as the full
+    contraction, for one launch and for the grouped launch (qfold, ofold, cfold), in the three engines."""
+    import ctypes as C
+
+    from l4p_amd import _lib
+    from l4p_amd._lib import EPI_DENSE, GemmDesc
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    dt = ops.torch_dtype(mode)
+    heads, hd, Cc = 8, 88, 1408
+    K, N = heads * hd, heads * Cc
+    a = as_mode(rnd((M, K), 1500), mode)[0]
+
+    def folded(seed):
+        w = torch.zeros(N, K)
+        blk = rnd((heads, Cc, hd), seed, hd ** -0.5)
+        for h in range(heads):
+            w[h * Cc:(h + 1) * Cc, h * hd:(h + 1) * hd] = blk[h]
+        return ops.pad_rows(w.to(dt).cuda(), 128)
+
+    w1, w2 = folded(1501), folded(1502)
+    wc = ops.pad_rows(as_mode(rnd((heads, K), 1503), mode)[0], 128)
+
+    def descs(outs, kwin):
+        ds = (GemmDesc * 3)()
+        for i, (w, n, o) in enumerate(((w1, N, outs[0]), (w2, N, outs[1]), (wc, heads, outs[2]))):
+            d = ds[i]
+            d.A, d.lda, d.W, d.ldw = a.data_ptr(), K, w.data_ptr(), K
+            d.M, d.N, d.K, d.epi, d.ldc = M, n, K, EPI_DENSE, n
+            if o.dtype == torch.float32 and mode != L4P_F32:
+                d.out_f32 = o.data_ptr()
+            else:
+                d.out_T = o.data_ptr()
+            if kwin and i < 2:
+                d.kw_cols, d.kw_len = Cc, hd
+        return ds
+
+    def outs():
+        return [torch.zeros(M, N, dtype=dt, device="cuda"), torch.zeros(M, N, dtype=dt, device="cuda"), torch.zeros(M, heads, dtype=torch.float32, device="cuda")]
+
+    full, win, grp = outs(), outs(), outs()
+    df, dw, dg = descs(full, False), descs(win, True), descs(grp, True)
+    for i in range(3):
+        _lib.check(lib.l4p_gemm(st, mode, C.byref(df[i])), "l4p_gemm")
+        _lib.check(lib.l4p_gemm(st, mode, C.byref(dw[i])), "l4p_gemm(kw)")
+    if mode != L4P_F32:
+        _lib.check(lib.l4p_gemm_group(st, mode, dg, 3), "l4p_gemm_group(kw)")
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(full[i], win[i]), i
+        if mode != L4P_F32:
+            assert torch.equal(full[i], grp[i]), i
+    ref = a.float().cpu() @ w1[:N].float().cpu().t()
+    check(win[0], ref, mode, True)
+
+
 def test_cu_masked_stream_runs_kernels(dev):
     """l4p_stream_create_cu_mask (plumbing of the sharded long-video path, parallel.cu_masked_stream): a stream confined to 32 CUs
     runs the engine's kernels with the same result as the default stream, and can be released."""
