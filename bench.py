@@ -343,7 +343,8 @@ def c5_phase_times(net, batch, tasks, rank, world, group):
                 try:
                     par.decode_encoded_windows_on(par.decoder_stream(net.device, nq8), net, data, tasks, g8)
                     o = run_tracker(lasts, 0, 8)
-                    tr.join_streams()
+                    if not par.stitch_beside_tracker():
+                        tr.join_streams()
                     net.stitch_windows(windows, data, dense, strides)
                 finally:
                     tr.join_streams()
@@ -379,7 +380,8 @@ def c5_phase_times(net, batch, tasks, rank, world, group):
                     try:
                         par.decode_encoded_windows_on(par.decoder_stream(net.device, nq8), net, data, tasks, g8)
                         o = run_tracker(lasts, 0, 8)
-                        tr.join_streams()
+                        if not par.stitch_beside_tracker():
+                            tr.join_streams()
                         seam_part()
                     finally:
                         tr.join_streams()
