@@ -74,7 +74,7 @@ int l4p_stream_destroy(l4p_stream stream);
  *                S % 256 == 0): one wave per SIMD with 64 query rows (csrc/attention64.hip: every K / V^T fragment read feeds two
  *                MFMAs); 0 = the 8-wave form with 32 rows per wave.  Equal to the rounding of P, not bit for bit (the rare rescale of
  *                the deferred maximum is decided per wave).
- *   "gemm_skinny" (L4P_GEMM_SKINNY, default 1): l4p_gemm / l4p_gemm_group of the 16-bit engines on dense problems with M <= 64 rows and
+ *   "gemm_skinny" (L4P_GEMM_SKINNY, default 1): l4p_gemm / l4p_gemm_group of the 16-bit engines on dense problems with M <= 128 rows and
  *                K % 64 == 0 (the tracker's token-side projections of a rank's query shard) run one wave per 16 x 32 output block with
  *                the operands streamed from global memory into MFMA fragment registers (csrc/gemm_skinny.hpp); bit-identical to the
  *                LDS-staged kernels (0)

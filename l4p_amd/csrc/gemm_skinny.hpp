@@ -1,4 +1,4 @@
-// Dense GEMM for a HANDFUL of rows (M <= 64: the tracker's token-side projections of one rank's query shard - 6 prompt tokens per
+// Dense GEMM for a HANDFUL of rows (M <= 128: the tracker's token-side projections of one rank's query shard - 6 prompt tokens per
 // track, 8 tracks per rank of configs[4] -, sam/transformer.py:223-245, mask_decoder.py:160-180) against a weight matrix that comes
 // from HBM / the Infinity Cache every time.
 //

@@ -476,7 +476,7 @@ def test_gemm_group_equals_separate_launches(dev):
 
 @pytest.mark.parametrize("mode", [L4P_BF16, L4P_F16])
 def test_gemm_skinny_equals_the_staged_kernels_bitwise(dev, knob, mode):
-    """gemm_skinny.hpp (M <= 64 rows: one wave per 16 x 32 output block, operands streamed into fragment registers with hand-counted
+    """gemm_skinny.hpp (M <= 128 rows and at most 512 output blocks: one wave per 16 x 32 output block, operands streamed into fragment registers with hand-counted
     waits) against the LDS-staged kernels it replaces for the tracker's token-side projections: bit for bit - same MFMA, same k
     order, same epilogue - over the three unrolled contraction lengths and the generic loop, ragged M and N, bias / ReLU / GELU /
     float residual / both outputs, a strided A (the hyper-network's token rows), and a grouped launch; and against fp32."""
@@ -525,7 +525,7 @@ def test_gemm_skinny_equals_the_staged_kernels_bitwise(dev, knob, mode):
              (48, 1408, 2048, ACT_NONE, True, True), (48, 1408, 704, ACT_NONE, True, False), (48, 4096, 704, ACT_NONE, False, False),
              (8, 1408, 1408, ACT_RELU, False, False), (8, 176, 1408, ACT_NONE, False, True), (48, 8, 704, ACT_NONE, False, True),
              (5, 40, 128, ACT_GELU, False, True), (64, 1408, 1344, ACT_NONE, True, False), (33, 200, 2816, ACT_RELU, False, False),
-             (17, 96, 64, ACT_NONE, False, True)]
+             (17, 96, 64, ACT_NONE, False, True), (96, 1408, 1408, ACT_NONE, True, False), (128, 704, 2048, ACT_RELU, False, True)]
     for i, (M, N, K, act, res, both) in enumerate(cases):
         yT, yf, ref = run(M, N, K, act, res, both, 700 + 10 * i, skinny=1)
         zT, zf, _ = run(M, N, K, act, res, both, 700 + 10 * i, skinny=0)

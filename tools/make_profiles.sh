@@ -58,7 +58,7 @@ bash tools/drift_report.sh > $O/${TAG}_bf16_drift_ratios.txt 2>&1
 # round 6, one of eight ranks of configs[4]: its query shard's tracker kernel by kernel, with this round's token-side forms on / off, the
 # rank's timeline (decoders beside the tracker) and the decoders' CU mask
 python tools/prof_detail.py c5 2 8 > $O/${TAG}_c5_rank_shard_per_shape_event_profile.txt 2>/dev/null
-KNOBS="L4P_GEMM_SKINNY L4P_TRACK_DEEP L4P_TRACK_FOLD_L0 L4P_READOUT_WIDE" bash tools/probes/c5_tracker_alone.sh > $O/${TAG}_c5_rank_shard_knobs.txt 2>&1
+KNOBS="L4P_GEMM_SKINNY L4P_TRACK_DEEP L4P_TRACK_FOLD_L0 L4P_TRACK_KWIN L4P_READOUT_WIDE" bash tools/probes/c5_tracker_alone.sh > $O/${TAG}_c5_rank_shard_knobs.txt 2>&1
 bash tools/probes/c5_rank_masks.sh > $O/${TAG}_c5_rank_decoder_cu_masks.txt 2>&1
 bash tools/probes/c5_rank_timeline.sh > $O/${TAG}_c5_rank_timeline.txt 2>&1
 ls -la $O | grep ${TAG}_ | head -40
